@@ -1,0 +1,210 @@
+/*
+ * uis_numerics.h -- the canonical float32 arithmetic of the UIS-RNN decode path.
+ *
+ * The reference (uisrnn/uisrnn.py:388-453, uisrnn/loss_func.py:19-41) delegates
+ * its arithmetic to PyTorch CPU kernels whose summation order and libm are not
+ * part of its contract.  This header fixes ONE order of operations that both
+ * the gfx950 kernels (uisrnn_amd/csrc) and the CPU restatement (oracle/) follow,
+ * built only from IEEE-754 single operations (add, mul, div, fma, rint), so the
+ * two agree bit for bit; agreement with the reference itself is then a
+ * tolerance statement checked by tests/golden.
+ *
+ * Compile with -ffp-contract=off on both sides: every fused multiply-add here
+ * is an explicit fmaf().
+ *
+ * Plain C99 / HIP C++.  No dependencies.
+ */
+#ifndef UIS_NUMERICS_H_
+#define UIS_NUMERICS_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define UIS_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define UIS_HD static inline
+#endif
+
+/* Dense chains pad their contraction length to a multiple of this. */
+#define UIS_KBLOCK 16
+
+/*
+ * Contraction order of every dense chain (GRU gates, mean head, input
+ * projection).  acc starts at the bias; the K axis (zero padded to a multiple
+ * of 16) is walked block by block, and inside a block in the order
+ *   0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
+ * with one fmaf per element.  This is what a v_mfma_f32_16x16x4_f32 chain
+ * computes when every lane fetches four consecutive k of its row with one
+ * 16-byte load (register r of k-lane q holds k = 4q + r; MFMA number r sums
+ * q = 0..3 in order).
+ */
+UIS_HD int uis_korder(int i) { /* i in [0,16) -> k offset inside the block */
+  return ((i & 3) << 2) | (i >> 2);
+}
+
+UIS_HD float uis_fma(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fmaf(a, b, c);
+#else
+  return fmaf(a, b, c);
+#endif
+}
+
+UIS_HD float uis_rint(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_rintf(x);
+#else
+  return rintf(x);
+#endif
+}
+
+UIS_HD float uis_bits2f(uint32_t u) {
+  union { uint32_t u; float f; } c;
+  c.u = u;
+  return c.f;
+}
+
+UIS_HD uint32_t uis_f2bits(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  return c.u;
+}
+
+/* exp(x), |rel err| ~ 1e-7; clamps to [-87, 88] so the result stays normal. */
+UIS_HD float uis_expf(float x) {
+  if (x != x) return x;
+  if (x > 88.0f) x = 88.0f;
+  if (x < -87.0f) x = -87.0f;
+  float n = uis_rint(x * 1.44269504088896341f);
+  float r = uis_fma(n, -0.693145751953125f, x);          /* ln2 hi (exact in 12 bits) */
+  r = uis_fma(n, -1.42860682030941723212e-6f, r);        /* ln2 lo */
+  float p = 1.9841270e-4f;                                /* 1/5040 */
+  p = uis_fma(p, r, 1.3888889e-3f);                       /* 1/720 */
+  p = uis_fma(p, r, 8.3333333e-3f);                       /* 1/120 */
+  p = uis_fma(p, r, 4.1666667e-2f);                       /* 1/24 */
+  p = uis_fma(p, r, 1.6666667e-1f);                       /* 1/6 */
+  p = uis_fma(p, r, 0.5f);
+  p = uis_fma(p, r, 1.0f);
+  p = uis_fma(p, r, 1.0f);
+  int e = (int)n + 127;                                   /* in [2, 254] after the clamp */
+  return p * uis_bits2f((uint32_t)e << 23);
+}
+
+/* logistic function, as torch.sigmoid in the GRU gates (uisrnn/uisrnn.py:47). */
+UIS_HD float uis_sigmoidf(float x) {
+  return 1.0f / (1.0f + uis_expf(-x));
+}
+
+/* tanh(x): expm1 series on |x| <= 0.5, exp form outside. */
+UIS_HD float uis_tanhf(float x) {
+  if (x != x) return x;
+  float ax = x < 0.0f ? -x : x;
+  if (ax <= 0.5f) {
+    float y = x + x; /* |y| <= 1 */
+    float p = 2.5052108e-8f;              /* 1/11! */
+    p = uis_fma(p, y, 2.7557319e-7f);     /* 1/10! */
+    p = uis_fma(p, y, 2.7557319e-6f);     /* 1/9!  */
+    p = uis_fma(p, y, 2.4801587e-5f);     /* 1/8!  */
+    p = uis_fma(p, y, 1.9841270e-4f);     /* 1/7!  */
+    p = uis_fma(p, y, 1.3888889e-3f);     /* 1/6!  */
+    p = uis_fma(p, y, 8.3333333e-3f);     /* 1/5!  */
+    p = uis_fma(p, y, 4.1666667e-2f);     /* 1/4!  */
+    p = uis_fma(p, y, 1.6666667e-1f);     /* 1/3!  */
+    p = uis_fma(p, y, 0.5f);              /* 1/2!  */
+    p = uis_fma(p, y, 1.0f);
+    float em = p * y;                     /* expm1(2x) */
+    return em / (em + 2.0f);
+  }
+  float t = uis_expf(-2.0f * ax);
+  float v = (1.0f - t) / (1.0f + t);
+  return x < 0.0f ? -v : v;
+}
+
+/*
+ * One GRU unit (PyTorch gate order r|z|n; torch.gru called at
+ * uisrnn/uisrnn.py:47).  gi_* = W_i* inp + b_i*, gh_* = W_h* h + b_h*.
+ */
+UIS_HD float uis_gru_unit(float gi_r, float gi_z, float gi_n,
+                          float gh_r, float gh_z, float gh_n, float h) {
+  float r = uis_sigmoidf(gi_r + gh_r);
+  float z = uis_sigmoidf(gi_z + gh_z);
+  float n = uis_tanhf(gi_n + r * gh_n);
+  return (h - n) * z + n;
+}
+
+/*
+ * Weighted squared error of uisrnn/loss_func.py:19-41 for one row:
+ * term_d = ((a_d - b_d) * (a_d - b_d)) * w_d, summed by uis_mse_finish over the
+ * canonical tree below, then the reference's mean * D * 1 / nnz with
+ * nnz = ((a_0 - b_0)^2 != 0) (quirk: exact zero in dim 0 gives inf or nan).
+ */
+UIS_HD float uis_mse_term(float a, float b, float w) {
+  float d = a - b;
+  float s = d * d;
+  return s * w;
+}
+
+UIS_HD float uis_mse_finish(float sum, float first_sq, int dim) {
+  float fd = (float)dim;
+  float mean = sum / fd;
+  float v = (mean * fd) * 1.0f;
+  float nnz = (first_sq != 0.0f) ? 1.0f : 0.0f;
+  return v / nnz;
+}
+
+/*
+ * Canonical summation tree of the D weighted terms: 64 virtual lanes; lane j
+ * owns d = 256*q + 4*j + i (i = 0..3, q = 0,1,...) and adds them in increasing
+ * d starting from 0.0f; then an xor butterfly with offsets 32,16,8,4,2,1
+ * (lane j adds lane j^off).  Host-side helper; the kernels implement the same
+ * tree with DPP/shuffles.
+ */
+#if !defined(__HIP_DEVICE_COMPILE__)
+static inline float uis_tree_sum(const float* term, int dim) {
+  float lane[64];
+  for (int j = 0; j < 64; ++j) {
+    float acc = 0.0f;
+    for (int base = 4 * j; base < dim; base += 256)
+      for (int i = 0; i < 4 && base + i < dim; ++i) acc = acc + term[base + i];
+    lane[j] = acc;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    float nxt[64];
+    for (int j = 0; j < 64; ++j) nxt[j] = lane[j] + lane[j ^ off];
+    for (int j = 0; j < 64; ++j) lane[j] = nxt[j];
+  }
+  return lane[0];
+}
+#endif
+
+/*
+ * Running "mean" update of uisrnn/uisrnn.py:425-429: n = frames assigned to the
+ * cluster BEFORE this one.  Three separately rounded float ops, as torch does.
+ */
+UIS_HD float uis_mean_update(float old_mean, float m, int n) {
+  float a = old_mean * (float)(n - 1);
+  float b = a + m;
+  return b / (float)n;
+}
+
+/*
+ * Step loss: float32( float64(mse) - prior ), prior in float64
+ * (uisrnn/uisrnn.py:415-420,444-446; numpy in-place subtract on a 0-d f32 array).
+ */
+UIS_HD float uis_step_loss(float mse, double prior) {
+  return (float)((double)mse - prior);
+}
+
+/* Total order on scores for the prune: ascending value, then ascending index. */
+UIS_HD uint32_t uis_score_key(float s) {
+  if (s == 0.0f) s = 0.0f; /* -0 == +0 */
+  uint32_t u = uis_f2bits(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+UIS_HD int uis_isfinite(float s) {
+  return (uis_f2bits(s) & 0x7f800000u) != 0x7f800000u;
+}
+
+#endif /* UIS_NUMERICS_H_ */

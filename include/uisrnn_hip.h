@@ -1,0 +1,168 @@
+/*
+ * uisrnn_hip.h -- C ABI of the MI355X (gfx950) UIS-RNN beam-search decoder.
+ *
+ * This is the drop-in boundary for ONE path of google/uis-rnn: the inference
+ * beam search  UISRNN.predict -> predict_single -> _calculate_score ->
+ * _update_beam_state -> CoreRNN / BeamState
+ * (reference: uisrnn/uisrnn.py:388-590, uisrnn/loss_func.py:19-41).
+ *
+ * The reference has no FFI of its own -- its boundary is the Python method set
+ * on uisrnn.UISRNN (uisrnn/__init__.py:26-30).  A maintainer binds these entry
+ * points with ctypes (cffi is the other option) exactly as uisrnn_amd/_capi.py
+ * does; INTEGRATION.md shows the stub.  Plain C types only: no torch, no HIP
+ * types in the signatures.  Device pointers are passed as void* / float*.
+ *
+ * Threading: a handle is bound to one HIP device and is not thread-safe; use
+ * one handle per thread / per rank.  All calls are blocking.
+ * Errors: every function returns UIS_OK (0) or a negative uis_status;
+ * uis_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef UISRNN_HIP_H_
+#define UISRNN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UIS_ABI_VERSION 1
+
+typedef enum uis_status {
+  UIS_OK = 0,
+  UIS_ERR_INVALID_ARG = -1,   /* NULL pointer, non-positive size, bad option      */
+  UIS_ERR_DIM_MISMATCH = -2,  /* maps to the reference's ValueError (uisrnn.py:518-521) */
+  UIS_ERR_NO_DEVICE = -3,     /* no usable gfx950 device / HIP runtime failure at create */
+  UIS_ERR_HIP = -4,           /* a HIP call failed during decode                   */
+  UIS_ERR_OOM = -5,           /* device or host allocation failed                  */
+  UIS_ERR_CLUSTER_CAP = -6,   /* a surviving hypothesis needed more than max_clusters
+                                 clusters; labels_out of the flagged utterances are
+                                 invalid -- retry with a larger cap (the Python host does) */
+  UIS_ERR_UNSUPPORTED = -7    /* option combination outside the built kernels' range */
+} uis_status;
+
+/*
+ * Model parameters consumed by predict (reference: UISRNN.__init__ / load,
+ * uisrnn/uisrnn.py:83-107,149-170; CoreRNN, uisrnn/uisrnn.py:32-52).
+ * All arrays are host pointers, float32, row-major, PyTorch layouts; they are
+ * copied at uis_create and need not outlive it.
+ */
+typedef struct uis_model_desc {
+  int32_t observation_dim;            /* D  (args.observation_dim)            */
+  int32_t rnn_hidden_size;            /* H  (args.rnn_hidden_size)            */
+  int32_t rnn_depth;                  /* number of GRU layers                 */
+  int32_t reserved0;
+  const float* const* gru_weight_ih;  /* [depth] -> (3H, D) layer 0, (3H, H) above; gates r|z|n */
+  const float* const* gru_weight_hh;  /* [depth] -> (3H, H)                   */
+  const float* const* gru_bias_ih;    /* [depth] -> (3H)                      */
+  const float* const* gru_bias_hh;    /* [depth] -> (3H)                      */
+  const float* linear_mean1_weight;   /* (H, H)                               */
+  const float* linear_mean1_bias;     /* (H)                                  */
+  const float* linear_mean2_weight;   /* (D, H)                               */
+  const float* linear_mean2_bias;     /* (D)                                  */
+  const float* rnn_init_hidden;       /* (depth, H)  (rnn_init_hidden[:,0,:]) */
+  const float* sigma2;                /* (D)                                  */
+  double transition_bias;             /* p0 in (0,1)                          */
+  double crp_alpha;                   /* alpha > 0                            */
+} uis_model_desc;
+
+/* Inference options (reference: uisrnn/arguments.py:172-193). */
+typedef struct uis_decode_opts {
+  int32_t beam_size;       /* args.beam_size       (>= 1)                     */
+  int32_t look_ahead;      /* args.look_ahead      (>= 1)                     */
+  int32_t test_iteration;  /* args.test_iteration  (>= 1)                     */
+  int32_t max_clusters;    /* per-hypothesis cluster cap; 0 = default (16)    */
+  uint32_t flags;          /* UIS_FLAG_*                                      */
+  int32_t reserved[3];
+} uis_decode_opts;
+
+#define UIS_FLAG_NO_DEDUP   0x1u /* run one RNN row per surviving hypothesis even when
+                                    several share the same cluster state (A/B switch;
+                                    results are bit-identical either way)            */
+#define UIS_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of via hipGraph  */
+#define UIS_FLAG_PROFILE    0x4u /* bracket every kernel with HIP events on the
+                                    decode stream and fill uis_stats.kernel_*      */
+
+#define UIS_N_KERNELS 8
+typedef struct uis_stats {
+  int32_t n_steps;                    /* lock-step decode steps executed            */
+  int32_t max_clusters_seen;          /* max clusters in any surviving hypothesis   */
+  int64_t rnn_rows;                   /* RNN rows actually evaluated (after dedup)  */
+  int64_t rnn_rows_nodedup;           /* rows without dedup = surviving hypotheses  */
+  int64_t candidates;                 /* candidates scored                           */
+  double  decode_ms;                  /* device time of the whole decode (events)   */
+  double  kernel_ms[UIS_N_KERNELS];   /* UIS_FLAG_PROFILE: summed per kernel class  */
+  int64_t kernel_launches[UIS_N_KERNELS];
+  int32_t n_overflow;                 /* utterances that hit UIS_ERR_CLUSTER_CAP    */
+  int32_t reserved;
+} uis_stats;
+
+/* kernel classes for uis_stats.kernel_ms */
+enum {
+  UIS_K_INPUT_PROJ = 0, /* W_ih0 x + b over all frames, new-cluster MSE      */
+  UIS_K_SELECT = 1,     /* score + prune + commit                           */
+  UIS_K_GRU = 2,        /* hidden-side GRU GEMM + gates                     */
+  UIS_K_HEAD1 = 3,      /* linear_mean1 + relu                              */
+  UIS_K_HEAD2 = 4,      /* linear_mean2 + running-mean update               */
+  UIS_K_BACKTRACE = 5,  /* back-pointer walk -> labels                      */
+  UIS_K_UPPER_IN = 6,   /* input-side GEMM of GRU layers >= 1               */
+  UIS_K_EXPAND = 7      /* look_ahead >= 2: intermediate sub-step expansion */
+};
+
+typedef struct uis_handle uis_handle;
+
+int32_t uis_abi_version(void);
+
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+int32_t uis_device_count(void);
+
+/*
+ * Create a decoder on HIP device `device`: uploads the weights in the padded
+ * layouts the kernels use and precomputes the per-model constants
+ * (m0, h1) = CoreRNN(0, rnn_init_hidden)  (uisrnn/uisrnn.py:435-439) and
+ * w = 1 / (2 sigma2)  (uisrnn/uisrnn.py:414).
+ */
+int32_t uis_create(const uis_model_desc* desc, int32_t device, uis_handle** out);
+
+void uis_destroy(uis_handle* h);
+
+/*
+ * Decode n_utt utterances (reference: UISRNN.predict over a list,
+ * uisrnn/uisrnn.py:564-590; each one UISRNN.predict_single, :479-562).
+ *   frames   : host, float32, [offsets[n_utt], D] row-major (utterance u owns rows
+ *              offsets[u] .. offsets[u+1]); the caller has already cast the
+ *              reference's float64 input to float32 (uisrnn.py:525-526)
+ *   offsets  : host, int64, [n_utt + 1], offsets[0] == 0, non-decreasing
+ *   labels_out : host, int32, [offsets[n_utt]]  -- predicted cluster id per frame
+ *              (trace[-N:] of the best hypothesis, uisrnn.py:561)
+ *   scores_out : host, float32, [n_utt] or NULL -- neg_likelihood of the best hypothesis
+ *   stats    : optional
+ * Empty utterances (N == 0) are allowed and produce no labels.
+ */
+int32_t uis_decode(uis_handle* h, const float* frames, const int64_t* offsets,
+                   int32_t n_utt, const uis_decode_opts* opts,
+                   int32_t* labels_out, float* scores_out, uis_stats* stats);
+
+/*
+ * Same, with frames / labels_out / scores_out resident on the handle's device
+ * (HBM pointers, e.g. torch tensor data_ptr()); offsets stays on the host.
+ * No PCIe transfer of the frame stream happens inside the call.
+ */
+int32_t uis_decode_device(uis_handle* h, const float* d_frames, const int64_t* offsets,
+                          int32_t n_utt, const uis_decode_opts* opts,
+                          int32_t* d_labels_out, float* d_scores_out, uis_stats* stats);
+
+/*
+ * After a decode: per-utterance overflow flags (1 = hit the cluster cap) and
+ * the full final beam scores, for the host-side retry loop and the parity tests.
+ *   overflow_out : host int32 [n_utt] or NULL
+ *   beam_scores_out : host float32 [n_utt * beam_size] or NULL (+inf padded)
+ */
+int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out);
+
+const char* uis_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UISRNN_HIP_H_ */

@@ -1,0 +1,322 @@
+"""ctypes binding of the C ABI declared in include/uisrnn_hip.h.
+
+The reference has no FFI; its boundary is the Python method set on
+``uisrnn.UISRNN`` (uisrnn/__init__.py:26-30, uisrnn/uisrnn.py:479-623).  This
+module is the thin layer between that Python surface (uisrnn_amd/uisrnn.py)
+and ``libuisrnn_hip.so``.  There is deliberately NO fallback: if the HIP
+library is missing or no gfx950 device is usable, the calls raise.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libuisrnn_hip.so')
+
+UIS_OK = 0
+UIS_ERR_INVALID_ARG = -1
+UIS_ERR_DIM_MISMATCH = -2
+UIS_ERR_NO_DEVICE = -3
+UIS_ERR_HIP = -4
+UIS_ERR_OOM = -5
+UIS_ERR_CLUSTER_CAP = -6
+UIS_ERR_UNSUPPORTED = -7
+
+UIS_FLAG_NO_DEDUP = 0x1
+UIS_FLAG_NO_GRAPH = 0x2
+UIS_FLAG_PROFILE = 0x4
+
+UIS_N_KERNELS = 8
+KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
+                'upper_in', 'expand')
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_fpp = ctypes.POINTER(_fp)
+
+
+class ModelDesc(ctypes.Structure):
+  """struct uis_model_desc (include/uisrnn_hip.h)."""
+  _fields_ = [
+      ('observation_dim', ctypes.c_int32),
+      ('rnn_hidden_size', ctypes.c_int32),
+      ('rnn_depth', ctypes.c_int32),
+      ('reserved0', ctypes.c_int32),
+      ('gru_weight_ih', _fpp),
+      ('gru_weight_hh', _fpp),
+      ('gru_bias_ih', _fpp),
+      ('gru_bias_hh', _fpp),
+      ('linear_mean1_weight', _fp),
+      ('linear_mean1_bias', _fp),
+      ('linear_mean2_weight', _fp),
+      ('linear_mean2_bias', _fp),
+      ('rnn_init_hidden', _fp),
+      ('sigma2', _fp),
+      ('transition_bias', ctypes.c_double),
+      ('crp_alpha', ctypes.c_double),
+  ]
+
+
+class DecodeOpts(ctypes.Structure):
+  """struct uis_decode_opts (include/uisrnn_hip.h)."""
+  _fields_ = [
+      ('beam_size', ctypes.c_int32),
+      ('look_ahead', ctypes.c_int32),
+      ('test_iteration', ctypes.c_int32),
+      ('max_clusters', ctypes.c_int32),
+      ('flags', ctypes.c_uint32),
+      ('reserved', ctypes.c_int32 * 3),
+  ]
+
+
+class Stats(ctypes.Structure):
+  """struct uis_stats (include/uisrnn_hip.h)."""
+  _fields_ = [
+      ('n_steps', ctypes.c_int32),
+      ('max_clusters_seen', ctypes.c_int32),
+      ('rnn_rows', ctypes.c_int64),
+      ('rnn_rows_nodedup', ctypes.c_int64),
+      ('candidates', ctypes.c_int64),
+      ('decode_ms', ctypes.c_double),
+      ('kernel_ms', ctypes.c_double * UIS_N_KERNELS),
+      ('kernel_launches', ctypes.c_int64 * UIS_N_KERNELS),
+      ('n_overflow', ctypes.c_int32),
+      ('reserved', ctypes.c_int32),
+  ]
+
+  def as_dict(self):
+    return {
+        'n_steps': self.n_steps,
+        'max_clusters_seen': self.max_clusters_seen,
+        'rnn_rows': self.rnn_rows,
+        'rnn_rows_nodedup': self.rnn_rows_nodedup,
+        'candidates': self.candidates,
+        'decode_ms': self.decode_ms,
+        'kernel_ms': {n: self.kernel_ms[i] for i, n in enumerate(KERNEL_NAMES)},
+        'kernel_launches': {
+            n: self.kernel_launches[i] for i, n in enumerate(KERNEL_NAMES)},
+        'n_overflow': self.n_overflow,
+    }
+
+
+def _f32(a):
+  return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _ptr(a):
+  return a.ctypes.data_as(_fp)
+
+
+def make_desc(params):
+  """Build a ModelDesc from a parameter dict (see uisrnn_amd/weights.py).
+
+  Returns (desc, keepalive): keepalive holds the numpy buffers the struct
+  points into and must outlive every use of desc.
+  """
+  depth = int(params['rnn_depth'])
+  keep = []
+
+  def arr(a, shape):
+    a = _f32(a)
+    if tuple(a.shape) != tuple(shape):
+      raise ValueError('parameter has shape {} but {} is required'.format(
+          a.shape, shape))
+    keep.append(a)
+    return a
+
+  dim = int(params['observation_dim'])
+  hid = int(params['rnn_hidden_size'])
+
+  def ptr_array(key, shapes):
+    arrs = [arr(params[key][l], shapes[l]) for l in range(depth)]
+    pa = (_fp * depth)(*[_ptr(a) for a in arrs])
+    keep.append(pa)
+    return ctypes.cast(pa, _fpp)
+
+  in_dims = [dim] + [hid] * (depth - 1)
+  desc = ModelDesc()
+  desc.observation_dim = dim
+  desc.rnn_hidden_size = hid
+  desc.rnn_depth = depth
+  desc.gru_weight_ih = ptr_array(
+      'gru_weight_ih', [(3 * hid, in_dims[l]) for l in range(depth)])
+  desc.gru_weight_hh = ptr_array(
+      'gru_weight_hh', [(3 * hid, hid)] * depth)
+  desc.gru_bias_ih = ptr_array('gru_bias_ih', [(3 * hid,)] * depth)
+  desc.gru_bias_hh = ptr_array('gru_bias_hh', [(3 * hid,)] * depth)
+  desc.linear_mean1_weight = _ptr(arr(params['linear_mean1_weight'], (hid, hid)))
+  desc.linear_mean1_bias = _ptr(arr(params['linear_mean1_bias'], (hid,)))
+  desc.linear_mean2_weight = _ptr(arr(params['linear_mean2_weight'], (dim, hid)))
+  desc.linear_mean2_bias = _ptr(arr(params['linear_mean2_bias'], (dim,)))
+  desc.rnn_init_hidden = _ptr(arr(params['rnn_init_hidden'], (depth, hid)))
+  desc.sigma2 = _ptr(arr(params['sigma2'], (dim,)))
+  desc.transition_bias = float(params['transition_bias'])
+  desc.crp_alpha = float(params['crp_alpha'])
+  return desc, keep
+
+
+def make_opts(beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+  opts = DecodeOpts()
+  opts.beam_size = int(beam_size)
+  opts.look_ahead = int(look_ahead)
+  opts.test_iteration = int(test_iteration)
+  opts.max_clusters = int(max_clusters)
+  opts.flags = int(flags)
+  return opts
+
+
+class HipLibraryError(RuntimeError):
+  """The HIP decoder library is missing, failed to load or reported an error."""
+
+
+_lib = None
+
+
+def load_library(path=None):
+  """dlopen libuisrnn_hip.so and declare every entry point of the header."""
+  global _lib
+  if _lib is not None and path is None:
+    return _lib
+  path = path or LIB_PATH
+  if not os.path.exists(path):
+    raise HipLibraryError(
+        '{} not found: build it with `python -m uisrnn_amd.build` (hipcc, '
+        'gfx950). There is no CPU fallback for the decode path.'.format(path))
+  lib = ctypes.CDLL(path)
+  i32 = ctypes.c_int32
+  i32p = ctypes.POINTER(ctypes.c_int32)
+  i64p = ctypes.POINTER(ctypes.c_int64)
+  lib.uis_abi_version.restype = i32
+  lib.uis_abi_version.argtypes = []
+  lib.uis_device_count.restype = i32
+  lib.uis_device_count.argtypes = []
+  lib.uis_create.restype = i32
+  lib.uis_create.argtypes = [
+      ctypes.POINTER(ModelDesc), i32, ctypes.POINTER(ctypes.c_void_p)]
+  lib.uis_destroy.restype = None
+  lib.uis_destroy.argtypes = [ctypes.c_void_p]
+  lib.uis_decode.restype = i32
+  lib.uis_decode.argtypes = [
+      ctypes.c_void_p, _fp, i64p, i32, ctypes.POINTER(DecodeOpts), i32p, _fp,
+      ctypes.POINTER(Stats)]
+  lib.uis_decode_device.restype = i32
+  lib.uis_decode_device.argtypes = [
+      ctypes.c_void_p, ctypes.c_void_p, i64p, i32, ctypes.POINTER(DecodeOpts),
+      ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Stats)]
+  lib.uis_last_decode_info.restype = i32
+  lib.uis_last_decode_info.argtypes = [ctypes.c_void_p, i32p, _fp]
+  lib.uis_last_error.restype = ctypes.c_char_p
+  lib.uis_last_error.argtypes = []
+  if path == LIB_PATH:
+    _lib = lib
+  return lib
+
+
+EXPORTED_SYMBOLS = (
+    'uis_abi_version', 'uis_device_count', 'uis_create', 'uis_destroy',
+    'uis_decode', 'uis_decode_device', 'uis_last_decode_info',
+    'uis_last_error')
+
+
+def last_error(lib):
+  msg = lib.uis_last_error()
+  return msg.decode('utf-8', 'replace') if msg else ''
+
+
+class Decoder:
+  """Owns one uis_handle (one HIP device)."""
+
+  def __init__(self, params, device=0):
+    self._lib = load_library()
+    self.params = params
+    self.observation_dim = int(params['observation_dim'])
+    desc, keep = make_desc(params)
+    handle = ctypes.c_void_p()
+    rc = self._lib.uis_create(ctypes.byref(desc), int(device),
+                              ctypes.byref(handle))
+    del keep
+    if rc != UIS_OK:
+      raise HipLibraryError('uis_create failed ({}): {}'.format(
+          rc, last_error(self._lib)))
+    self._handle = handle
+    self.device = int(device)
+
+  def close(self):
+    if getattr(self, '_handle', None):
+      self._lib.uis_destroy(self._handle)
+      self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def _check(self, rc, what):
+    if rc == UIS_OK or rc == UIS_ERR_CLUSTER_CAP:
+      return rc
+    msg = last_error(self._lib)
+    if rc == UIS_ERR_DIM_MISMATCH:
+      raise ValueError(msg)
+    raise HipLibraryError('{} failed ({}): {}'.format(what, rc, msg))
+
+  def decode(self, frames, offsets, beam_size, look_ahead, test_iteration,
+             max_clusters=0, flags=0, want_beam_scores=False):
+    """Decode packed host utterances.
+
+    Args:
+      frames: float32 [sum N, D] C-contiguous.
+      offsets: int64 [U + 1].
+    Returns:
+      dict with labels (int32 [sum N]), scores (float32 [U]), overflow
+      (int32 [U]), stats (dict) and optionally beam_scores [U, beam_size].
+    """
+    frames = np.ascontiguousarray(frames, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_utt = offsets.shape[0] - 1
+    total = int(offsets[-1])
+    if frames.ndim != 2 or frames.shape[0] != total:
+      raise ValueError('frames must be [offsets[-1], D]')
+    if total and frames.shape[1] != self.observation_dim:
+      raise ValueError('frames do not match observation_dim')
+    labels = np.empty(total, dtype=np.int32)
+    scores = np.empty(n_utt, dtype=np.float32)
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags)
+    stats = Stats()
+    rc = self._lib.uis_decode(
+        self._handle, frames.ctypes.data_as(_fp),
+        offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        ctypes.byref(opts), labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        scores.ctypes.data_as(_fp), ctypes.byref(stats))
+    rc = self._check(rc, 'uis_decode')
+    out = {'labels': labels, 'scores': scores, 'stats': stats.as_dict(),
+           'status': rc}
+    overflow = np.zeros(n_utt, dtype=np.int32)
+    beam_scores = (np.empty((n_utt, int(beam_size)), dtype=np.float32)
+                   if want_beam_scores else None)
+    rc2 = self._lib.uis_last_decode_info(
+        self._handle, overflow.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        beam_scores.ctypes.data_as(_fp) if want_beam_scores else None)
+    self._check(rc2, 'uis_last_decode_info')
+    out['overflow'] = overflow
+    if want_beam_scores:
+      out['beam_scores'] = beam_scores
+    return out
+
+  def decode_device(self, d_frames_ptr, offsets, beam_size, look_ahead,
+                    test_iteration, d_labels_ptr, d_scores_ptr, max_clusters=0,
+                    flags=0):
+    """Decode with frames/labels/scores already resident in HBM (raw pointers)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_utt = offsets.shape[0] - 1
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags)
+    stats = Stats()
+    rc = self._lib.uis_decode_device(
+        self._handle, ctypes.c_void_p(int(d_frames_ptr)),
+        offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        ctypes.byref(opts), ctypes.c_void_p(int(d_labels_ptr)),
+        ctypes.c_void_p(int(d_scores_ptr) if d_scores_ptr else None),
+        ctypes.byref(stats))
+    rc = self._check(rc, 'uis_decode_device')
+    return {'stats': stats.as_dict(), 'status': rc}
