@@ -1,0 +1,110 @@
+"""GPU parity: the HIP decoder against the CPU oracle, bit for bit.
+
+Every call goes through the C ABI (uisrnn_amd._capi -> libuisrnn_hip.so).
+Labels are compared exactly; scores and the whole final beam are compared as
+float32 BIT PATTERNS -- both sides follow include/uis_numerics.h, so any
+difference is a bug, not round-off.  (Agreement of the oracle with the
+reference itself is tests/test_oracle_golden.py, run on CPU; relative
+tolerance 1e-4 there, as BASELINE.json's north_star states.)
+"""
+
+import numpy as np
+import pytest
+
+import golden_util
+from uisrnn_amd import _capi
+from uisrnn_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+  return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
+             flags=0, max_clusters=0, decoder=None):
+  ref = oracle_lib.decode(params, seqs, beam_size, look_ahead, test_iteration,
+                          n_threads=8)
+  dec = decoder or _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  cap = max(int(ref['max_clusters'].max()) if len(seqs) else 1, 1)
+  out = dec.decode(frames, offsets, beam_size, look_ahead, test_iteration,
+                   max_clusters=max_clusters or max(cap, 4), flags=flags,
+                   want_beam_scores=True)
+  assert out['status'] == 0
+  assert not out['overflow'].any()
+  for u in range(len(seqs)):
+    got = out['labels'][offsets[u]:offsets[u + 1]]
+    assert np.array_equal(got, ref['labels'][u]), 'labels differ, utterance %d' % u
+  assert np.array_equal(_bits(out['scores']), _bits(ref['scores']))
+  assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  assert out['stats']['max_clusters_seen'] == cap
+  return out, ref
+
+
+@pytest.mark.parametrize('name', ['tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
+                                  'd20_h24_depth3'])
+def test_golden_cases_bit_exact(name, oracle_lib):
+  case = golden_util.load_case(name)
+  dec = _capi.Decoder(case['params'])
+  for run in case['runs']:
+    if run['look_ahead'] != 1:
+      continue
+    out, _ = _compare(case['params'], case['seqs'], run['beam_size'], 1,
+                      run['test_iteration'], oracle_lib, decoder=dec)
+    # and against the reference's own outputs stored in the fixture
+    offsets = np.cumsum([0] + [len(s) for s in case['seqs']])
+    for u in range(len(case['seqs'])):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]],
+                            run['labels'][u])
+    np.testing.assert_allclose(out['scores'], run['best'], rtol=1e-4)
+
+
+def test_tracker_d256_bit_exact(oracle_lib):
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(2000, 12, [50, 80, 31, 64, 17, 100, 1, 2, 77,
+                                             45, 90, 33], 256)
+  out, _ = _compare(params, seqs, 10, 1, 2, oracle_lib)
+  assert out['stats']['rnn_rows'] <= out['stats']['rnn_rows_nodedup']
+
+
+def test_dedup_flag_is_bit_identical(oracle_lib):
+  params = synth.tracker_params(256, 512, 1, seed=3)
+  seqs, _ = synth.make_utterances(3000, 6, [40, 55, 23, 64, 9, 70], 256)
+  a, _ = _compare(params, seqs, 10, 1, 2, oracle_lib)
+  b, _ = _compare(params, seqs, 10, 1, 2, oracle_lib,
+                  flags=_capi.UIS_FLAG_NO_DEDUP)
+  assert b['stats']['rnn_rows'] == b['stats']['rnn_rows_nodedup']
+  assert a['stats']['rnn_rows'] < b['stats']['rnn_rows']
+
+
+def _many_cluster_case():
+  """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
+  from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel
+  params = weights.init_params(64, 48, 1, sigma2=0.5, transition_bias=0.5,
+                               crp_alpha=50.0, seed=5)
+  rng = np.random.default_rng(6)
+  return params, rng
+
+
+def test_random_weights_many_clusters(oracle_lib):
+  """Cluster-cap stress: far more clusters than the default table size."""
+  params, rng = _many_cluster_case()
+  seqs = [rng.standard_normal((n, 64)) for n in (40, 45, 12)]
+  _, ref = _compare(params, seqs, 8, 1, 2, oracle_lib)
+  assert ref['max_clusters'].max() > 16
+
+
+def test_cluster_cap_is_reported(oracle_lib):
+  params, rng = _many_cluster_case()
+  seqs = [rng.standard_normal((40, 64)), rng.standard_normal((3, 64))]
+  ref = oracle_lib.decode(params, seqs, 8, 1, 2)
+  assert ref['max_clusters'][0] > 8 and ref['max_clusters'][1] <= 8
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  out = dec.decode(frames, offsets, 8, 1, 2, max_clusters=8)
+  assert out['status'] == _capi.UIS_ERR_CLUSTER_CAP
+  assert out['overflow'].tolist() == [1, 0]
+  # the utterance that fit is still decoded correctly
+  assert np.array_equal(out['labels'][offsets[1]:offsets[2]], ref['labels'][1])

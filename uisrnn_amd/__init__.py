@@ -1,1 +1,12 @@
-"""MI355X-native UIS-RNN beam-search decoder (drop-in for uisrnn.UISRNN.predict)."""
+"""MI355X-native UIS-RNN beam-search decoder.
+
+Drop-in for the inference path of google/uis-rnn: the names re-exported here
+are the decode-path subset of uisrnn/__init__.py:26-30.
+"""
+
+from uisrnn_amd import arguments
+from uisrnn_amd import uisrnn as _uisrnn
+
+parse_arguments = arguments.parse_arguments
+UISRNN = _uisrnn.UISRNN
+parallel_predict = _uisrnn.parallel_predict

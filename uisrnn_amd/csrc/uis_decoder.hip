@@ -1,0 +1,506 @@
+// uis_decoder.hip -- host side of libuisrnn_hip.so: the C ABI of include/uisrnn_hip.h.
+//
+// Replaces, for the decode path only, what the reference does in
+//   UISRNN.__init__/load  (weights in)            uisrnn/uisrnn.py:83-107,149-170
+//   UISRNN.predict / predict_single (beam search) uisrnn/uisrnn.py:479-590
+// Utterances advance in lock-step: per step one select launch (one workgroup
+// per utterance) and one batched CoreRNN evaluation over the surviving
+// hypotheses of ALL utterances (GRU GEMM, mean-head GEMMs).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "uis_kernels.hip"
+#include "uisrnn_hip.h"
+
+#define UIS_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(e_ == hipErrorOutOfMemory ? UIS_ERR_OOM : UIS_ERR_HIP,               \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return UIS_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(UIS_ERR_OOM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+    }
+    cap = want;
+    return UIS_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfileEvents {
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> cls;
+  size_t used = 0;
+};
+
+}  // namespace
+
+struct uis_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevModel m{};
+  std::vector<void*> model_allocs;
+  double alpha = 1.0;
+  // workspace (grow only)
+  DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
+  DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
+  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
+  ProfileEvents prof;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  // info of the last decode
+  int last_U = 0, last_B = 0;
+  std::vector<int32_t> last_overflow;
+  std::vector<float> last_beam_scores;
+};
+
+namespace {
+
+// Re-pack a (n_out x K) row-major matrix (optionally 3 stacked gates of `rows_per_gate`
+// rows each, padded to `rows_per_gate_p`) into MFMA tile order:
+//   out[((tile*nKb + kb)*64 + lane)*4 + r] = W[tile*16 + (lane&15)][kb*16 + 4*(lane>>4) + r]
+std::vector<float> tile_weights(const float* W, int gates, int rows_per_gate, int rows_per_gate_p, int K, int Kp) {
+  const int Fp = gates * rows_per_gate_p;
+  const int nKb = Kp / 16;
+  std::vector<float> out((size_t)Fp * Kp, 0.0f);
+  for (int tile = 0; tile < Fp / 16; ++tile)
+    for (int kb = 0; kb < nKb; ++kb)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int fp = tile * 16 + (lane & 15);
+        const int g = fp / rows_per_gate_p, j = fp % rows_per_gate_p;
+        if (j >= rows_per_gate) continue;
+        const float* src = W + (size_t)(g * rows_per_gate + j) * K;
+        for (int r = 0; r < 4; ++r) {
+          const int k = kb * 16 + 4 * (lane >> 4) + r;
+          if (k < K) out[(((size_t)tile * nKb + kb) * 64 + lane) * 4 + r] = src[k];
+        }
+      }
+  return out;
+}
+
+std::vector<float> pad_bias(const float* b, int gates, int n, int np) {
+  std::vector<float> out((size_t)gates * np, 0.0f);
+  for (int g = 0; g < gates; ++g)
+    for (int j = 0; j < n; ++j) out[(size_t)g * np + j] = b[(size_t)g * n + j];
+  return out;
+}
+
+int upload(uis_handle* h, const std::vector<float>& v, const float** dst) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, std::max<size_t>(v.size(), 4) * sizeof(float)));
+  h->model_allocs.push_back(p);
+  HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<const float*>(p);
+  return UIS_OK;
+}
+
+inline dim3 dense_grid(long rows, int tiles) { return dim3((unsigned)((rows + 15) / 16), (unsigned)((tiles + 3) / 4), 1); }
+
+struct Launcher {
+  uis_handle* h;
+  bool profile;
+  int begin(int cls) {
+    if (!profile) return UIS_OK;
+    ProfileEvents& p = h->prof;
+    if (p.used + 2 > p.ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        p.ev.push_back(e);
+      }
+    }
+    p.cls.push_back(cls);
+    HIPCHK(hipEventRecord(p.ev[p.used], h->stream));
+    return UIS_OK;
+  }
+  int end() {
+    if (!profile) return UIS_OK;
+    ProfileEvents& p = h->prof;
+    HIPCHK(hipEventRecord(p.ev[p.used + 1], h->stream));
+    p.used += 2;
+    return UIS_OK;
+  }
+};
+
+#define LAUNCH(cls, ...)                       \
+  do {                                         \
+    int rc_ = lch.begin(cls);                  \
+    if (rc_) return rc_;                       \
+    __VA_ARGS__;                               \
+    HIPCHK(hipGetLastError());                 \
+    rc_ = lch.end();                           \
+    if (rc_) return rc_;                       \
+  } while (0)
+
+// One batched CoreRNN evaluation over the rows emitted for step parity `par`.
+int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
+  const DevModel& m = h->m;
+  for (int l = 0; l < m.depth; ++l) {
+    if (l > 0)
+      LAUNCH(UIS_K_UPPER_IN, hipLaunchKernelGGL(k_dense_upper_in, dense_grid(max_rows, m.G / 16), dim3(256), 0,
+                                                h->stream, m, st, par, l));
+    LAUNCH(UIS_K_GRU, hipLaunchKernelGGL(k_dense_gru, dense_grid(max_rows, m.Hp / 16), dim3(256), 0, h->stream, m,
+                                         st, par, l));
+  }
+  LAUNCH(UIS_K_HEAD1,
+         hipLaunchKernelGGL(k_dense_head1, dense_grid(max_rows, m.Hp / 16), dim3(256), 0, h->stream, m, st, par));
+  LAUNCH(UIS_K_HEAD2,
+         hipLaunchKernelGGL(k_dense_head2, dense_grid(max_rows, m.Dp / 16), dim3(256), 0, h->stream, m, st, par));
+  return UIS_OK;
+}
+
+// (m0, h1) = CoreRNN(0, rnn_init_hidden)  (uisrnn.py:435-439), with the decode kernels themselves.
+int bootstrap_constants(uis_handle* h, const float* d_hinit) {
+  DevModel& m = h->m;
+  Launcher lch{h, false};
+  const size_t hid_elems = (size_t)m.depth * m.Hp;
+  float *d_x = nullptr, *d_gi0 = nullptr, *d_pm = nullptr, *d_ph = nullptr, *d_gi_up = nullptr, *d_a1 = nullptr;
+  RnnRow* d_rows = nullptr;
+  int32_t* d_nrows = nullptr;
+  HIPCHK(hipMalloc(&d_x, m.Dp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_gi0, m.G * sizeof(float)));
+  HIPCHK(hipMalloc(&d_pm, m.Dp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_ph, hid_elems * sizeof(float)));
+  HIPCHK(hipMalloc(&d_gi_up, m.G * sizeof(float)));
+  HIPCHK(hipMalloc(&d_a1, m.Hp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_rows, sizeof(RnnRow)));
+  HIPCHK(hipMalloc(&d_nrows, 2 * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(d_x, 0, m.Dp * sizeof(float), h->stream));
+  RnnRow rr{};
+  rr.utt = 0; rr.src = -1; rr.dst = 0; rr.nprev = 0; rr.frame = 0;
+  int32_t nr[2] = {1, 1};
+  HIPCHK(hipMemcpyAsync(d_rows, &rr, sizeof(rr), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d_nrows, nr, sizeof(nr), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_dense_input_proj, dense_grid(1, m.G / 16), dim3(256), 0, h->stream, m, d_x, d_gi0, 1L);
+  HIPCHK(hipGetLastError());
+  DecodeState st{};
+  st.U = 1; st.B = 1; st.Kmax = 1; st.S = 1; st.L = 1; st.tau = 1;
+  st.gi0 = d_gi0; st.pool_mean = d_pm; st.pool_hid = d_ph; st.rows = d_rows; st.nrows = d_nrows;
+  st.gi_up = d_gi_up; st.a1 = d_a1;
+  const float* saved_h1 = m.h1;
+  m.h1 = d_hinit;  // src = -1 reads "h1": make that rnn_init_hidden for this one evaluation
+  int rc = launch_rnn(h, lch, st, 0, 1);
+  m.h1 = saved_h1;
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(const_cast<float*>(m.m0), d_pm, m.Dp * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(const_cast<float*>(m.h1), d_ph, hid_elems * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_x); (void)hipFree(d_gi0); (void)hipFree(d_pm); (void)hipFree(d_ph);
+  (void)hipFree(d_gi_up); (void)hipFree(d_a1); (void)hipFree(d_rows); (void)hipFree(d_nrows);
+  return UIS_OK;
+}
+
+int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
+                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
+  if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
+  const DevModel& m = h->m;
+  const int B = opts->beam_size, L = opts->look_ahead, tau = opts->test_iteration;
+  int Kmax = opts->max_clusters > 0 ? opts->max_clusters : 16;
+  if (B < 1 || B > 256) return fail(UIS_ERR_UNSUPPORTED, "beam_size must be in [1, 256]");
+  if (L < 1 || tau < 1) return fail(UIS_ERR_INVALID_ARG, "look_ahead and test_iteration must be >= 1");
+  if (L != 1) return fail(UIS_ERR_UNSUPPORTED, "look_ahead > 1 is not built yet");
+  if (Kmax > 4096) return fail(UIS_ERR_UNSUPPORTED, "max_clusters must be <= 4096");
+  if (offsets[0] != 0) return fail(UIS_ERR_INVALID_ARG, "offsets[0] must be 0");
+  int64_t maxN = 0;
+  for (int u = 0; u < n_utt; ++u) {
+    const int64_t n = offsets[u + 1] - offsets[u];
+    if (n < 0) return fail(UIS_ERR_INVALID_ARG, "offsets must be non-decreasing");
+    maxN = std::max(maxN, n);
+  }
+  const int64_t F = n_utt ? offsets[n_utt] : 0;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  h->last_U = n_utt; h->last_B = B;
+  h->last_overflow.assign(n_utt, 0);
+  h->last_beam_scores.assign((size_t)n_utt * B, INFINITY);
+  if (n_utt == 0) return UIS_OK;
+  if (F > 0 && (!d_frames || !d_labels)) return fail(UIS_ERR_INVALID_ARG, "frames/labels_out is null");
+  const int64_t maxT = (int64_t)tau * maxN;
+  if (maxT > 0x7fffff00LL) return fail(UIS_ERR_UNSUPPORTED, "test_iteration * N too large");
+  HIPCHK(hipSetDevice(h->device));
+
+  const int U = n_utt;
+  const int S = B * Kmax + B;
+  const long max_rows = (long)U * B;
+  const bool profile = (opts->flags & UIS_FLAG_PROFILE) != 0;
+  Launcher lch{h, profile};
+  h->prof.used = 0; h->prof.cls.clear();
+
+  const SelectLds lds = select_lds_layout(m.Dp, B, Kmax, S);
+  if (lds.total > 160 * 1024)
+    return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+
+  // ---- workspace
+  int rc;
+#define ENSURE(buf, bytes) if ((rc = h->buf.ensure(bytes))) return rc
+  ENSURE(off, (size_t)(U + 1) * 8);
+  ENSURE(utt_step, (size_t)U * 4);
+  ENSURE(overflow, (size_t)U * 4);
+  if (m.D != m.Dp) ENSURE(xpad, (size_t)std::max<int64_t>(F, 1) * m.Dp * 4);
+  ENSURE(gi0, (size_t)std::max<int64_t>(F, 1) * m.G * 4);
+  ENSURE(mse0, (size_t)std::max<int64_t>(F, 1) * 4);
+  ENSURE(logblk, (size_t)(maxT + 2) * 8);
+  ENSURE(logden, (size_t)(maxT + 2) * 8);
+  ENSURE(pool_mean, (size_t)U * S * m.Dp * 4);
+  ENSURE(pool_hid, (size_t)U * S * m.depth * m.Hp * 4);
+  ENSURE(pool_cnt, (size_t)U * S * 4);
+  ENSURE(beam_n, (size_t)2 * U * 4);
+  ENSURE(beam_K, (size_t)2 * U * B * 4);
+  ENSURE(beam_last, (size_t)2 * U * B * 4);
+  ENSURE(beam_sum, (size_t)2 * U * B * 4);
+  ENSURE(beam_score, (size_t)2 * U * B * 4);
+  ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
+  ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
+  ENSURE(bp, (size_t)std::max<int64_t>(tau * F, 1) * B * 4);
+  ENSURE(rows, (size_t)max_rows * sizeof(RnnRow));
+  ENSURE(nrows, 2 * 4);
+  ENSURE(gi_up, m.depth > 1 ? (size_t)max_rows * m.G * 4 : 16);
+  ENSURE(a1, (size_t)max_rows * m.Hp * 4);
+  ENSURE(counters, 4 * 8);
+  ENSURE(beam_scores_out, (size_t)U * B * 4);
+#undef ENSURE
+
+  // ---- per-decode tables
+  std::vector<double> logblk(maxT + 2), logden(maxT + 2);
+  for (int64_t n = 0; n < maxT + 2; ++n) {
+    logblk[n] = n > 0 ? std::log((double)n) : 0.0;      // np.log(block_counts[cluster]), uisrnn.py:418-419
+    logden[n] = std::log((double)n + h->alpha);          // np.log(sum(block_counts) + crp_alpha)
+  }
+  HIPCHK(hipMemcpyAsync(h->off.p, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->logblk.p, logblk.data(), logblk.size() * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->logden.p, logden.data(), logden.size() * 8, hipMemcpyHostToDevice, h->stream));
+
+  DecodeState st{};
+  st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags;
+  st.off = h->off.as<int64_t>(); st.utt_step = h->utt_step.as<int32_t>(); st.overflow = h->overflow.as<int32_t>();
+  st.gi0 = h->gi0.as<float>(); st.mse0 = h->mse0.as<float>();
+  st.logblk = h->logblk.as<double>(); st.logden = h->logden.as<double>();
+  st.pool_mean = h->pool_mean.as<float>(); st.pool_hid = h->pool_hid.as<float>(); st.pool_cnt = h->pool_cnt.as<int32_t>();
+  st.beam_n = h->beam_n.as<int32_t>(); st.beam_K = h->beam_K.as<int32_t>(); st.beam_last = h->beam_last.as<int32_t>();
+  st.beam_sum = h->beam_sum.as<int32_t>(); st.beam_score = h->beam_score.as<float>();
+  st.beam_slot = h->beam_slot.as<int32_t>(); st.beam_blk = h->beam_blk.as<int32_t>();
+  st.bp = h->bp.as<uint32_t>(); st.rows = h->rows.as<RnnRow>(); st.nrows = h->nrows.as<int32_t>();
+  st.gi_up = h->gi_up.as<float>(); st.a1 = h->a1.as<float>();
+  st.counters = h->counters.as<unsigned long long>();
+
+  HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+  const float* d_x = d_frames;
+  if (m.D != m.Dp && F > 0) {
+    const long total = (long)F * m.Dp;
+    hipLaunchKernelGGL(k_pad_frames, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d_frames,
+                       h->xpad.as<float>(), (long)F, m.D, m.Dp);
+    HIPCHK(hipGetLastError());
+    d_x = h->xpad.as<float>();
+  }
+  st.x = d_x;
+  hipLaunchKernelGGL(k_init_state, dim3((U + 255) / 256), dim3(256), 0, h->stream, st);
+  HIPCHK(hipGetLastError());
+  if (F > 0) {
+    LAUNCH(UIS_K_INPUT_PROJ, {
+      hipLaunchKernelGGL(k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, h->stream, m, d_x,
+                         h->gi0.as<float>(), (long)F);
+      hipLaunchKernelGGL(k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, h->stream, m, d_x,
+                         h->mse0.as<float>(), (long)F);
+    });
+  }
+
+  // ---- lock-step decode
+  for (int64_t step = 0; step < maxT; ++step) {
+    const int par = (int)(step & 1);
+    LAUNCH(UIS_K_SELECT,
+           hipLaunchKernelGGL(k_select, dim3(U), dim3(256), (size_t)lds.total, h->stream, m, st, par));
+    rc = launch_rnn(h, lch, st, par, max_rows);
+    if (rc) return rc;
+  }
+  LAUNCH(UIS_K_BACKTRACE, hipLaunchKernelGGL(k_backtrace, dim3((U + 63) / 64), dim3(64), 0, h->stream, st, d_labels,
+                                             d_scores, h->beam_scores_out.as<float>()));
+  HIPCHK(hipEventRecord(h->ev_end, h->stream));
+
+  unsigned long long counters[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(counters, h->counters.p, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->last_overflow.data(), h->overflow.p, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), h->beam_scores_out.p, (size_t)U * B * 4, hipMemcpyDeviceToHost,
+                        h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int n_over = 0;
+  for (int u = 0; u < U; ++u) n_over += h->last_overflow[u] != 0;
+  if (stats) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+    stats->n_steps = (int32_t)maxT;
+    stats->decode_ms = ms;
+    stats->rnn_rows = (int64_t)counters[0];
+    stats->rnn_rows_nodedup = (int64_t)counters[1];
+    stats->candidates = (int64_t)counters[2];
+    stats->max_clusters_seen = (int32_t)counters[3];
+    stats->n_overflow = n_over;
+    if (profile) {
+      for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
+        float t = 0.0f;
+        HIPCHK(hipEventElapsedTime(&t, h->prof.ev[i], h->prof.ev[i + 1]));
+        const int c = h->prof.cls[i / 2];
+        stats->kernel_ms[c] += t;
+        stats->kernel_launches[c] += 1;
+      }
+    }
+  }
+  if (n_over)
+    return fail(UIS_ERR_CLUSTER_CAP, std::to_string(n_over) + " utterance(s) needed more than max_clusters=" +
+                                         std::to_string(Kmax) + " clusters per hypothesis");
+  return UIS_OK;
+}
+
+}  // namespace
+
+UIS_EXPORT int32_t uis_abi_version(void) { return UIS_ABI_VERSION; }
+
+UIS_EXPORT int32_t uis_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+UIS_EXPORT const char* uis_last_error(void) { return g_err.c_str(); }
+
+UIS_EXPORT void uis_destroy(uis_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->model_allocs) (void)hipFree(p);
+  DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
+                    &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
+                    &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
+  if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+  if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handle** out) {
+  if (!d || !out) return fail(UIS_ERR_INVALID_ARG, "null desc/out");
+  *out = nullptr;
+  const int D = d->observation_dim, H = d->rnn_hidden_size, depth = d->rnn_depth;
+  if (D < 1 || H < 1 || depth < 1 || depth > UIS_MAX_DEPTH)
+    return fail(UIS_ERR_INVALID_ARG, "observation_dim, rnn_hidden_size >= 1 and 1 <= rnn_depth <= 8 required");
+  if (!(d->transition_bias > 0.0 && d->transition_bias < 1.0))
+    return fail(UIS_ERR_INVALID_ARG, "transition_bias must be in (0, 1) (the reference takes its log)");
+  if (!(d->crp_alpha > 0.0)) return fail(UIS_ERR_INVALID_ARG, "crp_alpha must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(UIS_ERR_NO_DEVICE, "no HIP device visible; this decoder has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(UIS_ERR_NO_DEVICE, "device index out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(UIS_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(UIS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  if (hipSetDevice(device) != hipSuccess) return fail(UIS_ERR_NO_DEVICE, "hipSetDevice failed");
+
+  uis_handle* h = new uis_handle();
+  h->device = device;
+  h->alpha = d->crp_alpha;
+  auto bail = [&](int rc) { uis_destroy(h); return rc; };
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(UIS_ERR_HIP, "stream create failed"));
+  if (hipEventCreate(&h->ev_begin) != hipSuccess || hipEventCreate(&h->ev_end) != hipSuccess)
+    return bail(fail(UIS_ERR_HIP, "event create failed"));
+  DevModel& m = h->m;
+  m.D = D; m.H = H; m.depth = depth;
+  m.Dp = round_up(D, 16); m.Hp = round_up(H, 16); m.G = 3 * m.Hp;
+  m.lp_stay = std::log(1.0 - d->transition_bias);  // np.log(1 - transition_bias), uisrnn.py:416
+  m.lp_sw = std::log(d->transition_bias);
+  m.l_alpha = std::log(d->crp_alpha);
+  int rc;
+  for (int l = 0; l < depth; ++l) {
+    const int K = l == 0 ? D : H, Kp = l == 0 ? m.Dp : m.Hp;
+    if ((rc = upload(h, tile_weights(d->gru_weight_ih[l], 3, H, m.Hp, K, Kp), &m.wih[l]))) return bail(rc);
+    if ((rc = upload(h, tile_weights(d->gru_weight_hh[l], 3, H, m.Hp, H, m.Hp), &m.whh[l]))) return bail(rc);
+    if ((rc = upload(h, pad_bias(d->gru_bias_ih[l], 3, H, m.Hp), &m.bih[l]))) return bail(rc);
+    if ((rc = upload(h, pad_bias(d->gru_bias_hh[l], 3, H, m.Hp), &m.bhh[l]))) return bail(rc);
+  }
+  if ((rc = upload(h, tile_weights(d->linear_mean1_weight, 1, H, m.Hp, H, m.Hp), &m.w1))) return bail(rc);
+  if ((rc = upload(h, pad_bias(d->linear_mean1_bias, 1, H, m.Hp), &m.b1))) return bail(rc);
+  if ((rc = upload(h, tile_weights(d->linear_mean2_weight, 1, D, m.Dp, H, m.Hp), &m.w2))) return bail(rc);
+  if ((rc = upload(h, pad_bias(d->linear_mean2_bias, 1, D, m.Dp), &m.b2))) return bail(rc);
+  std::vector<float> wgt(m.Dp, 0.0f);
+  for (int i = 0; i < D; ++i) wgt[i] = 1.0f / (2.0f * d->sigma2[i]);  // 1 / (2 * sigma2), uisrnn.py:414
+  if ((rc = upload(h, wgt, &m.wgt))) return bail(rc);
+  std::vector<float> hinit((size_t)depth * m.Hp, 0.0f);
+  for (int l = 0; l < depth; ++l)
+    for (int j = 0; j < H; ++j) hinit[(size_t)l * m.Hp + j] = d->rnn_init_hidden[(size_t)l * H + j];
+  const float* d_hinit = nullptr;
+  if ((rc = upload(h, hinit, &d_hinit))) return bail(rc);
+  if ((rc = upload(h, std::vector<float>(m.Dp, 0.0f), &m.m0))) return bail(rc);
+  if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return bail(fail(UIS_ERR_HIP, std::string("hipFuncSetAttribute(k_select): ") + hipGetErrorString(e)));
+  if ((rc = bootstrap_constants(h, d_hinit))) return bail(rc);
+  *out = h;
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_decode_device(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
+                                     const uis_decode_opts* opts, int32_t* d_labels_out, float* d_scores_out,
+                                     uis_stats* stats) {
+  return decode_impl(h, d_frames, offsets, n_utt, opts, d_labels_out, d_scores_out, stats);
+}
+
+UIS_EXPORT int32_t uis_decode(uis_handle* h, const float* frames, const int64_t* offsets, int32_t n_utt,
+                              const uis_decode_opts* opts, int32_t* labels_out, float* scores_out, uis_stats* stats) {
+  if (!h || !offsets || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets or negative n_utt");
+  const int64_t F = n_utt ? offsets[n_utt] : 0;
+  if (F < 0) return fail(UIS_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  if (F > 0 && (!frames || !labels_out)) return fail(UIS_ERR_INVALID_ARG, "frames/labels_out is null");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = h->io_frames.ensure((size_t)std::max<int64_t>(F, 1) * h->m.D * 4))) return rc;
+  if ((rc = h->io_labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
+  if ((rc = h->io_scores.ensure((size_t)std::max(n_utt, 1) * 4))) return rc;
+  if (F > 0)
+    HIPCHK(hipMemcpyAsync(h->io_frames.p, frames, (size_t)F * h->m.D * 4, hipMemcpyHostToDevice, h->stream));
+  rc = decode_impl(h, h->io_frames.as<float>(), offsets, n_utt, opts, h->io_labels.as<int32_t>(),
+                   h->io_scores.as<float>(), stats);
+  if (rc != UIS_OK && rc != UIS_ERR_CLUSTER_CAP) return rc;
+  if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, h->io_labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+  if (scores_out && n_utt > 0)
+    HIPCHK(hipMemcpyAsync(scores_out, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return rc;
+}
+
+UIS_EXPORT int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out) {
+  if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
+  if (overflow_out && h->last_U) memcpy(overflow_out, h->last_overflow.data(), (size_t)h->last_U * 4);
+  if (beam_scores_out && h->last_U) memcpy(beam_scores_out, h->last_beam_scores.data(), (size_t)h->last_U * h->last_B * 4);
+  return UIS_OK;
+}

@@ -1,0 +1,84 @@
+// uis_kernels.h -- device data layout and kernel argument blocks of the gfx950
+// UIS-RNN decoder.  See DESIGN.md for the layout rationale.
+//
+// Vocabulary (follows the reference, uisrnn/uisrnn.py):
+//   utterance   one test sequence [N, D]
+//   hypothesis  one BeamState (uisrnn.py:55-77): K clusters, block counts, last
+//               cluster, neg_likelihood
+//   cluster state  (mean, hidden, frame count) of one cluster of one hypothesis;
+//               lives in a per-utterance SLOT POOL and is shared between
+//               hypotheses copy-on-write, like the reference's shallow list copies
+//   rnn row     one CoreRNN.forward evaluation (uisrnn.py:45-52) = one row of the
+//               batched GRU / mean-head GEMMs
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UIS_MAX_DEPTH 8
+#define UIS_MAX_LOOKAHEAD 8
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One CoreRNN evaluation scheduled by the select/expand kernels.
+struct RnnRow {
+  int32_t utt;     // utterance index
+  int32_t src;     // source slot (cluster state before this frame), -1 = fresh cluster (h1)
+  int32_t dst;     // destination slot
+  int32_t nprev;   // frames already assigned to the cluster (0 for a fresh cluster)
+  int64_t frame;   // row of the packed frame stream
+  int64_t pad;
+};
+
+struct DevModel {
+  int D, H, depth, Dp, Hp, G;  // G = 3*Hp (gates r|z|n, each padded to Hp)
+  // weights in MFMA tile order: [feature tile][k block][lane 0..63][4]
+  const float* wih[UIS_MAX_DEPTH];
+  const float* whh[UIS_MAX_DEPTH];
+  const float* bih[UIS_MAX_DEPTH];  // [G]
+  const float* bhh[UIS_MAX_DEPTH];  // [G]
+  const float* w1;  const float* b1;   // (Hp x Hp) tiled, [Hp]
+  const float* w2;  const float* b2;   // (Dp x Hp) tiled, [Dp]
+  const float* wgt;    // [Dp]  1 / (2 sigma2), 0 in the padding
+  const float* m0;     // [Dp]  mean of a fresh cluster before its first frame
+  const float* h1;     // [depth][Hp] hidden of a fresh cluster before its first frame
+  double lp_stay, lp_sw, l_alpha;
+};
+
+// Everything the per-step kernels need about the running decode.
+struct DecodeState {
+  int U, B, Kmax, S, L, tau;
+  uint32_t flags;
+  // utterances
+  const int64_t* off;     // [U+1] frame offsets
+  int32_t* utt_step;      // [U] next decode step of each utterance
+  int32_t* overflow;      // [U]
+  // frame stream
+  const float* x;         // [frames][Dp]
+  const float* gi0;       // [frames][G]   W_ih0 x + b_ih0
+  const float* mse0;      // [frames]      weighted MSE against m0
+  // prior tables (float64)
+  const double* logblk;   // [Tmax+2] log(n)
+  const double* logden;   // [Tmax+2] log(n + alpha)
+  // slot pool
+  float* pool_mean;       // [U][S][Dp]
+  float* pool_hid;        // [U][S][depth][Hp]
+  int32_t* pool_cnt;      // [U][S]
+  // beam tables, double buffered on step parity: index ((par*U + u)*B + b)
+  int32_t* beam_n;        // [2][U]
+  int32_t* beam_K;        // [2][U][B]
+  int32_t* beam_last;     // [2][U][B]
+  int32_t* beam_sum;      // [2][U][B]   sum(block_counts)
+  float*   beam_score;    // [2][U][B]
+  int32_t* beam_slot;     // [2][U][B][Kmax]
+  int32_t* beam_blk;      // [2][U][B][Kmax]
+  // back-pointers: bp[tau*off[u]*B + step*B + r] = (parent << 16) | cluster
+  uint32_t* bp;
+  // rnn rows of the current step, appended with atomics
+  RnnRow* rows;           // [U*B]
+  int32_t* nrows;         // [2] row counters, by step parity
+  // intermediates, one row per rnn row
+  float* gi_up;           // [U*B][G]   input-side gates of GRU layers >= 1
+  float* a1;              // [U*B][Hp]  relu(linear_mean1)
+  // counters (device): [0] rnn rows, [1] rnn rows without dedup, [2] candidates, [3] max K
+  unsigned long long* counters;
+};

@@ -1,0 +1,533 @@
+// uis_kernels.hip -- gfx950 kernels of the UIS-RNN beam-search decode.
+//
+// Reference behaviour being reproduced (google/uis-rnn):
+//   k_dense_* : CoreRNN.forward                uisrnn/uisrnn.py:45-52
+//   k_mse0    : weighted_mse_loss vs m0        uisrnn/loss_func.py:19-41, uisrnn.py:440-443
+//   k_select  : _calculate_score + prune + the bookkeeping half of _update_beam_state
+//                                              uisrnn/uisrnn.py:388-453,455-477,534-559
+//   k_backtrace : trace[-N:] of beam_set[0]    uisrnn/uisrnn.py:561
+// Arithmetic order: include/uis_numerics.h (bit-identical to oracle/uis_oracle.c).
+//
+// Written for wave64 / MFMA f32 16x16x4 / 8 XCDs; no other target.
+#include "uis_kernels.h"
+#include "uis_numerics.h"
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ float wave_tree_sum(float v) {
+  // xor butterfly 32,16,...,1 == uis_tree_sum's second stage
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Weighted MSE of one row against the frame staged in LDS, canonical tree.
+// All 64 lanes of the calling wave participate; every lane returns the value.
+__device__ __forceinline__ float wave_weighted_mse(const float* __restrict__ mean,
+                                                   const float* sx, const float* swgt,
+                                                   int Dp, int D, int lane) {
+  float acc = 0.0f;
+  for (int base = 4 * lane; base < Dp; base += 256) {
+    f32x4 m = *reinterpret_cast<const f32x4*>(mean + base);
+    f32x4 x = *reinterpret_cast<const f32x4*>(sx + base);
+    f32x4 w = *reinterpret_cast<const f32x4*>(swgt + base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = acc + uis_mse_term(m[i], x[i], w[i]);
+  }
+  float sum = wave_tree_sum(acc);
+  float d0 = mean[0] - sx[0];
+  return uis_mse_finish(sum, d0 * d0, D);
+}
+
+// -------------------------------------------------------------- dense chains
+//
+// out[row][f] = bias[f] + sum_k W[f][k] * in[row][k] as v_mfma_f32_16x16x4_f32
+// chains.  A operand = weights (16 features x 4 k), B operand = 16 rnn rows.
+// Lane l holds, for its row (l & 15), features 4*(l>>4) .. +3 of the tile.
+// One wave owns one 16-row x 16-feature tile per gate; K is walked in blocks of
+// 16 with one 16-byte load per operand per lane (weights pre-tiled so the load is
+// one contiguous KiB per wave).
+
+template <int NG>
+__device__ __forceinline__ void dense_mainloop(const float* __restrict__ Wt, int tiles_per_gate,
+                                               int tile, int nKb, const float* __restrict__ inrow,
+                                               f32x4 (&acc)[NG]) {
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4;
+  const f32x4* wp[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    wp[g] = reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile) * nKb) * 64 + lane;
+  const f32x4* bp = reinterpret_cast<const f32x4*>(inrow) + q;
+  f32x4 a_cur[NG], b_cur;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) a_cur[g] = wp[g][0];
+  b_cur = bp[0];
+  for (int kb = 0; kb < nKb; ++kb) {
+    f32x4 a_nxt[NG], b_nxt;
+    const int kn = kb + 1 < nKb ? kb + 1 : kb;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a_nxt[g] = wp[g][(size_t)kn * 64];
+    b_nxt = bp[(size_t)kn * 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][r], b_cur[r], acc[g], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a_cur[g] = a_nxt[g];
+    b_cur = b_nxt;
+  }
+}
+
+__device__ __forceinline__ f32x4 load_bias4(const float* bias, int f) {
+  return *reinterpret_cast<const f32x4*>(bias + f);
+}
+
+// gi0[frame][G] = b_ih0 + W_ih0 x[frame]   for every frame of the packed stream.
+__global__ __launch_bounds__(256) void k_dense_input_proj(DevModel m, const float* __restrict__ x,
+                                                          float* __restrict__ gi0, long nframes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * 4 + wave;
+  const int ntiles = m.G / 16;
+  if (tile >= ntiles) return;
+  const long row0 = (long)blockIdx.x * 16;
+  if (row0 >= nframes) return;
+  long row = row0 + (lane & 15);
+  const bool valid = row < nframes;
+  if (!valid) row = nframes - 1;
+  const int f = tile * 16 + (lane >> 4) * 4;
+  f32x4 acc[1];
+  acc[0] = load_bias4(m.bih[0], f);
+  dense_mainloop<1>(m.wih[0], 0, tile, m.Dp / 16, x + (size_t)row * m.Dp, acc);
+  if (valid) *reinterpret_cast<f32x4*>(gi0 + (size_t)row * m.G + f) = acc[0];
+}
+
+// Input-side gates of GRU layer `layer` >= 1: gi_up[row][G] = b_ih + W_ih h'_{layer-1}
+__global__ __launch_bounds__(256) void k_dense_upper_in(DevModel m, DecodeState st, int par, int layer) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= m.G / 16) return;
+  const int nrows = st.nrows[par];
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= nrows) return;
+  int row = row0 + (lane & 15);
+  const bool valid = row < nrows;
+  if (!valid) row = nrows - 1;
+  const RnnRow rr = st.rows[row];
+  const float* in = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * m.depth * m.Hp + (size_t)(layer - 1) * m.Hp;
+  const int f = tile * 16 + (lane >> 4) * 4;
+  f32x4 acc[1];
+  acc[0] = load_bias4(m.bih[layer], f);
+  dense_mainloop<1>(m.wih[layer], 0, tile, m.Hp / 16, in, acc);
+  if (valid) *reinterpret_cast<f32x4*>(st.gi_up + (size_t)row * m.G + f) = acc[0];
+}
+
+// GRU layer: gh = b_hh + W_hh h_src (three gate chains per unit), gates, h' -> dst slot.
+__global__ __launch_bounds__(256) void k_dense_gru(DevModel m, DecodeState st, int par, int layer) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * 4 + wave;          // 16 hidden units
+  const int tiles_per_gate = m.Hp / 16;
+  if (tile >= tiles_per_gate) return;
+  const int nrows = st.nrows[par];
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= nrows) return;
+  int row = row0 + (lane & 15);
+  const bool valid = row < nrows;
+  if (!valid) row = nrows - 1;
+  const RnnRow rr = st.rows[row];
+  const size_t slot_stride = (size_t)m.depth * m.Hp;
+  const float* hsrc = rr.src >= 0
+      ? st.pool_hid + ((size_t)rr.utt * st.S + rr.src) * slot_stride + (size_t)layer * m.Hp
+      : m.h1 + (size_t)layer * m.Hp;
+  const int j = tile * 16 + (lane >> 4) * 4;       // first of this lane's 4 units
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = load_bias4(m.bhh[layer], g * m.Hp + j);
+  dense_mainloop<3>(m.whh[layer], tiles_per_gate, tile, m.Hp / 16, hsrc, acc);
+  if (!valid) return;
+  const float* gi = layer == 0 ? st.gi0 + (size_t)rr.frame * m.G : st.gi_up + (size_t)row * m.G;
+  const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j);
+  const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j);
+  const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j);
+  const f32x4 h = *reinterpret_cast<const f32x4*>(hsrc + j);
+  f32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    out[i] = (j + i < m.H) ? uis_gru_unit(gir[i], giz[i], gin[i], acc[0][i], acc[1][i], acc[2][i], h[i]) : 0.0f;
+  float* hdst = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * slot_stride + (size_t)layer * m.Hp;
+  *reinterpret_cast<f32x4*>(hdst + j) = out;
+}
+
+// a1[row] = relu(b1 + W1 h'_top)
+__global__ __launch_bounds__(256) void k_dense_head1(DevModel m, DecodeState st, int par) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= m.Hp / 16) return;
+  const int nrows = st.nrows[par];
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= nrows) return;
+  int row = row0 + (lane & 15);
+  const bool valid = row < nrows;
+  if (!valid) row = nrows - 1;
+  const RnnRow rr = st.rows[row];
+  const float* in = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * m.depth * m.Hp + (size_t)(m.depth - 1) * m.Hp;
+  const int f = tile * 16 + (lane >> 4) * 4;
+  f32x4 acc[1];
+  acc[0] = load_bias4(m.b1, f);
+  dense_mainloop<1>(m.w1, 0, tile, m.Hp / 16, in, acc);
+  if (!valid) return;
+  f32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = acc[0][i] > 0.0f ? acc[0][i] : 0.0f;
+  *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f) = out;
+}
+
+// m = b2 + W2 a1; running-mean update (uisrnn.py:425-429) -> dst slot
+__global__ __launch_bounds__(256) void k_dense_head2(DevModel m, DecodeState st, int par) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= m.Dp / 16) return;
+  const int nrows = st.nrows[par];
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= nrows) return;
+  int row = row0 + (lane & 15);
+  const bool valid = row < nrows;
+  if (!valid) row = nrows - 1;
+  const RnnRow rr = st.rows[row];
+  const int f = tile * 16 + (lane >> 4) * 4;
+  f32x4 acc[1];
+  acc[0] = load_bias4(m.b2, f);
+  dense_mainloop<1>(m.w2, 0, tile, m.Hp / 16, st.a1 + (size_t)row * m.Hp, acc);
+  if (!valid) return;
+  f32x4 out = acc[0];
+  if (rr.src >= 0) {
+    const f32x4 old = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)rr.utt * st.S + rr.src) * m.Dp + f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = uis_mean_update(old[i], acc[0][i], rr.nprev);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) if (f + i >= m.D) out[i] = 0.0f;
+  *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)rr.utt * st.S + rr.dst) * m.Dp + f) = out;
+}
+
+// mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
+__global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restrict__ x,
+                                              float* __restrict__ mse0, long nframes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* swgt = reinterpret_cast<float*>(smem_raw);
+  float* sx = swgt + m.Dp;  // 4 waves x Dp
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
+  const long frame = (long)blockIdx.x * 4 + wave;
+  float* myx = sx + (size_t)wave * m.Dp;
+  if (frame < nframes)
+    for (int i = lane; i < m.Dp; i += 64) myx[i] = x[(size_t)frame * m.Dp + i];
+  __syncthreads();
+  if (frame >= nframes) return;
+  float v = wave_weighted_mse(m.m0, myx, swgt, m.Dp, m.D, lane);
+  if (lane == 0) mse0[frame] = v;
+}
+
+// Zero-pad the frame stream to Dp columns when D is not a multiple of 16.
+__global__ void k_pad_frames(const float* __restrict__ src, float* __restrict__ dst, long nframes, int D, int Dp) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = nframes * Dp;
+  if (i >= total) return;
+  long r = i / Dp; int c = (int)(i % Dp);
+  dst[i] = c < D ? src[r * D + c] : 0.0f;
+}
+
+// Reset the per-decode state: every utterance starts with one empty hypothesis
+// (beam_set = [BeamState()], uisrnn.py:528).
+__global__ void k_init_state(DecodeState st) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull; }
+  if (u >= st.U) return;
+  st.utt_step[u] = 0;
+  st.overflow[u] = 0;
+  st.beam_n[u] = 1;            // parity 0
+  st.beam_n[st.U + u] = 0;
+  size_t e = (size_t)u * st.B;
+  st.beam_K[e] = 0; st.beam_last[e] = -1; st.beam_sum[e] = 0; st.beam_score[e] = 0.0f;
+}
+
+// ------------------------------------------------------------------ select
+//
+// One workgroup per utterance, one decode step (look_ahead == 1 window):
+//   A  weighted MSE of the frame against every live cluster state (one wave per slot)
+//   B  score every (hypothesis, cluster) candidate: float32(mse - prior) accumulated in float32
+//   C  keep the min(#finite, B) lowest (ties: lowest (hypothesis, cluster))
+//   D  build the next beam tables, allocate destination slots, emit the rnn rows
+// Dynamic LDS layout is carved by select_lds_bytes() below.
+
+struct SelectLds {
+  int off_x, off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_base, off_score;
+  int off_live, off_livelist, off_mse, off_key, off_cscore, off_win, off_src, off_dst, off_lead, off_free, off_misc;
+  int total;
+};
+
+__host__ __device__ inline SelectLds select_lds_layout(int Dp, int B, int Kmax, int S) {
+  SelectLds l;
+  int o = 0;
+  auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+  const int C = B * (Kmax + 1);
+  l.off_x = take(Dp * 4);
+  l.off_wgt = take(Dp * 4);
+  l.off_slot = take(B * Kmax * 4);
+  l.off_blk = take(B * Kmax * 4);
+  l.off_K = take(B * 4);
+  l.off_last = take(B * 4);
+  l.off_sum = take(B * 4);
+  l.off_base = take((B + 1) * 4);
+  l.off_score = take(B * 4);
+  l.off_live = take(S * 4);
+  l.off_livelist = take(S * 4);
+  l.off_mse = take(S * 4);
+  l.off_key = take(C * 8);
+  l.off_cscore = take(C * 4);
+  l.off_win = take(B * 4);
+  l.off_src = take(B * 4);
+  l.off_dst = take(B * 4);
+  l.off_lead = take(B * 4);
+  l.off_free = take(B * 4);
+  l.off_misc = take(16 * 4);
+  l.total = o;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const long N = (long)(st.off[u + 1] - st.off[u]);
+  const long T = (long)st.tau * N;
+  const int step = st.utt_step[u];
+  // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
+  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
+  if (step >= T) return;  // utterance finished (uniform over the workgroup)
+  const long frame = st.off[u] + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
+  const int nxt = par ^ 1;
+
+  const SelectLds L = select_lds_layout(m.Dp, B, Kmax, S);
+  float* sx = reinterpret_cast<float*>(smem_raw + L.off_x);
+  float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
+  int* sslot = reinterpret_cast<int*>(smem_raw + L.off_slot);
+  int* sblk = reinterpret_cast<int*>(smem_raw + L.off_blk);
+  int* sK = reinterpret_cast<int*>(smem_raw + L.off_K);
+  int* slast = reinterpret_cast<int*>(smem_raw + L.off_last);
+  int* ssum = reinterpret_cast<int*>(smem_raw + L.off_sum);
+  int* sbase = reinterpret_cast<int*>(smem_raw + L.off_base);
+  float* sscore = reinterpret_cast<float*>(smem_raw + L.off_score);
+  int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
+  int* slivelist = reinterpret_cast<int*>(smem_raw + L.off_livelist);
+  float* smse = reinterpret_cast<float*>(smem_raw + L.off_mse);
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem_raw + L.off_key);
+  float* scscore = reinterpret_cast<float*>(smem_raw + L.off_cscore);
+  int* swin = reinterpret_cast<int*>(smem_raw + L.off_win);
+  int* ssrc = reinterpret_cast<int*>(smem_raw + L.off_src);
+  int* sdst = reinterpret_cast<int*>(smem_raw + L.off_dst);
+  int* slead = reinterpret_cast<int*>(smem_raw + L.off_lead);
+  int* sfree = reinterpret_cast<int*>(smem_raw + L.off_free);
+  int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite [2] nlead
+
+  const size_t bcur = ((size_t)par * U + u) * B;
+  const size_t bnxt = ((size_t)nxt * U + u) * B;
+  const int nb = st.beam_n[(size_t)par * U + u];
+
+  // ---- stage the frame, the weights and the beam tables
+  for (int i = tid; i < m.Dp; i += 256) { sx[i] = st.x[(size_t)frame * m.Dp + i]; swgt[i] = m.wgt[i]; }
+  for (int b = tid; b < nb; b += 256) {
+    sK[b] = st.beam_K[bcur + b]; slast[b] = st.beam_last[bcur + b];
+    ssum[b] = st.beam_sum[bcur + b]; sscore[b] = st.beam_score[bcur + b];
+  }
+  for (int s = tid; s < S; s += 256) slive[s] = 0;
+  if (tid < 16) smisc[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < nb * Kmax; e += 256) {
+    const int b = e / Kmax, c = e - b * Kmax;
+    if (c < sK[b]) {
+      const int s = st.beam_slot[(bcur + b) * Kmax + c];
+      sslot[e] = s; sblk[e] = st.beam_blk[(bcur + b) * Kmax + c];
+      slive[s] = 1;
+    }
+  }
+  if (tid == 0) {  // candidate offsets: hypothesis b owns candidates sbase[b] .. sbase[b] + K_b
+    int acc = 0;
+    for (int b = 0; b < nb; ++b) { sbase[b] = acc; acc += sK[b] + 1; }
+    sbase[nb] = acc;
+  }
+  __syncthreads();
+  for (int s = tid; s < S; s += 256)
+    if (slive[s]) slivelist[atomicAdd(&smisc[0], 1)] = s;
+  __syncthreads();
+  const int nlive = smisc[0];
+
+  // ---- A: MSE against every live cluster state
+  const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  for (int i = wave; i < nlive; i += 4) {
+    const int s = slivelist[i];
+    const float v = wave_weighted_mse(pmean + (size_t)s * m.Dp, sx, swgt, m.Dp, m.D, lane);
+    if (lane == 0) smse[s] = v;
+  }
+  __syncthreads();
+
+  // ---- B: candidate scores
+  const int C = sbase[nb];
+  const float mse_new = st.mse0[frame];
+  for (int i = tid; i < C; i += 256) {
+    int b = 0;
+    while (i >= sbase[b + 1]) ++b;
+    const int c = i - sbase[b];
+    float mse; double prior;
+    if (c < sK[b]) {  // existing cluster, uisrnn.py:409-420
+      mse = smse[sslot[b * Kmax + c]];
+      prior = (c == slast[b]) ? m.lp_stay
+                              : (m.lp_sw + st.logblk[sblk[b * Kmax + c]]) - st.logden[ssum[b]];
+    } else {          // new cluster, uisrnn.py:440-446
+      mse = mse_new;
+      prior = (m.lp_sw + m.l_alpha) - st.logden[ssum[b]];
+    }
+    const float sc = sscore[b] + uis_step_loss(mse, prior);  // float32 accumulate, uisrnn.py:452
+    scscore[i] = sc;
+    const bool fin = uis_isfinite(sc);
+    skey[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
+    if (fin) atomicAdd(&smisc[1], 1);
+  }
+  __syncthreads();
+
+  // ---- C: rank by counting (keys are unique)
+  const int nfin = smisc[1];
+  const int keep = nfin < B ? nfin : B;  // uisrnn.py:551-552
+  for (int i = tid; i < C; i += 256) {
+    const unsigned long long k = skey[i];
+    if (k == ~0ull) continue;
+    int rank = 0;
+    for (int j2 = 0; j2 < C; ++j2) rank += skey[j2] < k;
+    if (rank < keep) swin[rank] = i;
+  }
+  __syncthreads();
+
+  // ---- D: winners -> (parent, cluster, source slot); dedup rows by source slot
+  const bool nodedup = (st.flags & 1u) != 0;
+  if (tid < keep) {
+    const int i = swin[tid];
+    int b = 0;
+    while (i >= sbase[b + 1]) ++b;
+    const int c = i - sbase[b];
+    ssrc[tid] = c < sK[b] ? sslot[b * Kmax + c] : -1;
+  }
+  __syncthreads();
+  if (tid < keep) {
+    int lead = tid;
+    if (!nodedup)
+      for (int r2 = 0; r2 < tid; ++r2) if (ssrc[r2] == ssrc[tid]) { lead = r2; break; }
+    slead[tid] = lead;
+  }
+  __syncthreads();
+  if (tid == 0) {  // ordinal of each leader (keep <= B, serial is fine)
+    int n = 0;
+    for (int r = 0; r < keep; ++r) if (slead[r] == r) sdst[r] = n++; else sdst[r] = -1;
+    smisc[2] = n;
+  }
+  __syncthreads();
+  const int nlead = smisc[2];
+  // first nlead free slots (not referenced by the current beam), in slot order;
+  // smisc[3] = free slots seen so far, smisc[8..11] = per-wave counts
+  for (int base = 0; base < S && smisc[3] < nlead; base += 256) {
+    const int s = base + tid;
+    const bool fr = s < S && !slive[s];
+    const unsigned long long mask = __ballot(fr);
+    if (lane == 0) smisc[8 + wave] = __popcll(mask);
+    __syncthreads();
+    int before = smisc[3];
+    for (int w = 0; w < wave; ++w) before += smisc[8 + w];
+    const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
+    if (fr && pos < nlead) sfree[pos] = s;
+    __syncthreads();
+    if (tid == 0) smisc[3] += smisc[8] + smisc[9] + smisc[10] + smisc[11];
+    __syncthreads();
+  }
+  // resolve dst: leaders take sfree[ordinal]; followers copy their leader's
+  if (tid < keep && slead[tid] == tid) sdst[tid] = sfree[sdst[tid]];
+  __syncthreads();
+  if (tid < keep && slead[tid] != tid) sdst[tid] = sdst[slead[tid]];
+  __syncthreads();
+
+  // next beam tables (BeamState copy + the list updates of uisrnn.py:425-433,451)
+  for (int e = tid; e < keep * Kmax; e += 256) {
+    const int r = e / Kmax, c2 = e - r * Kmax;
+    const int i = swin[r];
+    int b = 0;
+    while (i >= sbase[b + 1]) ++b;
+    const int c = i - sbase[b];
+    const int Kb = sK[b];
+    const bool is_new = c == Kb;
+    const int Knew = Kb + (is_new ? 1 : 0);
+    if (c2 < Knew && c2 < Kmax) {
+      int slot, blk;
+      if (c2 == c) { slot = sdst[r]; blk = is_new ? 1 : sblk[b * Kmax + c] + (c != slast[b] ? 1 : 0); }
+      else { slot = sslot[b * Kmax + c2]; blk = sblk[b * Kmax + c2]; }
+      st.beam_slot[(bnxt + r) * Kmax + c2] = slot;
+      st.beam_blk[(bnxt + r) * Kmax + c2] = blk;
+    }
+  }
+  if (tid < keep) {
+    const int r = tid;
+    const int i = swin[r];
+    int b = 0;
+    while (i >= sbase[b + 1]) ++b;
+    const int c = i - sbase[b];
+    const int Kb = sK[b];
+    const bool is_new = c == Kb;
+    int Knew = Kb + (is_new ? 1 : 0);
+    if (Knew > Kmax) { Knew = Kmax; st.overflow[u] = 1; }  // cluster cap hit: utterance flagged
+    st.beam_K[bnxt + r] = Knew;
+    st.beam_last[bnxt + r] = c;
+    st.beam_sum[bnxt + r] = ssum[b] + ((is_new || c != slast[b]) ? 1 : 0);
+    st.beam_score[bnxt + r] = scscore[i];
+    st.bp[((size_t)st.tau * st.off[u] + step) * B + r] = ((unsigned)b << 16) | (unsigned)c;
+    atomicMax(&st.counters[3], (unsigned long long)Knew);
+    if (slead[r] == r) {  // emit the rnn row
+      const int src = ssrc[r];
+      const int nprev = src >= 0 ? st.pool_cnt[(size_t)u * S + src] : 0;
+      st.pool_cnt[(size_t)u * S + sdst[r]] = nprev + 1;
+      const int pos = atomicAdd(&st.nrows[par], 1);
+      RnnRow rr; rr.utt = u; rr.src = src; rr.dst = sdst[r]; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
+      st.rows[pos] = rr;
+    }
+  }
+  if (tid == 0) {
+    st.beam_n[(size_t)nxt * U + u] = keep;
+    st.utt_step[u] = step + 1;
+    atomicAdd(&st.counters[0], (unsigned long long)nlead);
+    atomicAdd(&st.counters[1], (unsigned long long)keep);
+    atomicAdd(&st.counters[2], (unsigned long long)C);
+  }
+}
+
+// trace[-N:] of the best hypothesis (uisrnn.py:561) by walking the back-pointers.
+__global__ void k_backtrace(DecodeState st, int32_t* __restrict__ labels, float* __restrict__ scores,
+                            float* __restrict__ beam_scores) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= st.U) return;
+  const long N = (long)(st.off[u + 1] - st.off[u]);
+  const long T = (long)st.tau * N;
+  const int par = (int)(T & 1);  // parity holding the final beam
+  const int nb = N > 0 ? st.beam_n[(size_t)par * st.U + u] : 0;
+  const size_t e = ((size_t)par * st.U + u) * st.B;
+  if (beam_scores)
+    for (int b = 0; b < st.B; ++b) beam_scores[(size_t)u * st.B + b] = b < nb ? st.beam_score[e + b] : INFINITY;
+  if (scores) scores[u] = nb > 0 ? st.beam_score[e] : (N > 0 ? INFINITY : 0.0f);
+  if (N == 0) return;
+  int32_t* out = labels + st.off[u];
+  if (nb == 0) { for (long i = 0; i < N; ++i) out[i] = -1; return; }
+  const uint32_t* bp = st.bp + (size_t)st.tau * st.off[u] * st.B;
+  int r = 0;
+  for (long s = T - 1; s >= T - N; --s) {
+    const uint32_t v = bp[(size_t)s * st.B + r];
+    out[s - (T - N)] = (int32_t)(v & 0xffffu);
+    r = (int)(v >> 16);
+  }
+}

@@ -1,0 +1,224 @@
+"""Host-side mirror of ``uisrnn.UISRNN`` for the decode path.
+
+Same constructor, ``load`` / ``save`` / ``predict`` / ``predict_single`` and
+module-level ``parallel_predict`` as the reference (uisrnn/uisrnn.py:80-623),
+same argument meaning and the same exceptions; the beam search itself runs in
+libuisrnn_hip.so on the MI355X through uisrnn_amd._capi.  There is no CPU
+implementation behind this class: without the HIP library and a gfx950 device
+``predict`` raises.
+
+Training (``fit``) is outside the scope of this package: train with the
+reference and ``load()`` its checkpoint here.
+"""
+
+import numpy as np
+
+from uisrnn_amd import _capi
+from uisrnn_amd import weights
+
+_DEFAULT_MAX_CLUSTERS = 16
+_MAX_CLUSTERS_LIMIT = 1024
+
+
+class UISRNN:
+  """Unbounded Interleaved-State RNN -- MI355X decode."""
+
+  def __init__(self, args):
+    """Construct from the model namespace (uisrnn/uisrnn.py:83-107).
+
+    Weights are freshly initialised like the reference's; use load() or
+    load_params() to install trained ones.
+    """
+    self.observation_dim = args.observation_dim
+    self.params = weights.init_params(
+        args.observation_dim, args.rnn_hidden_size, args.rnn_depth,
+        sigma2=args.sigma2, transition_bias=args.transition_bias,
+        crp_alpha=args.crp_alpha)
+    self.estimate_sigma2 = args.sigma2 is None
+    self.estimate_transition_bias = args.transition_bias is None
+    self.device_index = int(getattr(args, 'device_index', 0))
+    self.verbosity = getattr(args, 'verbosity', 3)
+    self._decoder = None
+    self.last_stats = None
+
+  # ---- the attributes callers of the reference read and write
+  @property
+  def transition_bias(self):
+    return self.params['transition_bias']
+
+  @transition_bias.setter
+  def transition_bias(self, value):
+    self.params['transition_bias'] = value
+    self._invalidate()
+
+  @property
+  def transition_bias_denominator(self):
+    return self.params.get('transition_bias_denominator', 0.0)
+
+  @property
+  def crp_alpha(self):
+    return self.params['crp_alpha']
+
+  @crp_alpha.setter
+  def crp_alpha(self, value):
+    self.params['crp_alpha'] = value
+    self._invalidate()
+
+  @property
+  def sigma2(self):
+    return self.params['sigma2']
+
+  @sigma2.setter
+  def sigma2(self, value):
+    self.params['sigma2'] = np.broadcast_to(
+        np.asarray(value, dtype=np.float32), (self.observation_dim,)).copy()
+    self._invalidate()
+
+  @property
+  def rnn_init_hidden(self):
+    depth, hid = self.params['rnn_depth'], self.params['rnn_hidden_size']
+    return self.params['rnn_init_hidden'].reshape(depth, 1, hid)
+
+  def _invalidate(self):
+    if self._decoder is not None:
+      self._decoder.close()
+    self._decoder = None
+
+  def load_params(self, params):
+    """Install a parameter dict (uisrnn_amd.weights) wholesale."""
+    if params['observation_dim'] != self.observation_dim:
+      raise ValueError('parameters do not match args.observation_dim')
+    self.params = params
+    self._invalidate()
+
+  def load(self, filepath):
+    """Load a checkpoint written by the reference's save() (uisrnn.py:149-170)."""
+    self.load_params(weights.load_checkpoint(filepath))
+
+  def save(self, filepath):
+    """Write the reference's checkpoint format (uisrnn.py:135-147)."""
+    weights.save_checkpoint(self.params, filepath)
+
+  def fit(self, *unused_args, **unused_kwargs):
+    raise NotImplementedError(
+        'Training is outside the scope of uisrnn_amd (decode path only): '
+        'train with google/uis-rnn and load() the checkpoint.')
+
+  fit_concatenated = fit
+
+  def _get_decoder(self):
+    if self.params['transition_bias'] is None:
+      # the reference fails in np.log(None) (uisrnn.py:416-418)
+      raise TypeError('transition_bias is None: fit or load a model first.')
+    if self._decoder is None:
+      self._decoder = _capi.Decoder(self.params, self.device_index)
+    return self._decoder
+
+  def _check_sequence(self, test_sequence):
+    """The reference's argument checks, uisrnn/uisrnn.py:510-521."""
+    if (not isinstance(test_sequence, np.ndarray) or
+        test_sequence.dtype != float):
+      raise TypeError('test_sequence should be a numpy array of float type.')
+    if test_sequence.ndim != 2:
+      raise ValueError('test_sequence must be 2-dim array.')
+    if test_sequence.shape[1] != self.observation_dim:
+      raise ValueError('test_sequence does not match the dimension specified '
+                       'by args.observation_dim.')
+
+  def _decode_batch(self, sequences, args, flags=0):
+    """Decode a list of validated sequences in one lock-step batch."""
+    decoder = self._get_decoder()
+    n_utt = len(sequences)
+    lens = np.array([s.shape[0] for s in sequences], dtype=np.int64)
+    offsets = np.zeros(n_utt + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(lens)
+    frames = np.empty((int(offsets[-1]), self.observation_dim), dtype=np.float32)
+    for seq, start in zip(sequences, offsets[:-1]):
+      # float64 -> float32 once, like torch.from_numpy(seq).float() (uisrnn.py:525)
+      frames[start:start + seq.shape[0]] = seq
+    results = [None] * n_utt
+    pending = list(range(n_utt))
+    cap = int(getattr(args, 'max_clusters', 0) or _DEFAULT_MAX_CLUSTERS)
+    stats = None
+    while pending:
+      sub_lens = lens[pending]
+      sub_off = np.zeros(len(pending) + 1, dtype=np.int64)
+      sub_off[1:] = np.cumsum(sub_lens)
+      if len(pending) == n_utt:
+        sub_frames = frames
+      else:
+        sub_frames = np.concatenate(
+            [frames[offsets[u]:offsets[u + 1]] for u in pending], axis=0)
+      out = decoder.decode(sub_frames, sub_off, args.beam_size, args.look_ahead,
+                           args.test_iteration, max_clusters=cap, flags=flags)
+      if stats is None:
+        stats = out['stats']
+      still = []
+      for k, u in enumerate(pending):
+        if out['overflow'][k]:
+          still.append(u)
+        else:
+          results[u] = out['labels'][sub_off[k]:sub_off[k + 1]].tolist()
+      pending = still
+      if pending:
+        # a surviving hypothesis opened more clusters than the device tables
+        # hold: decode those utterances again with twice the room
+        cap *= 2
+        if cap > _MAX_CLUSTERS_LIMIT:
+          raise RuntimeError(
+              'more than {} clusters per hypothesis'.format(_MAX_CLUSTERS_LIMIT))
+    self.last_stats = stats
+    return results
+
+  def predict_single(self, test_sequence, args):
+    """Predict labels for one test sequence (uisrnn/uisrnn.py:479-562).
+
+    Args:
+      test_sequence: 2-dim float64 numpy array [N, D].
+      args: inference namespace (beam_size, look_ahead, test_iteration).
+
+    Returns:
+      list of N ints: the predicted cluster id per frame.
+
+    Raises:
+      TypeError: test_sequence is not a float numpy array.
+      ValueError: wrong rank or observation dimension.
+    """
+    self._check_sequence(test_sequence)
+    return self._decode_batch([test_sequence], args)[0]
+
+  def predict(self, test_sequences, args):
+    """Predict labels for one sequence or a list of them (uisrnn.py:564-590).
+
+    A list is decoded as ONE lock-step batch on the GPU (the reference loops
+    over it serially); the results are the same as calling predict_single on
+    each element.
+
+    Raises:
+      TypeError: test_sequences is neither a list nor a numpy array.
+    """
+    if isinstance(test_sequences, np.ndarray):
+      return self.predict_single(test_sequences, args)
+    if isinstance(test_sequences, list):
+      for test_sequence in test_sequences:
+        self._check_sequence(test_sequence)
+      if not test_sequences:
+        return []
+      return self._decode_batch(test_sequences, args)
+    raise TypeError('test_sequences should be either a list or numpy array.')
+
+
+def parallel_predict(model, test_sequences, args, num_processes=4):
+  """Drop-in for uisrnn.parallel_predict (uisrnn/uisrnn.py:593-623).
+
+  The reference maps utterances over a forkserver process pool; here the
+  utterances of the list are already decoded concurrently in one GPU batch,
+  so num_processes is accepted and ignored.
+
+  Raises:
+    TypeError: test_sequences is not a list.
+  """
+  del num_processes
+  if not isinstance(test_sequences, list):
+    raise TypeError('test_sequences must be a list.')
+  return model.predict(test_sequences, args)
