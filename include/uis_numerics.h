@@ -26,19 +26,35 @@
 #define UIS_HD static inline
 #endif
 
+/* Bumped whenever the order of operations below changes; liboracle.so and
+   libuisrnn_hip.so both export it and the tests require them to agree, so a
+   stale binary on either side is caught instead of showing up as 1-ulp noise. */
+#define UIS_NUMERICS_VERSION 2
+
 /* Dense chains pad their contraction length to a multiple of this. */
 #define UIS_KBLOCK 16
 
+/* Every dense contraction is cut into this many K segments. */
+#define UIS_KSPLIT 8
+
 /*
  * Contraction order of every dense chain (GRU gates, mean head, input
- * projection).  acc starts at the bias; the K axis (zero padded to a multiple
- * of 16) is walked block by block, and inside a block in the order
+ * projection):  out = (((c_0 + c_1) + c_2) + ... + c_7).
+ * The K axis (zero padded to a multiple of 16) is nKb blocks of 16; segment s
+ * owns blocks [s*q, min((s+1)*q, nKb)) with q = ceil(nKb / UIS_KSPLIT).  c_0
+ * starts at the bias, c_s (s > 0) at +0.0f, an empty segment stays +0.0f and is
+ * still added.  Inside a segment the blocks are walked in increasing order and
+ * inside a block in the order
  *   0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15
- * with one fmaf per element.  This is what a v_mfma_f32_16x16x4_f32 chain
+ * with one fmaf per element.  That is what a v_mfma_f32_16x16x4_f32 chain
  * computes when every lane fetches four consecutive k of its row with one
  * 16-byte load (register r of k-lane q holds k = 4q + r; MFMA number r sums
- * q = 0..3 in order).
+ * q = 0..3 in order); the eight segments are eight waves of one workgroup whose
+ * partial tiles meet in LDS -- eight times the loads in flight and an eighth of
+ * the serial stream per wave, which is what bounds a skinny GEMM on MI355X.
  */
+UIS_HD int uis_kseg_blocks(int nKb) { return (nKb + UIS_KSPLIT - 1) / UIS_KSPLIT; }
+
 UIS_HD int uis_korder(int i) { /* i in [0,16) -> k offset inside the block */
   return ((i & 3) << 2) | (i >> 2);
 }

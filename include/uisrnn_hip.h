@@ -80,8 +80,9 @@ typedef struct uis_decode_opts {
                                     several share the same cluster state (A/B switch;
                                     results are bit-identical either way)            */
 #define UIS_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of via hipGraph  */
-#define UIS_FLAG_PROFILE    0x4u /* bracket every kernel with HIP events on the
-                                    decode stream and fill uis_stats.kernel_*      */
+#define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
+                                    decode stream (hipExtLaunchKernelGGL: the dispatch's
+                                    own begin/end timestamps) and fill uis_stats.kernel_* */
 
 #define UIS_N_KERNELS 8
 typedef struct uis_stats {
@@ -112,6 +113,9 @@ enum {
 typedef struct uis_handle uis_handle;
 
 int32_t uis_abi_version(void);
+
+/* UIS_NUMERICS_VERSION of include/uis_numerics.h this library was built with. */
+int32_t uis_numerics_version(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
 int32_t uis_device_count(void);
@@ -159,6 +163,20 @@ int32_t uis_decode_device(uis_handle* h, const float* d_frames, const int64_t* o
  *   beam_scores_out : host float32 [n_utt * beam_size] or NULL (+inf padded)
  */
 int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out);
+
+/*
+ * Read back the per-model constants computed at uis_create with the decode
+ * kernels: m0 [D] and h1 [depth * H], (m0, h1) = CoreRNN(0, rnn_init_hidden)
+ * (uisrnn/uisrnn.py:435-439).  Host pointers; either may be NULL.
+ */
+int32_t uis_model_constants(uis_handle* h, float* m0_out, float* h1_out);
+
+/*
+ * One CoreRNN.forward for seq_len = 1, batch = 1 (uisrnn/uisrnn.py:45-52) through the
+ * decode kernels: x [D], h_in [depth * H] -> mean_out [D], h_out [depth * H] (host
+ * pointers).  Unit-level entry point for parity tests; the decode does not call it.
+ */
+int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in, float* mean_out, float* h_out);
 
 const char* uis_last_error(void);
 

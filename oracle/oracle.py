@@ -28,9 +28,9 @@ def build(force=False):
 def lib():
   global _lib
   if _lib is None:
-    if not os.path.exists(LIB_PATH):
-      build()
+    build()  # make: a no-op when liboracle.so is newer than its sources
     _lib = ctypes.CDLL(LIB_PATH)
+    _lib.uis_oracle_numerics_version.restype = ctypes.c_int32
     fp = ctypes.POINTER(ctypes.c_float)
     i32p = ctypes.POINTER(ctypes.c_int32)
     i64p = ctypes.POINTER(ctypes.c_int64)
@@ -49,6 +49,10 @@ def lib():
     _lib.uis_oracle_constants.argtypes = [
         ctypes.POINTER(_capi.ModelDesc), fp, fp]
   return _lib
+
+
+def numerics_version():
+  return int(lib().uis_oracle_numerics_version())
 
 
 def _fp(a):

@@ -75,18 +75,28 @@ static float* transpose_canon(const float* W, int n_out, int K) {
   return t;
 }
 
-/* out[j] = bias[j] + sum_k W[j][k] v[k], canonical order, one fmaf per term;
-   padding terms are fmaf(0, 0, acc) like the zero-padded device buffers. */
+/* out[j] = bias[j] + sum_k W[j][k] v[k] in the canonical order of uis_numerics.h:
+   UIS_KSPLIT segment chains (one fmaf per term, padding terms are fmaf(0, 0, acc)
+   like the zero-padded device buffers) combined left to right. */
 static void dense_chain(const float* wt, const float* bias, const float* v, int K,
                         int n_out, float* out) {
   int Kp = round_up(K, UIS_KBLOCK);
-  for (int j = 0; j < n_out; ++j) out[j] = bias[j];
-  for (int kk = 0; kk < Kp; ++kk) {
-    int k = canon_k(kk, K);
-    float vk = k < 0 ? 0.0f : v[k];
-    const float* row = wt + (size_t)kk * n_out;
-    for (int j = 0; j < n_out; ++j) out[j] = fmaf(row[j], vk, out[j]);
+  int nKb = Kp / UIS_KBLOCK;
+  int q = uis_kseg_blocks(nKb);
+  float* seg = (float*)malloc((size_t)n_out * sizeof(float));
+  for (int s = 0; s < UIS_KSPLIT; ++s) {
+    for (int j = 0; j < n_out; ++j) seg[j] = s == 0 ? bias[j] : 0.0f;
+    int kb0 = s * q, kb1 = (s + 1) * q < nKb ? (s + 1) * q : nKb;
+    for (int kk = kb0 * UIS_KBLOCK; kk < kb1 * UIS_KBLOCK; ++kk) {
+      int k = canon_k(kk, K);
+      float vk = k < 0 ? 0.0f : v[k];
+      const float* row = wt + (size_t)kk * n_out;
+      for (int j = 0; j < n_out; ++j) seg[j] = fmaf(row[j], vk, seg[j]);
+    }
+    if (s == 0) for (int j = 0; j < n_out; ++j) out[j] = seg[j];
+    else for (int j = 0; j < n_out; ++j) out[j] = out[j] + seg[j];
   }
+  free(seg);
 }
 
 /* CoreRNN.forward for seq_len = 1, batch = 1 (uisrnn/uisrnn.py:45-52). */
@@ -468,6 +478,8 @@ ORACLE_EXPORT int32_t uis_oracle_decode(const uis_model_desc* desc, const float*
   model_free(m);
   return UIS_OK;
 }
+
+ORACLE_EXPORT int32_t uis_oracle_numerics_version(void) { return UIS_NUMERICS_VERSION; }
 
 /* Unit-level entry points so tests can pin single functions against the reference. */
 

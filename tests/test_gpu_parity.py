@@ -43,6 +43,33 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
   return out, ref
 
 
+def test_same_numerics_version(oracle_lib):
+  """Both binaries were built from the same include/uis_numerics.h."""
+  assert (_capi.load_library().uis_numerics_version() ==
+          oracle_lib.numerics_version())
+
+
+def test_rnn_step_bit_exact(oracle_lib):
+  """CoreRNN.forward (uisrnn.py:45-52): kernels vs oracle, and vs the reference's outputs."""
+  for name in ('tiny_d16', 'toy_d2_depth2', 'd32_lookahead3', 'd20_h24_depth3',
+               'tracker_d256'):
+    case = golden_util.load_case(name)
+    dec = _capi.Decoder(case['params'])
+    unit = case['unit']
+    for x, h, mean_ref, h_ref in zip(unit['unit_x'], unit['unit_h'],
+                                     unit['unit_mean'], unit['unit_hout']):
+      mean, hout = dec.rnn_step(x, h)
+      mean_o, hout_o = oracle_lib.rnn_step(case['params'], x, h)
+      assert np.array_equal(_bits(mean), _bits(mean_o))
+      assert np.array_equal(_bits(hout), _bits(hout_o))
+      np.testing.assert_allclose(mean, mean_ref, rtol=1e-4, atol=1e-6)
+      np.testing.assert_allclose(hout, h_ref, rtol=1e-4, atol=1e-6)
+    m0, h1 = dec.constants()
+    m0_o, h1_o = oracle_lib.constants(case['params'])
+    assert np.array_equal(_bits(m0), _bits(m0_o))
+    assert np.array_equal(_bits(h1), _bits(h1_o))
+
+
 @pytest.mark.parametrize('name', ['tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
                                   'd20_h24_depth3'])
 def test_golden_cases_bit_exact(name, oracle_lib):

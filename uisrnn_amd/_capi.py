@@ -178,7 +178,7 @@ def load_library(path=None):
   global _lib
   if _lib is not None and path is None:
     return _lib
-  path = path or LIB_PATH
+  path = path or os.environ.get('UIS_LIB_PATH') or LIB_PATH
   if not os.path.exists(path):
     raise HipLibraryError(
         '{} not found: build it with `python -m uisrnn_amd.build` (hipcc, '
@@ -189,6 +189,8 @@ def load_library(path=None):
   i64p = ctypes.POINTER(ctypes.c_int64)
   lib.uis_abi_version.restype = i32
   lib.uis_abi_version.argtypes = []
+  lib.uis_numerics_version.restype = i32
+  lib.uis_numerics_version.argtypes = []
   lib.uis_device_count.restype = i32
   lib.uis_device_count.argtypes = []
   lib.uis_create.restype = i32
@@ -206,17 +208,20 @@ def load_library(path=None):
       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Stats)]
   lib.uis_last_decode_info.restype = i32
   lib.uis_last_decode_info.argtypes = [ctypes.c_void_p, i32p, _fp]
+  lib.uis_model_constants.restype = i32
+  lib.uis_model_constants.argtypes = [ctypes.c_void_p, _fp, _fp]
+  lib.uis_rnn_step.restype = i32
+  lib.uis_rnn_step.argtypes = [ctypes.c_void_p, _fp, _fp, _fp, _fp]
   lib.uis_last_error.restype = ctypes.c_char_p
   lib.uis_last_error.argtypes = []
-  if path == LIB_PATH:
-    _lib = lib
+  _lib = lib
   return lib
 
 
 EXPORTED_SYMBOLS = (
-    'uis_abi_version', 'uis_device_count', 'uis_create', 'uis_destroy',
+    'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
     'uis_decode', 'uis_decode_device', 'uis_last_decode_info',
-    'uis_last_error')
+    'uis_model_constants', 'uis_rnn_step', 'uis_last_error')
 
 
 def last_error(lib):
@@ -252,6 +257,27 @@ class Decoder:
       self.close()
     except Exception:  # pylint: disable=broad-except
       pass
+
+  def constants(self):
+    """(m0 [D], h1 [depth, H]) as computed on the device at create time."""
+    m0 = np.empty(self.observation_dim, dtype=np.float32)
+    h1 = np.empty((int(self.params['rnn_depth']),
+                   int(self.params['rnn_hidden_size'])), dtype=np.float32)
+    self._check(self._lib.uis_model_constants(
+        self._handle, m0.ctypes.data_as(_fp), h1.ctypes.data_as(_fp)),
+                'uis_model_constants')
+    return m0, h1
+
+  def rnn_step(self, x, h_in):
+    """CoreRNN.forward of one row on the device: x [D], h_in [depth, H]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    h_in = np.ascontiguousarray(h_in, dtype=np.float32)
+    mean = np.empty(self.observation_dim, dtype=np.float32)
+    h_out = np.empty_like(h_in)
+    self._check(self._lib.uis_rnn_step(
+        self._handle, x.ctypes.data_as(_fp), h_in.ctypes.data_as(_fp),
+        mean.ctypes.data_as(_fp), h_out.ctypes.data_as(_fp)), 'uis_rnn_step')
+    return mean, h_out
 
   def _check(self, rc, what):
     if rc == UIS_OK or rc == UIS_ERR_CLUSTER_CAP:

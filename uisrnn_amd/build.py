@@ -43,16 +43,18 @@ def up_to_date():
   return all(os.path.getmtime(d) <= out_m for d in DEPENDS)
 
 
-def build(force=False, verbose=False):
-  if not force and up_to_date():
+def build(force=False, verbose=False, defines=(), output=None):
+  """Compile the library.  `defines` / `output` build tuning variants for A/B runs."""
+  output = output or OUTPUT
+  if output == OUTPUT and not force and up_to_date():
     return OUTPUT
-  cmd = [hipcc()] + FLAGS + [
+  cmd = [hipcc()] + FLAGS + ['-D' + d for d in defines] + [
       '-I', os.path.join(_ROOT, 'include'), '-I', os.path.join(_HERE, 'csrc'),
-  ] + SOURCES + ['-o', OUTPUT]
+  ] + SOURCES + ['-o', output]
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd)
-  return OUTPUT
+  return output
 
 
 if __name__ == '__main__':

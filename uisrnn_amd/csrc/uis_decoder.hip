@@ -7,6 +7,7 @@
 // per utterance) and one batched CoreRNN evaluation over the surviving
 // hypotheses of ALL utterances (GRU GEMM, mean-head GEMMs).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -125,12 +126,18 @@ int upload(uis_handle* h, const std::vector<float>& v, const float** dst) {
 }
 
 inline dim3 dense_grid(long rows, int tiles) { return dim3((unsigned)((rows + 15) / 16), (unsigned)((tiles + 3) / 4), 1); }
+// 1-D, XCD-aware grid of the per-step dense kernels (dense_block_map in uis_kernels.hip)
+inline dim3 dense_grid_xcd(long rows, int tiles) {
+  return dim3((unsigned)dense_grid_blocks((int)((rows + 15) / 16), tiles), 1, 1);
+}
 
+// Launches go through here.  With UIS_FLAG_PROFILE every kernel is launched with
+// hipExtLaunchKernelGGL's start/stop events, which carry the dispatch's own begin/end
+// timestamps (what rocprofv3 --kernel-trace reports), not host-side bracket times.
 struct Launcher {
   uis_handle* h;
   bool profile;
-  int begin(int cls) {
-    if (!profile) return UIS_OK;
+  int events(hipEvent_t* a, hipEvent_t* b, int cls) {
     ProfileEvents& p = h->prof;
     if (p.used + 2 > p.ev.size()) {
       for (int i = 0; i < 2; ++i) {
@@ -140,83 +147,91 @@ struct Launcher {
       }
     }
     p.cls.push_back(cls);
-    HIPCHK(hipEventRecord(p.ev[p.used], h->stream));
+    *a = p.ev[p.used];
+    *b = p.ev[p.used + 1];
+    p.used += 2;
     return UIS_OK;
   }
-  int end() {
-    if (!profile) return UIS_OK;
-    ProfileEvents& p = h->prof;
-    HIPCHK(hipEventRecord(p.ev[p.used + 1], h->stream));
-    p.used += 2;
+  template <typename... KArgs, typename... Args>
+  int run(int cls, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+    if (profile) {
+      hipEvent_t a, b;
+      int rc = events(&a, &b, cls);
+      if (rc) return rc;
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, h->stream, a, b, 0, args...);
+    } else {
+      hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
+    }
+    HIPCHK(hipGetLastError());
     return UIS_OK;
   }
 };
 
-#define LAUNCH(cls, ...)                       \
-  do {                                         \
-    int rc_ = lch.begin(cls);                  \
-    if (rc_) return rc_;                       \
-    __VA_ARGS__;                               \
-    HIPCHK(hipGetLastError());                 \
-    rc_ = lch.end();                           \
-    if (rc_) return rc_;                       \
+#define LAUNCH(...)                       \
+  do {                                    \
+    int rc_ = lch.run(__VA_ARGS__);       \
+    if (rc_) return rc_;                  \
   } while (0)
 
 // One batched CoreRNN evaluation over the rows emitted for step parity `par`.
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
   for (int l = 0; l < m.depth; ++l) {
-    if (l > 0)
-      LAUNCH(UIS_K_UPPER_IN, hipLaunchKernelGGL(k_dense_upper_in, dense_grid(max_rows, m.G / 16), dim3(256), 0,
-                                                h->stream, m, st, par, l));
-    LAUNCH(UIS_K_GRU, hipLaunchKernelGGL(k_dense_gru, dense_grid(max_rows, m.Hp / 16), dim3(256), 0, h->stream, m,
-                                         st, par, l));
+    if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dense_grid_xcd(max_rows, m.G / 16), dim3(512), 0, m, st, par, l);
+    LAUNCH(UIS_K_GRU, k_dense_gru, dense_grid_xcd(max_rows, m.Hp / 16), dim3(512), 0, m, st, par, l);
   }
-  LAUNCH(UIS_K_HEAD1,
-         hipLaunchKernelGGL(k_dense_head1, dense_grid(max_rows, m.Hp / 16), dim3(256), 0, h->stream, m, st, par));
-  LAUNCH(UIS_K_HEAD2,
-         hipLaunchKernelGGL(k_dense_head2, dense_grid(max_rows, m.Dp / 16), dim3(256), 0, h->stream, m, st, par));
+  LAUNCH(UIS_K_HEAD1, k_dense_head1, dense_grid_xcd(max_rows, m.Hp / 16), dim3(512), 0, m, st, par);
+  LAUNCH(UIS_K_HEAD2, k_dense_head2, dense_grid_xcd(max_rows, m.Dp / 16), dim3(512), 0, m, st, par);
   return UIS_OK;
 }
 
-// (m0, h1) = CoreRNN(0, rnn_init_hidden)  (uisrnn.py:435-439), with the decode kernels themselves.
-int bootstrap_constants(uis_handle* h, const float* d_hinit) {
+// One CoreRNN.forward (uisrnn.py:45-52) of a single row with the decode kernels themselves:
+// x [Dp] and h_in [depth][Hp] on the device -> mean [Dp], h_out [depth][Hp] on the device.
+int rnn_step_once(uis_handle* h, const float* d_x, const float* d_hin, float* d_mean, float* d_hout) {
   DevModel& m = h->m;
   Launcher lch{h, false};
-  const size_t hid_elems = (size_t)m.depth * m.Hp;
-  float *d_x = nullptr, *d_gi0 = nullptr, *d_pm = nullptr, *d_ph = nullptr, *d_gi_up = nullptr, *d_a1 = nullptr;
+  float *d_gi0 = nullptr, *d_gi_up = nullptr, *d_a1 = nullptr;
   RnnRow* d_rows = nullptr;
   int32_t* d_nrows = nullptr;
-  HIPCHK(hipMalloc(&d_x, m.Dp * sizeof(float)));
   HIPCHK(hipMalloc(&d_gi0, m.G * sizeof(float)));
-  HIPCHK(hipMalloc(&d_pm, m.Dp * sizeof(float)));
-  HIPCHK(hipMalloc(&d_ph, hid_elems * sizeof(float)));
   HIPCHK(hipMalloc(&d_gi_up, m.G * sizeof(float)));
   HIPCHK(hipMalloc(&d_a1, m.Hp * sizeof(float)));
   HIPCHK(hipMalloc(&d_rows, sizeof(RnnRow)));
   HIPCHK(hipMalloc(&d_nrows, 2 * sizeof(int32_t)));
-  HIPCHK(hipMemsetAsync(d_x, 0, m.Dp * sizeof(float), h->stream));
   RnnRow rr{};
   rr.utt = 0; rr.src = -1; rr.dst = 0; rr.nprev = 0; rr.frame = 0;
   int32_t nr[2] = {1, 1};
   HIPCHK(hipMemcpyAsync(d_rows, &rr, sizeof(rr), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(d_nrows, nr, sizeof(nr), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_dense_input_proj, dense_grid(1, m.G / 16), dim3(256), 0, h->stream, m, d_x, d_gi0, 1L);
-  HIPCHK(hipGetLastError());
+  LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(1, m.G / 16), dim3(256), 0, m, d_x, d_gi0, 1L);
   DecodeState st{};
   st.U = 1; st.B = 1; st.Kmax = 1; st.S = 1; st.L = 1; st.tau = 1;
-  st.gi0 = d_gi0; st.pool_mean = d_pm; st.pool_hid = d_ph; st.rows = d_rows; st.nrows = d_nrows;
+  st.gi0 = d_gi0; st.pool_mean = d_mean; st.pool_hid = d_hout; st.rows = d_rows; st.nrows = d_nrows;
   st.gi_up = d_gi_up; st.a1 = d_a1;
   const float* saved_h1 = m.h1;
-  m.h1 = d_hinit;  // src = -1 reads "h1": make that rnn_init_hidden for this one evaluation
+  m.h1 = d_hin;  // a row with src = -1 reads its hidden state from "h1": point that at h_in
   int rc = launch_rnn(h, lch, st, 0, 1);
   m.h1 = saved_h1;
   if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(const_cast<float*>(m.m0), d_pm, m.Dp * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(const_cast<float*>(m.h1), d_ph, hid_elems * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_x); (void)hipFree(d_gi0); (void)hipFree(d_pm); (void)hipFree(d_ph);
-  (void)hipFree(d_gi_up); (void)hipFree(d_a1); (void)hipFree(d_rows); (void)hipFree(d_nrows);
+  (void)hipFree(d_gi0); (void)hipFree(d_gi_up); (void)hipFree(d_a1); (void)hipFree(d_rows); (void)hipFree(d_nrows);
+  return UIS_OK;
+}
+
+// (m0, h1) = CoreRNN(0, rnn_init_hidden)  (uisrnn.py:435-439).
+int bootstrap_constants(uis_handle* h, const float* d_hinit) {
+  DevModel& m = h->m;
+  float *d_x = nullptr, *d_pm = nullptr, *d_ph = nullptr;
+  const size_t hid_elems = (size_t)m.depth * m.Hp;
+  HIPCHK(hipMalloc(&d_x, m.Dp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_pm, m.Dp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_ph, hid_elems * sizeof(float)));
+  HIPCHK(hipMemsetAsync(d_x, 0, m.Dp * sizeof(float), h->stream));
+  int rc = rnn_step_once(h, d_x, d_hinit, d_pm, d_ph);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(const_cast<float*>(m.m0), d_pm, m.Dp * sizeof(float), hipMemcpyDeviceToDevice));
+  HIPCHK(hipMemcpy(const_cast<float*>(m.h1), d_ph, hid_elems * sizeof(float), hipMemcpyDeviceToDevice));
+  (void)hipFree(d_x); (void)hipFree(d_pm); (void)hipFree(d_ph);
   return UIS_OK;
 }
 
@@ -325,24 +340,21 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   hipLaunchKernelGGL(k_init_state, dim3((U + 255) / 256), dim3(256), 0, h->stream, st);
   HIPCHK(hipGetLastError());
   if (F > 0) {
-    LAUNCH(UIS_K_INPUT_PROJ, {
-      hipLaunchKernelGGL(k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, h->stream, m, d_x,
-                         h->gi0.as<float>(), (long)F);
-      hipLaunchKernelGGL(k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, h->stream, m, d_x,
-                         h->mse0.as<float>(), (long)F);
-    });
+    LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, h->gi0.as<float>(),
+           (long)F);
+    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
+           h->mse0.as<float>(), (long)F);
   }
 
   // ---- lock-step decode
   for (int64_t step = 0; step < maxT; ++step) {
     const int par = (int)(step & 1);
-    LAUNCH(UIS_K_SELECT,
-           hipLaunchKernelGGL(k_select, dim3(U), dim3(256), (size_t)lds.total, h->stream, m, st, par));
+    LAUNCH(UIS_K_SELECT, k_select, dim3(U), dim3(256), (size_t)lds.total, m, st, par);
     rc = launch_rnn(h, lch, st, par, max_rows);
     if (rc) return rc;
   }
-  LAUNCH(UIS_K_BACKTRACE, hipLaunchKernelGGL(k_backtrace, dim3((U + 63) / 64), dim3(64), 0, h->stream, st, d_labels,
-                                             d_scores, h->beam_scores_out.as<float>()));
+  LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((U + 63) / 64), dim3(64), 0, st, d_labels, d_scores,
+         h->beam_scores_out.as<float>());
   HIPCHK(hipEventRecord(h->ev_end, h->stream));
 
   unsigned long long counters[4] = {0, 0, 0, 0};
@@ -382,6 +394,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 }  // namespace
 
 UIS_EXPORT int32_t uis_abi_version(void) { return UIS_ABI_VERSION; }
+UIS_EXPORT int32_t uis_numerics_version(void) { return UIS_NUMERICS_VERSION; }
 
 UIS_EXPORT int32_t uis_device_count(void) {
   int n = 0;
@@ -495,6 +508,47 @@ UIS_EXPORT int32_t uis_decode(uis_handle* h, const float* frames, const int64_t*
   if (scores_out && n_utt > 0)
     HIPCHK(hipMemcpyAsync(scores_out, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return rc;
+}
+
+UIS_EXPORT int32_t uis_model_constants(uis_handle* h, float* m0_out, float* h1_out) {
+  if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
+  const DevModel& m = h->m;
+  HIPCHK(hipSetDevice(h->device));
+  if (m0_out) {
+    std::vector<float> tmp(m.Dp);
+    HIPCHK(hipMemcpy(tmp.data(), m.m0, (size_t)m.Dp * 4, hipMemcpyDeviceToHost));
+    memcpy(m0_out, tmp.data(), (size_t)m.D * 4);
+  }
+  if (h1_out) {
+    std::vector<float> tmp((size_t)m.depth * m.Hp);
+    HIPCHK(hipMemcpy(tmp.data(), m.h1, tmp.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < m.depth; ++l) memcpy(h1_out + (size_t)l * m.H, tmp.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+  }
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in, float* mean_out, float* h_out) {
+  if (!h || !x || !h_in || !mean_out || !h_out) return fail(UIS_ERR_INVALID_ARG, "null argument");
+  const DevModel& m = h->m;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t hid_elems = (size_t)m.depth * m.Hp;
+  std::vector<float> xp(m.Dp, 0.0f), hp(hid_elems, 0.0f), mo(m.Dp), ho(hid_elems);
+  memcpy(xp.data(), x, (size_t)m.D * 4);
+  for (int l = 0; l < m.depth; ++l) memcpy(hp.data() + (size_t)l * m.Hp, h_in + (size_t)l * m.H, (size_t)m.H * 4);
+  float *d_x = nullptr, *d_h = nullptr, *d_m = nullptr, *d_o = nullptr;
+  HIPCHK(hipMalloc(&d_x, xp.size() * 4)); HIPCHK(hipMalloc(&d_h, hp.size() * 4));
+  HIPCHK(hipMalloc(&d_m, mo.size() * 4)); HIPCHK(hipMalloc(&d_o, ho.size() * 4));
+  HIPCHK(hipMemcpy(d_x, xp.data(), xp.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_h, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+  int rc = rnn_step_once(h, d_x, d_h, d_m, d_o);
+  if (rc == UIS_OK) {
+    HIPCHK(hipMemcpy(mo.data(), d_m, mo.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ho.data(), d_o, ho.size() * 4, hipMemcpyDeviceToHost));
+    memcpy(mean_out, mo.data(), (size_t)m.D * 4);
+    for (int l = 0; l < m.depth; ++l) memcpy(h_out + (size_t)l * m.H, ho.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+  }
+  (void)hipFree(d_x); (void)hipFree(d_h); (void)hipFree(d_m); (void)hipFree(d_o);
   return rc;
 }
 

@@ -12,6 +12,7 @@
 #include "uis_kernels.h"
 #include "uis_numerics.h"
 
+
 // ------------------------------------------------------------------ helpers
 
 __device__ __forceinline__ float wave_tree_sum(float v) {
@@ -41,56 +42,141 @@ __device__ __forceinline__ float wave_weighted_mse(const float* __restrict__ mea
 
 // -------------------------------------------------------------- dense chains
 //
-// out[row][f] = bias[f] + sum_k W[f][k] * in[row][k] as v_mfma_f32_16x16x4_f32
-// chains.  A operand = weights (16 features x 4 k), B operand = 16 rnn rows.
-// Lane l holds, for its row (l & 15), features 4*(l>>4) .. +3 of the tile.
-// One wave owns one 16-row x 16-feature tile per gate; K is walked in blocks of
-// 16 with one 16-byte load per operand per lane (weights pre-tiled so the load is
-// one contiguous KiB per wave).
+// out[row][f] = bias[f] + sum_k W[f][k] * in[row][k] as v_mfma_f32_16x16x4_f32 chains in
+// the canonical order of uis_numerics.h (UIS_KSPLIT segment chains combined left to right).
+// A operand = weights (16 features x 4 k), B operand = 16 rows.  Lane l holds, for its
+// row (l & 15), features 4*(l>>4) .. +3 of the tile.  K is walked in blocks of 16 with one
+// 16-byte load per operand per lane; the weights are pre-tiled on the host so that a
+// wave's A load is one contiguous KiB.
+//
+// Two schedules of the same arithmetic:
+//   splitk_tile  -- per-step kernels (few hundred rows: a skinny GEMM whose cost is the
+//                   serial operand stream of a wave).  One 512-thread workgroup per
+//                   16-row x 16-feature tile; wave w owns K segment w, so a tile's operand
+//                   stream is cut in 8 and 8x as many loads are in flight; the partial
+//                   tiles meet in LDS and thread t < 256 combines element (row t>>4,
+//                   feature t&15) in segment order.
+//   fullk_tile   -- input projection (tens of thousands of rows, once per decode): one
+//                   wave walks all segments of its tile and combines on the fly.
+
+#define UIS_STAGE 4   // k-blocks fetched per pipeline stage
 
 template <int NG>
-__device__ __forceinline__ void dense_mainloop(const float* __restrict__ Wt, int tiles_per_gate,
-                                               int tile, int nKb, const float* __restrict__ inrow,
-                                               f32x4 (&acc)[NG]) {
-  const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NG], const f32x4* bp, int kb0, int kb1,
+                                             f32x4 (&acc)[NG]) {
+  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
+    f32x4 a[UIS_STAGE][NG], b[UIS_STAGE];
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) a[u][g] = wp[g][(size_t)kk * 64];
+      b[u] = bp[(size_t)kk * 4];
+    }
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      if (kb + u < kb1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][r], b[u][r], acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// Split-K schedule.  bias points at this tile's 16 biases of gate 0; gate g's are
+// gate_stride floats further.  spart: LDS [UIS_KSPLIT][NG][256].  Ends with the barrier;
+// afterwards splitk_combine(t) returns element (row t>>4, feature t&15).
+template <int NG>
+__device__ __forceinline__ void splitk_tile(const float* __restrict__ Wt, int tiles_per_gate, int tile, int nKb,
+                                            const float* __restrict__ inrow, const float* __restrict__ bias,
+                                            int gate_stride, float* spart) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int q = lane >> 4;
+  const int per = uis_kseg_blocks(nKb);
+  const int kb0 = w * per;
+  const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
   const f32x4* wp[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g)
     wp[g] = reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile) * nKb) * 64 + lane;
   const f32x4* bp = reinterpret_cast<const f32x4*>(inrow) + q;
-  f32x4 a_cur[NG], b_cur;
+  f32x4 acc[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) a_cur[g] = wp[g][0];
-  b_cur = bp[0];
-  for (int kb = 0; kb < nKb; ++kb) {
-    f32x4 a_nxt[NG], b_nxt;
-    const int kn = kb + 1 < nKb ? kb + 1 : kb;
+  for (int g = 0; g < NG; ++g)
+    acc[g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q)
+                    : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (kb0 < kb1) chain_blocks<NG>(wp, bp, kb0, kb1, acc);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) a_nxt[g] = wp[g][(size_t)kn * 64];
-    b_nxt = bp[(size_t)kn * 4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[g][r], b_cur[r], acc[g], 0, 0, 0);
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) a_cur[g] = a_nxt[g];
-    b_cur = b_nxt;
-  }
+  for (int g = 0; g < NG; ++g)
+    *reinterpret_cast<f32x4*>(spart + ((size_t)(w * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[g];
+  __syncthreads();
 }
 
-__device__ __forceinline__ f32x4 load_bias4(const float* bias, int f) {
-  return *reinterpret_cast<const f32x4*>(bias + f);
+template <int NG>
+__device__ __forceinline__ float splitk_combine(const float* spart, int g, int t) {
+  float v = spart[(size_t)g * 256 + t];
+#pragma unroll
+  for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) v = v + spart[(size_t)(sgm * NG + g) * 256 + t];
+  return v;
+}
+
+// Full-K schedule: one wave, all segments, combined on the fly.
+__device__ __forceinline__ f32x4 fullk_tile(const float* __restrict__ Wt, int tile, int nKb,
+                                            const float* __restrict__ inrow, const float* __restrict__ bias) {
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4;
+  const int per = uis_kseg_blocks(nKb);
+  const f32x4* wp[1] = {reinterpret_cast<const f32x4*>(Wt) + ((size_t)tile * nKb) * 64 + lane};
+  const f32x4* bp = reinterpret_cast<const f32x4*>(inrow) + q;
+  f32x4 total = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+  for (int sgm = 0; sgm < UIS_KSPLIT; ++sgm) {
+    const int kb0 = sgm * per;
+    const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
+    f32x4 acc[1];
+    acc[0] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (kb0 < kb1) chain_blocks<1>(wp, bp, kb0, kb1, acc);
+    if (sgm == 0) total = acc[0];
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) total[i] = total[i] + acc[0][i];
+    }
+  }
+  return total;
+}
+
+// Workgroup -> (row tile, feature tile) with XCD affinity: workgroup b runs on XCD b % 8
+// (observed dispatch order, used for speed only), so each XCD gets a fixed subset of the
+// feature tiles and its L2 streams only that slice of the weights.
+__host__ __device__ inline int dense_grid_blocks(int nrt, int nft) {
+  if (nft < 8 && 8 % nft == 0) { const int share = 8 / nft; return ((nrt + share - 1) / share) * 8; }
+  return nrt * nft;
+}
+__device__ __forceinline__ void dense_block_map(int b, int nrt, int nft, int& rt, int& ft) {
+  if (nft >= 8 && nft % 8 == 0) {
+    const int xcd = b & 7, slot = b >> 3, per = nft >> 3;
+    ft = xcd + 8 * (slot % per);
+    rt = slot / per;
+  } else if (nft < 8 && 8 % nft == 0) {
+    const int xcd = b & 7, slot = b >> 3, share = 8 / nft;
+    ft = xcd % nft;
+    rt = (xcd / nft) + share * slot;
+  } else {
+    ft = b % nft;
+    rt = b / nft;
+  }
 }
 
 // gi0[frame][G] = b_ih0 + W_ih0 x[frame]   for every frame of the packed stream.
 __global__ __launch_bounds__(256) void k_dense_input_proj(DevModel m, const float* __restrict__ x,
                                                           float* __restrict__ gi0, long nframes) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.y * 4 + wave;
   const int ntiles = m.G / 16;
+  const int tile = blockIdx.y * 4 + wave;
   if (tile >= ntiles) return;
   const long row0 = (long)blockIdx.x * 16;
   if (row0 >= nframes) return;
@@ -98,118 +184,118 @@ __global__ __launch_bounds__(256) void k_dense_input_proj(DevModel m, const floa
   const bool valid = row < nframes;
   if (!valid) row = nframes - 1;
   const int f = tile * 16 + (lane >> 4) * 4;
-  f32x4 acc[1];
-  acc[0] = load_bias4(m.bih[0], f);
-  dense_mainloop<1>(m.wih[0], 0, tile, m.Dp / 16, x + (size_t)row * m.Dp, acc);
-  if (valid) *reinterpret_cast<f32x4*>(gi0 + (size_t)row * m.G + f) = acc[0];
+  const f32x4 v = fullk_tile(m.wih[0], tile, m.Dp / 16, x + (size_t)row * m.Dp, m.bih[0] + tile * 16);
+  if (valid) *reinterpret_cast<f32x4*>(gi0 + (size_t)row * m.G + f) = v;
 }
 
+// Common prologue of the per-step kernels: which tile is this workgroup, which rnn rows.
+struct StepTile {
+  int rt, ft, row0, nrows;
+  bool active;
+};
+__device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft) {
+  StepTile t;
+  t.nrows = st.nrows[par];
+  const int nrt = (t.nrows + 15) >> 4;
+  t.active = (int)blockIdx.x < dense_grid_blocks(nrt, nft);
+  t.rt = 0; t.ft = 0;
+  if (t.active) {
+    dense_block_map(blockIdx.x, nrt, nft, t.rt, t.ft);
+    t.active = t.rt < nrt && t.ft < nft;
+  }
+  t.row0 = t.rt * 16;
+  return t;
+}
+__device__ __forceinline__ int clamp_row(int row, int nrows) { return row < nrows ? row : nrows - 1; }
+
 // Input-side gates of GRU layer `layer` >= 1: gi_up[row][G] = b_ih + W_ih h'_{layer-1}
-__global__ __launch_bounds__(256) void k_dense_upper_in(DevModel m, DecodeState st, int par, int layer) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.y * 4 + wave;
-  if (tile >= m.G / 16) return;
-  const int nrows = st.nrows[par];
-  const int row0 = blockIdx.x * 16;
-  if (row0 >= nrows) return;
-  int row = row0 + (lane & 15);
-  const bool valid = row < nrows;
-  if (!valid) row = nrows - 1;
-  const RnnRow rr = st.rows[row];
-  const float* in = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * m.depth * m.Hp + (size_t)(layer - 1) * m.Hp;
-  const int f = tile * 16 + (lane >> 4) * 4;
-  f32x4 acc[1];
-  acc[0] = load_bias4(m.bih[layer], f);
-  dense_mainloop<1>(m.wih[layer], 0, tile, m.Hp / 16, in, acc);
-  if (valid) *reinterpret_cast<f32x4*>(st.gi_up + (size_t)row * m.G + f) = acc[0];
+__global__ __launch_bounds__(512) void k_dense_upper_in(DevModel m, DecodeState st, int par, int layer) {
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
+  const StepTile tl = step_tile(st, par, m.G / 16);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, t = threadIdx.x;
+  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
+  const float* in = st.pool_hid + ((size_t)rb.utt * st.S + rb.dst) * m.depth * m.Hp + (size_t)(layer - 1) * m.Hp;
+  splitk_tile<1>(m.wih[layer], 0, tl.ft, m.Hp / 16, in, m.bih[layer] + tl.ft * 16, 0, spart);
+  if (t >= 256) return;
+  const int row = tl.row0 + (t >> 4);
+  if (row >= tl.nrows) return;
+  st.gi_up[(size_t)row * m.G + tl.ft * 16 + (t & 15)] = splitk_combine<1>(spart, 0, t);
 }
 
 // GRU layer: gh = b_hh + W_hh h_src (three gate chains per unit), gates, h' -> dst slot.
-__global__ __launch_bounds__(256) void k_dense_gru(DevModel m, DecodeState st, int par, int layer) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.y * 4 + wave;          // 16 hidden units
-  const int tiles_per_gate = m.Hp / 16;
-  if (tile >= tiles_per_gate) return;
-  const int nrows = st.nrows[par];
-  const int row0 = blockIdx.x * 16;
-  if (row0 >= nrows) return;
-  int row = row0 + (lane & 15);
-  const bool valid = row < nrows;
-  if (!valid) row = nrows - 1;
-  const RnnRow rr = st.rows[row];
+__global__ __launch_bounds__(512) void k_dense_gru(DevModel m, DecodeState st, int par, int layer) {
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 3 * 256];
+  const int nft = m.Hp / 16;
+  const StepTile tl = step_tile(st, par, nft);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, t = threadIdx.x;
   const size_t slot_stride = (size_t)m.depth * m.Hp;
-  const float* hsrc = rr.src >= 0
-      ? st.pool_hid + ((size_t)rr.utt * st.S + rr.src) * slot_stride + (size_t)layer * m.Hp
+  // epilogue operands of element (row t>>4, unit t&15): fetched now, used after the chains
+  const int erow = tl.row0 + (t >> 4);
+  const bool ework = t < 256 && erow < tl.nrows;
+  const int j = tl.ft * 16 + (t & 15);
+  RnnRow re{};
+  float gir = 0.0f, giz = 0.0f, gin = 0.0f, hprev = 0.0f;
+  if (ework) {
+    re = st.rows[erow];
+    const float* gi = layer == 0 ? st.gi0 + (size_t)re.frame * m.G : st.gi_up + (size_t)erow * m.G;
+    const float* hs = re.src >= 0
+        ? st.pool_hid + ((size_t)re.utt * st.S + re.src) * slot_stride + (size_t)layer * m.Hp
+        : m.h1 + (size_t)layer * m.Hp;
+    gir = gi[j]; giz = gi[m.Hp + j]; gin = gi[2 * m.Hp + j]; hprev = hs[j];
+  }
+  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
+  const float* hsrc = rb.src >= 0
+      ? st.pool_hid + ((size_t)rb.utt * st.S + rb.src) * slot_stride + (size_t)layer * m.Hp
       : m.h1 + (size_t)layer * m.Hp;
-  const int j = tile * 16 + (lane >> 4) * 4;       // first of this lane's 4 units
-  f32x4 acc[3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g) acc[g] = load_bias4(m.bhh[layer], g * m.Hp + j);
-  dense_mainloop<3>(m.whh[layer], tiles_per_gate, tile, m.Hp / 16, hsrc, acc);
-  if (!valid) return;
-  const float* gi = layer == 0 ? st.gi0 + (size_t)rr.frame * m.G : st.gi_up + (size_t)row * m.G;
-  const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j);
-  const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j);
-  const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j);
-  const f32x4 h = *reinterpret_cast<const f32x4*>(hsrc + j);
-  f32x4 out;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    out[i] = (j + i < m.H) ? uis_gru_unit(gir[i], giz[i], gin[i], acc[0][i], acc[1][i], acc[2][i], h[i]) : 0.0f;
-  float* hdst = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * slot_stride + (size_t)layer * m.Hp;
-  *reinterpret_cast<f32x4*>(hdst + j) = out;
+  splitk_tile<3>(m.whh[layer], nft, tl.ft, m.Hp / 16, hsrc, m.bhh[layer] + tl.ft * 16, m.Hp, spart);
+  if (!ework) return;
+  const float ghr = splitk_combine<3>(spart, 0, t);
+  const float ghz = splitk_combine<3>(spart, 1, t);
+  const float ghn = splitk_combine<3>(spart, 2, t);
+  const float out = j < m.H ? uis_gru_unit(gir, giz, gin, ghr, ghz, ghn, hprev) : 0.0f;
+  st.pool_hid[((size_t)re.utt * st.S + re.dst) * slot_stride + (size_t)layer * m.Hp + j] = out;
 }
 
 // a1[row] = relu(b1 + W1 h'_top)
-__global__ __launch_bounds__(256) void k_dense_head1(DevModel m, DecodeState st, int par) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.y * 4 + wave;
-  if (tile >= m.Hp / 16) return;
-  const int nrows = st.nrows[par];
-  const int row0 = blockIdx.x * 16;
-  if (row0 >= nrows) return;
-  int row = row0 + (lane & 15);
-  const bool valid = row < nrows;
-  if (!valid) row = nrows - 1;
-  const RnnRow rr = st.rows[row];
-  const float* in = st.pool_hid + ((size_t)rr.utt * st.S + rr.dst) * m.depth * m.Hp + (size_t)(m.depth - 1) * m.Hp;
-  const int f = tile * 16 + (lane >> 4) * 4;
-  f32x4 acc[1];
-  acc[0] = load_bias4(m.b1, f);
-  dense_mainloop<1>(m.w1, 0, tile, m.Hp / 16, in, acc);
-  if (!valid) return;
-  f32x4 out;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = acc[0][i] > 0.0f ? acc[0][i] : 0.0f;
-  *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f) = out;
+__global__ __launch_bounds__(512) void k_dense_head1(DevModel m, DecodeState st, int par) {
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
+  const StepTile tl = step_tile(st, par, m.Hp / 16);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, t = threadIdx.x;
+  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
+  const float* in = st.pool_hid + ((size_t)rb.utt * st.S + rb.dst) * m.depth * m.Hp + (size_t)(m.depth - 1) * m.Hp;
+  splitk_tile<1>(m.w1, 0, tl.ft, m.Hp / 16, in, m.b1 + tl.ft * 16, 0, spart);
+  if (t >= 256) return;
+  const int row = tl.row0 + (t >> 4);
+  if (row >= tl.nrows) return;
+  const float v = splitk_combine<1>(spart, 0, t);
+  st.a1[(size_t)row * m.Hp + tl.ft * 16 + (t & 15)] = v > 0.0f ? v : 0.0f;
 }
 
 // m = b2 + W2 a1; running-mean update (uisrnn.py:425-429) -> dst slot
-__global__ __launch_bounds__(256) void k_dense_head2(DevModel m, DecodeState st, int par) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.y * 4 + wave;
-  if (tile >= m.Dp / 16) return;
-  const int nrows = st.nrows[par];
-  const int row0 = blockIdx.x * 16;
-  if (row0 >= nrows) return;
-  int row = row0 + (lane & 15);
-  const bool valid = row < nrows;
-  if (!valid) row = nrows - 1;
-  const RnnRow rr = st.rows[row];
-  const int f = tile * 16 + (lane >> 4) * 4;
-  f32x4 acc[1];
-  acc[0] = load_bias4(m.b2, f);
-  dense_mainloop<1>(m.w2, 0, tile, m.Hp / 16, st.a1 + (size_t)row * m.Hp, acc);
-  if (!valid) return;
-  f32x4 out = acc[0];
-  if (rr.src >= 0) {
-    const f32x4 old = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)rr.utt * st.S + rr.src) * m.Dp + f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = uis_mean_update(old[i], acc[0][i], rr.nprev);
+__global__ __launch_bounds__(512) void k_dense_head2(DevModel m, DecodeState st, int par) {
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
+  const StepTile tl = step_tile(st, par, m.Dp / 16);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, t = threadIdx.x;
+  const int erow = tl.row0 + (t >> 4);
+  const bool ework = t < 256 && erow < tl.nrows;
+  const int f = tl.ft * 16 + (t & 15);
+  RnnRow re{};
+  float old = 0.0f;
+  if (ework) {
+    re = st.rows[erow];
+    if (re.src >= 0) old = st.pool_mean[((size_t)re.utt * st.S + re.src) * m.Dp + f];
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) if (f + i >= m.D) out[i] = 0.0f;
-  *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)rr.utt * st.S + rr.dst) * m.Dp + f) = out;
+  const int brow = clamp_row(tl.row0 + (lane & 15), tl.nrows);
+  splitk_tile<1>(m.w2, 0, tl.ft, m.Hp / 16, st.a1 + (size_t)brow * m.Hp, m.b2 + tl.ft * 16, 0, spart);
+  if (!ework) return;
+  float v = splitk_combine<1>(spart, 0, t);
+  if (re.src >= 0) v = uis_mean_update(old, v, re.nprev);
+  if (f >= m.D) v = 0.0f;
+  st.pool_mean[((size_t)re.utt * st.S + re.dst) * m.Dp + f] = v;
 }
 
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
@@ -336,9 +422,15 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   const size_t bnxt = ((size_t)nxt * U + u) * B;
   const int nb = st.beam_n[(size_t)par * U + u];
 
-  // ---- stage the frame, the weights and the beam tables
+  // ---- stage the frame, the weights and the WHOLE beam tables with independent loads
+  // (entries beyond K_b / nb are garbage and never used) so only one global round trip
+  // precedes the cluster-state reads
   for (int i = tid; i < m.Dp; i += 256) { sx[i] = st.x[(size_t)frame * m.Dp + i]; swgt[i] = m.wgt[i]; }
-  for (int b = tid; b < nb; b += 256) {
+  for (int e = tid; e < B * Kmax; e += 256) {
+    sslot[e] = st.beam_slot[bcur * Kmax + e];
+    sblk[e] = st.beam_blk[bcur * Kmax + e];
+  }
+  for (int b = tid; b < B; b += 256) {
     sK[b] = st.beam_K[bcur + b]; slast[b] = st.beam_last[bcur + b];
     ssum[b] = st.beam_sum[bcur + b]; sscore[b] = st.beam_score[bcur + b];
   }
@@ -347,11 +439,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   __syncthreads();
   for (int e = tid; e < nb * Kmax; e += 256) {
     const int b = e / Kmax, c = e - b * Kmax;
-    if (c < sK[b]) {
-      const int s = st.beam_slot[(bcur + b) * Kmax + c];
-      sslot[e] = s; sblk[e] = st.beam_blk[(bcur + b) * Kmax + c];
-      slive[s] = 1;
-    }
+    if (c < sK[b]) slive[sslot[e]] = 1;
   }
   if (tid == 0) {  // candidate offsets: hypothesis b owns candidates sbase[b] .. sbase[b] + K_b
     int acc = 0;
@@ -364,12 +452,45 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   __syncthreads();
   const int nlive = smisc[0];
 
-  // ---- A: MSE against every live cluster state
+  // ---- A: weighted MSE of the frame against every live cluster state.
+  // 16 lanes per cluster state (16 states per pass over the workgroup): physical lane p
+  // carries the canonical tree's virtual lanes p, p+16, p+32, p+48 (uis_numerics.h), so
+  // the first two butterfly levels are register adds and the last four stay inside a
+  // 16-lane row.
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
-  for (int i = wave; i < nlive; i += 4) {
-    const int s = slivelist[i];
-    const float v = wave_weighted_mse(pmean + (size_t)s * m.Dp, sx, swgt, m.Dp, m.D, lane);
-    if (lane == 0) smse[s] = v;
+  {
+    const int grp = tid >> 4, p = tid & 15;
+    for (int i0 = 0; i0 < nlive; i0 += 16) {
+      const int i = i0 + grp;
+      const bool act = i < nlive;
+      const int s = slivelist[act ? i : 0];
+      const float* mean = pmean + (size_t)s * m.Dp;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float first_sq = 0.0f;
+      for (int q = 0; q < m.Dp; q += 256) {
+        f32x4 mv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = q + 4 * (p + 16 * k);
+          mv[k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = q + 4 * (p + 16 * k);
+          if (d < m.Dp) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + d);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[e2], wv[e2]);
+            if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0]; first_sq = d0 * d0; }
+          }
+        }
+      }
+      float t = (v[0] + v[2]) + (v[1] + v[3]);   // butterfly levels 32 and 16
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+      if (p == 0 && act) smse[s] = uis_mse_finish(t, first_sq, m.D);
+    }
   }
   __syncthreads();
 
