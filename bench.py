@@ -54,6 +54,8 @@ def parse():
   ap.add_argument('--cpu_sample', type=int, default=0,
                   help='utterances in the CPU-baseline sample (0 = auto)')
   ap.add_argument('--flags', type=int, default=0, help='UIS_FLAG_* for the timed run')
+  ap.add_argument('--streams', type=int, default=0,
+                  help='utterance groups decoded concurrently (0 = library default)')
   return ap.parse_args()
 
 
@@ -96,7 +98,8 @@ def main():
   def one_step(flags):
     out = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
                                 d_labels.data_ptr(), d_scores.data_ptr(),
-                                max_clusters=16, flags=flags)
+                                max_clusters=16, flags=flags,
+                                n_streams=args.streams)
     if out['status'] != 0:
       raise RuntimeError('decode hit the cluster cap in the benchmark workload')
     if world > 1:
@@ -183,6 +186,7 @@ def main():
                                             frames=n_frames, beam_size=beam,
                                             parallelism='utterance-sharded x{}'.format(world)),
         'decode_ms_device': round(stats.get('decode_ms', 0.0), 3),
+        'n_streams': stats.get('n_streams', 0),
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(result), flush=True)

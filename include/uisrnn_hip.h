@@ -73,13 +73,16 @@ typedef struct uis_decode_opts {
   int32_t test_iteration;  /* args.test_iteration  (>= 1)                     */
   int32_t max_clusters;    /* per-hypothesis cluster cap; 0 = default (16)    */
   uint32_t flags;          /* UIS_FLAG_*                                      */
-  int32_t reserved[3];
+  int32_t n_streams;       /* utterance groups decoded concurrently, each on its
+                              own HIP stream; 0 = default (1), at most 8       */
+  int32_t reserved[2];
 } uis_decode_opts;
 
 #define UIS_FLAG_NO_DEDUP   0x1u /* run one RNN row per surviving hypothesis even when
                                     several share the same cluster state (A/B switch;
                                     results are bit-identical either way)            */
-#define UIS_FLAG_NO_GRAPH   0x2u /* launch kernels eagerly instead of via hipGraph  */
+#define UIS_FLAG_GRAPH      0x2u /* replay the per-step kernels from a captured hipGraph
+                                    (32 steps per graph) instead of launching eagerly  */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */
@@ -95,7 +98,7 @@ typedef struct uis_stats {
   double  kernel_ms[UIS_N_KERNELS];   /* UIS_FLAG_PROFILE: summed per kernel class  */
   int64_t kernel_launches[UIS_N_KERNELS];
   int32_t n_overflow;                 /* utterances that hit UIS_ERR_CLUSTER_CAP    */
-  int32_t reserved;
+  int32_t n_streams;                  /* utterance groups used                       */
 } uis_stats;
 
 /* kernel classes for uis_stats.kernel_ms */

@@ -23,7 +23,7 @@ def _bits(a):
 
 
 def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
-             flags=0, max_clusters=0, decoder=None):
+             flags=0, max_clusters=0, decoder=None, n_streams=0):
   ref = oracle_lib.decode(params, seqs, beam_size, look_ahead, test_iteration,
                           n_threads=8)
   dec = decoder or _capi.Decoder(params)
@@ -31,7 +31,7 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
   cap = max(int(ref['max_clusters'].max()) if len(seqs) else 1, 1)
   out = dec.decode(frames, offsets, beam_size, look_ahead, test_iteration,
                    max_clusters=max_clusters or max(cap, 4), flags=flags,
-                   want_beam_scores=True)
+                   want_beam_scores=True, n_streams=n_streams)
   assert out['status'] == 0
   assert not out['overflow'].any()
   for u in range(len(seqs)):
@@ -104,6 +104,28 @@ def test_dedup_flag_is_bit_identical(oracle_lib):
                   flags=_capi.UIS_FLAG_NO_DEDUP)
   assert b['stats']['rnn_rows'] == b['stats']['rnn_rows_nodedup']
   assert a['stats']['rnn_rows'] < b['stats']['rnn_rows']
+
+
+def test_streams_and_graph_are_bit_identical(oracle_lib):
+  """Utterance groups on several streams and hipGraph replay change scheduling only."""
+  params = synth.tracker_params(256, 512, 1, seed=1)
+  lengths = [70, 33, 64, 12, 90, 41, 5, 77, 64, 20, 51]
+  seqs, _ = synth.make_utterances(4000, len(lengths), lengths, 256)
+  dec = _capi.Decoder(params)
+  for n_streams, flags in ((1, 0), (3, 0), (1, _capi.UIS_FLAG_GRAPH),
+                           (4, _capi.UIS_FLAG_GRAPH), (8, 0)):
+    out, _ = _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec,
+                      flags=flags, n_streams=n_streams)
+    assert out['stats']['n_streams'] == n_streams
+
+
+def test_wide_tiles_bit_exact(oracle_lib):
+  """> 1024 rnn rows per step switches the dense kernels to their 2x2 tile shape."""
+  params = synth.tracker_params(256, 512, 1, seed=2)
+  n_utt = 112
+  lengths = [10 + (7 * u) % 23 for u in range(n_utt)]
+  seqs, _ = synth.make_utterances(6000, n_utt, lengths, 256)
+  _compare(params, seqs, 10, 1, 2, oracle_lib)
 
 
 def _many_cluster_case():

@@ -25,7 +25,7 @@ UIS_ERR_CLUSTER_CAP = -6
 UIS_ERR_UNSUPPORTED = -7
 
 UIS_FLAG_NO_DEDUP = 0x1
-UIS_FLAG_NO_GRAPH = 0x2
+UIS_FLAG_GRAPH = 0x2
 UIS_FLAG_PROFILE = 0x4
 
 UIS_N_KERNELS = 8
@@ -66,7 +66,8 @@ class DecodeOpts(ctypes.Structure):
       ('test_iteration', ctypes.c_int32),
       ('max_clusters', ctypes.c_int32),
       ('flags', ctypes.c_uint32),
-      ('reserved', ctypes.c_int32 * 3),
+      ('n_streams', ctypes.c_int32),
+      ('reserved', ctypes.c_int32 * 2),
   ]
 
 
@@ -82,7 +83,7 @@ class Stats(ctypes.Structure):
       ('kernel_ms', ctypes.c_double * UIS_N_KERNELS),
       ('kernel_launches', ctypes.c_int64 * UIS_N_KERNELS),
       ('n_overflow', ctypes.c_int32),
-      ('reserved', ctypes.c_int32),
+      ('n_streams', ctypes.c_int32),
   ]
 
   def as_dict(self):
@@ -97,6 +98,7 @@ class Stats(ctypes.Structure):
         'kernel_launches': {
             n: self.kernel_launches[i] for i, n in enumerate(KERNEL_NAMES)},
         'n_overflow': self.n_overflow,
+        'n_streams': self.n_streams,
     }
 
 
@@ -156,8 +158,10 @@ def make_desc(params):
   return desc, keep
 
 
-def make_opts(beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+def make_opts(beam_size, look_ahead, test_iteration, max_clusters=0, flags=0,
+              n_streams=0):
   opts = DecodeOpts()
+  opts.n_streams = int(n_streams)
   opts.beam_size = int(beam_size)
   opts.look_ahead = int(look_ahead)
   opts.test_iteration = int(test_iteration)
@@ -288,7 +292,7 @@ class Decoder:
     raise HipLibraryError('{} failed ({}): {}'.format(what, rc, msg))
 
   def decode(self, frames, offsets, beam_size, look_ahead, test_iteration,
-             max_clusters=0, flags=0, want_beam_scores=False):
+             max_clusters=0, flags=0, want_beam_scores=False, n_streams=0):
     """Decode packed host utterances.
 
     Args:
@@ -308,7 +312,8 @@ class Decoder:
       raise ValueError('frames do not match observation_dim')
     labels = np.empty(total, dtype=np.int32)
     scores = np.empty(n_utt, dtype=np.float32)
-    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags)
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags,
+                     n_streams)
     stats = Stats()
     rc = self._lib.uis_decode(
         self._handle, frames.ctypes.data_as(_fp),
@@ -332,11 +337,12 @@ class Decoder:
 
   def decode_device(self, d_frames_ptr, offsets, beam_size, look_ahead,
                     test_iteration, d_labels_ptr, d_scores_ptr, max_clusters=0,
-                    flags=0):
+                    flags=0, n_streams=0):
     """Decode with frames/labels/scores already resident in HBM (raw pointers)."""
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n_utt = offsets.shape[0] - 1
-    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags)
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags,
+                     n_streams)
     stats = Stats()
     rc = self._lib.uis_decode_device(
         self._handle, ctypes.c_void_p(int(d_frames_ptr)),

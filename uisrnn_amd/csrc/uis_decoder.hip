@@ -59,6 +59,16 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+#define UIS_WIDE_TILE_ROWS 1024   // rnn rows per step above which the 2x2 tiles win
+#define UIS_MAX_GROUPS 8
+#define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
+
+struct GraphCache {
+  hipGraphExec_t exec = nullptr;
+  DecodeState st{};
+  size_t lds = 0;
+};
+
 struct ProfileEvents {
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<int> cls;
@@ -78,7 +88,11 @@ struct uis_handle {
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
   ProfileEvents prof;
-  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
+  // utterance groups: one stream + one cached step graph each
+  std::vector<hipStream_t> gstreams;
+  std::vector<hipEvent_t> gdone;
+  std::vector<GraphCache> gcache;
   // info of the last decode
   int last_U = 0, last_B = 0;
   std::vector<int32_t> last_overflow;
@@ -136,6 +150,7 @@ inline dim3 dense_grid_xcd(long rows, int tiles) {
 // timestamps (what rocprofv3 --kernel-trace reports), not host-side bracket times.
 struct Launcher {
   uis_handle* h;
+  hipStream_t stream;
   bool profile;
   int events(hipEvent_t* a, hipEvent_t* b, int cls) {
     ProfileEvents& p = h->prof;
@@ -158,9 +173,9 @@ struct Launcher {
       hipEvent_t a, b;
       int rc = events(&a, &b, cls);
       if (rc) return rc;
-      hipExtLaunchKernelGGL(kernel, grid, block, shmem, h->stream, a, b, 0, args...);
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, a, b, 0, args...);
     } else {
-      hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, args...);
     }
     HIPCHK(hipGetLastError());
     return UIS_OK;
@@ -176,12 +191,20 @@ struct Launcher {
 // One batched CoreRNN evaluation over the rows emitted for step parity `par`.
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
+  const int mr = (int)max_rows;
+  const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
   for (int l = 0; l < m.depth; ++l) {
-    if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dense_grid_xcd(max_rows, m.G / 16), dim3(512), 0, m, st, par, l);
-    LAUNCH(UIS_K_GRU, k_dense_gru, dense_grid_xcd(max_rows, m.Hp / 16), dim3(512), 0, m, st, par, l);
+    if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
+    if (wide) LAUNCH(UIS_K_GRU, k_dense_gru<2>, dim3(step_grid_blocks(mr, m.Hp / 16, 2, 1)), dim3(512), 0, m, st, par, l);
+    else LAUNCH(UIS_K_GRU, k_dense_gru<1>, dim3(step_grid_blocks(mr, m.Hp / 16, 1, 1)), dim3(512), 0, m, st, par, l);
   }
-  LAUNCH(UIS_K_HEAD1, k_dense_head1, dense_grid_xcd(max_rows, m.Hp / 16), dim3(512), 0, m, st, par);
-  LAUNCH(UIS_K_HEAD2, k_dense_head2, dense_grid_xcd(max_rows, m.Dp / 16), dim3(512), 0, m, st, par);
+  if (wide) {
+    LAUNCH(UIS_K_HEAD1, (k_dense_head1<2, 2>), dim3(step_grid_blocks(mr, m.Hp / 16, 2, 2)), dim3(512), 0, m, st, par);
+    LAUNCH(UIS_K_HEAD2, k_dense_head2<2>, dim3(step_grid_blocks(mr, m.Dp / 16, 2, 1)), dim3(512), 0, m, st, par);
+  } else {
+    LAUNCH(UIS_K_HEAD1, (k_dense_head1<1, 1>), dim3(step_grid_blocks(mr, m.Hp / 16, 1, 1)), dim3(512), 0, m, st, par);
+    LAUNCH(UIS_K_HEAD2, k_dense_head2<1>, dim3(step_grid_blocks(mr, m.Dp / 16, 1, 1)), dim3(512), 0, m, st, par);
+  }
   return UIS_OK;
 }
 
@@ -189,14 +212,16 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
 // x [Dp] and h_in [depth][Hp] on the device -> mean [Dp], h_out [depth][Hp] on the device.
 int rnn_step_once(uis_handle* h, const float* d_x, const float* d_hin, float* d_mean, float* d_hout) {
   DevModel& m = h->m;
-  Launcher lch{h, false};
+  Launcher lch{h, h->stream, false};
   float *d_gi0 = nullptr, *d_gi_up = nullptr, *d_a1 = nullptr;
   RnnRow* d_rows = nullptr;
   int32_t* d_nrows = nullptr;
   HIPCHK(hipMalloc(&d_gi0, m.G * sizeof(float)));
-  HIPCHK(hipMalloc(&d_gi_up, m.G * sizeof(float)));
-  HIPCHK(hipMalloc(&d_a1, m.Hp * sizeof(float)));
-  HIPCHK(hipMalloc(&d_rows, sizeof(RnnRow)));
+  HIPCHK(hipMalloc(&d_gi_up, 64 * m.G * sizeof(float)));
+  HIPCHK(hipMalloc(&d_a1, 64 * m.Hp * sizeof(float)));
+  HIPCHK(hipMalloc(&d_rows, 64 * sizeof(RnnRow)));
+  HIPCHK(hipMemsetAsync(d_rows, 0, 64 * sizeof(RnnRow), h->stream));
+  HIPCHK(hipMemsetAsync(d_a1, 0, 64 * m.Hp * sizeof(float), h->stream));
   HIPCHK(hipMalloc(&d_nrows, 2 * sizeof(int32_t)));
   RnnRow rr{};
   rr.utt = 0; rr.src = -1; rr.dst = 0; rr.nprev = 0; rr.frame = 0;
@@ -235,6 +260,27 @@ int bootstrap_constants(uis_handle* h, const float* d_hinit) {
   return UIS_OK;
 }
 
+// Everything one utterance group needs: a view of the shared buffers (pointers offset to
+// the group's first utterance), its stream and its captured step graph.
+struct GroupPlan {
+  int u0 = 0, U = 0;
+  int64_t maxT = 0;
+  DecodeState st{};
+};
+
+// The kernels of `nsteps` consecutive decode steps (starting at an even step) on `stream`.
+int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t select_lds, int nsteps) {
+  const DevModel& m = h->m;
+  const long max_rows = (long)st.U * st.B;
+  for (int s = 0; s < nsteps; ++s) {
+    const int par = s & 1;
+    LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
+    int rc = launch_rnn(h, lch, st, par, max_rows);
+    if (rc) return rc;
+  }
+  return UIS_OK;
+}
+
 int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
   if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
@@ -265,14 +311,38 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 
   const int U = n_utt;
   const int S = B * Kmax + B;
-  const long max_rows = (long)U * B;
   const bool profile = (opts->flags & UIS_FLAG_PROFILE) != 0;
-  Launcher lch{h, profile};
+  const bool use_graph = !profile && (opts->flags & UIS_FLAG_GRAPH) != 0;
+  Launcher lch{h, h->stream, profile};
   h->prof.used = 0; h->prof.cls.clear();
 
   const SelectLds lds = select_lds_layout(m.Dp, B, Kmax, S);
   if (lds.total > 160 * 1024)
     return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+
+  // ---- utterance groups: independent lock-step chains, one stream each.  Measured on
+  // MI355X: the device overlaps at most ~2 of these small kernels, so more
+  // groups mean more launches, not more throughput -- the default is one group.
+  int G = opts->n_streams > 0 ? opts->n_streams : 1;
+  if (profile) G = 1;
+  G = std::max(1, std::min(std::min(G, UIS_MAX_GROUPS), U));
+  while ((int)h->gstreams.size() < G) {
+    hipStream_t sgrp;
+    HIPCHK(hipStreamCreateWithFlags(&sgrp, hipStreamNonBlocking));
+    h->gstreams.push_back(sgrp);
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->gdone.push_back(e);
+    h->gcache.emplace_back();
+  }
+  std::vector<GroupPlan> plan(G);
+  for (int g = 0; g < G; ++g) {
+    plan[g].u0 = (int)((int64_t)U * g / G);
+    plan[g].U = (int)((int64_t)U * (g + 1) / G) - plan[g].u0;
+    for (int u = plan[g].u0; u < plan[g].u0 + plan[g].U; ++u)
+      plan[g].maxT = std::max<int64_t>(plan[g].maxT, (int64_t)tau * (offsets[u + 1] - offsets[u]));
+  }
+  const long max_rows = (long)U * B;
 
   // ---- workspace
   int rc;
@@ -296,11 +366,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
   ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
   ENSURE(bp, (size_t)std::max<int64_t>(tau * F, 1) * B * 4);
-  ENSURE(rows, (size_t)max_rows * sizeof(RnnRow));
-  ENSURE(nrows, 2 * 4);
-  ENSURE(gi_up, m.depth > 1 ? (size_t)max_rows * m.G * 4 : 16);
-  ENSURE(a1, (size_t)max_rows * m.Hp * 4);
-  ENSURE(counters, 4 * 8);
+  const long rows_cap = max_rows + 48L * G;  // every group's last row tile may run past its rows
+  ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
+  ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
+  ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : 16);
+  ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
+  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
 #undef ENSURE
 
@@ -314,20 +385,9 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->logblk.p, logblk.data(), logblk.size() * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->logden.p, logden.data(), logden.size() * 8, hipMemcpyHostToDevice, h->stream));
 
-  DecodeState st{};
-  st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags;
-  st.off = h->off.as<int64_t>(); st.utt_step = h->utt_step.as<int32_t>(); st.overflow = h->overflow.as<int32_t>();
-  st.gi0 = h->gi0.as<float>(); st.mse0 = h->mse0.as<float>();
-  st.logblk = h->logblk.as<double>(); st.logden = h->logden.as<double>();
-  st.pool_mean = h->pool_mean.as<float>(); st.pool_hid = h->pool_hid.as<float>(); st.pool_cnt = h->pool_cnt.as<int32_t>();
-  st.beam_n = h->beam_n.as<int32_t>(); st.beam_K = h->beam_K.as<int32_t>(); st.beam_last = h->beam_last.as<int32_t>();
-  st.beam_sum = h->beam_sum.as<int32_t>(); st.beam_score = h->beam_score.as<float>();
-  st.beam_slot = h->beam_slot.as<int32_t>(); st.beam_blk = h->beam_blk.as<int32_t>();
-  st.bp = h->bp.as<uint32_t>(); st.rows = h->rows.as<RnnRow>(); st.nrows = h->nrows.as<int32_t>();
-  st.gi_up = h->gi_up.as<float>(); st.a1 = h->a1.as<float>();
-  st.counters = h->counters.as<unsigned long long>();
-
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+  // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
+  HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
   const float* d_x = d_frames;
   if (m.D != m.Dp && F > 0) {
     const long total = (long)F * m.Dp;
@@ -336,29 +396,84 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     HIPCHK(hipGetLastError());
     d_x = h->xpad.as<float>();
   }
-  st.x = d_x;
-  hipLaunchKernelGGL(k_init_state, dim3((U + 255) / 256), dim3(256), 0, h->stream, st);
-  HIPCHK(hipGetLastError());
   if (F > 0) {
     LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, h->gi0.as<float>(),
            (long)F);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
            h->mse0.as<float>(), (long)F);
   }
+  HIPCHK(hipEventRecord(h->ev_pre, h->stream));
 
-  // ---- lock-step decode
-  for (int64_t step = 0; step < maxT; ++step) {
-    const int par = (int)(step & 1);
-    LAUNCH(UIS_K_SELECT, k_select, dim3(U), dim3(256), (size_t)lds.total, m, st, par);
-    rc = launch_rnn(h, lch, st, par, max_rows);
-    if (rc) return rc;
+  // ---- group views of the shared buffers
+  for (int g = 0; g < G; ++g) {
+    GroupPlan& gp = plan[g];
+    DecodeState& st = gp.st;
+    const size_t u0 = (size_t)gp.u0;
+    st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags;
+    st.off = h->off.as<int64_t>() + u0;
+    st.utt_step = h->utt_step.as<int32_t>() + u0;
+    st.overflow = h->overflow.as<int32_t>() + u0;
+    st.x = d_x; st.gi0 = h->gi0.as<float>(); st.mse0 = h->mse0.as<float>();
+    st.logblk = h->logblk.as<double>(); st.logden = h->logden.as<double>();
+    st.pool_mean = h->pool_mean.as<float>() + u0 * S * m.Dp;
+    st.pool_hid = h->pool_hid.as<float>() + u0 * S * m.depth * m.Hp;
+    st.pool_cnt = h->pool_cnt.as<int32_t>() + u0 * S;
+    // beam tables: groups back to back, each laid out [2][U_g][...]
+    st.beam_n = h->beam_n.as<int32_t>() + 2 * u0;
+    st.beam_K = h->beam_K.as<int32_t>() + 2 * u0 * B;
+    st.beam_last = h->beam_last.as<int32_t>() + 2 * u0 * B;
+    st.beam_sum = h->beam_sum.as<int32_t>() + 2 * u0 * B;
+    st.beam_score = h->beam_score.as<float>() + 2 * u0 * B;
+    st.beam_slot = h->beam_slot.as<int32_t>() + 2 * u0 * B * Kmax;
+    st.beam_blk = h->beam_blk.as<int32_t>() + 2 * u0 * B * Kmax;
+    st.bp = h->bp.as<uint32_t>();
+    st.rows = h->rows.as<RnnRow>() + u0 * B + 48 * (size_t)g;
+    st.nrows = h->nrows.as<int32_t>() + 2 * g;
+    st.gi_up = h->gi_up.as<float>() + (m.depth > 1 ? (u0 * B + 48 * (size_t)g) * m.G : 0);
+    st.a1 = h->a1.as<float>() + (u0 * B + 48 * (size_t)g) * m.Hp;
+    st.counters = h->counters.as<unsigned long long>() + 4 * g;
   }
-  LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((U + 63) / 64), dim3(64), 0, st, d_labels, d_scores,
-         h->beam_scores_out.as<float>());
+
+  // ---- lock-step decode of every group on its own stream
+  for (int g = 0; g < G; ++g) {
+    GroupPlan& gp = plan[g];
+    hipStream_t sg = h->gstreams[g];
+    Launcher gl{h, sg, profile};
+    Launcher& lch = gl;  // LAUNCH() below targets this group's stream
+    HIPCHK(hipStreamWaitEvent(sg, h->ev_pre, 0));
+    LAUNCH(-1, k_init_state, dim3((gp.U + 255) / 256), dim3(256), 0, gp.st);
+    if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
+      GraphCache& gc = h->gcache[g];
+      const bool same = gc.exec && gc.lds == (size_t)lds.total && memcmp(&gc.st, &gp.st, sizeof(DecodeState)) == 0;
+      if (!same) {
+        if (gc.exec) { (void)hipGraphExecDestroy(gc.exec); gc.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(sg, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_steps(h, gl, gp.st, lds.total, UIS_GRAPH_STEPS);
+        hipError_t ce = hipStreamEndCapture(sg, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(UIS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        ce = hipGraphInstantiate(&gc.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ce != hipSuccess) { gc.exec = nullptr; return fail(UIS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); }
+        gc.st = gp.st; gc.lds = (size_t)lds.total;
+      }
+      const int64_t nlaunch = (gp.maxT + UIS_GRAPH_STEPS - 1) / UIS_GRAPH_STEPS;  // the tail steps are no-ops
+      for (int64_t i = 0; i < nlaunch; ++i) HIPCHK(hipGraphLaunch(gc.exec, sg));
+    } else {
+      const int64_t nsteps = gp.maxT + (gp.maxT & 1);
+      for (int64_t s0 = 0; s0 < nsteps; s0 += 2)
+        if ((rc = enqueue_steps(h, gl, gp.st, lds.total, 2))) return rc;
+    }
+    LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
+           d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
+    HIPCHK(hipEventRecord(h->gdone[g], sg));
+  }
+  for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->stream, h->gdone[g], 0));
   HIPCHK(hipEventRecord(h->ev_end, h->stream));
 
-  unsigned long long counters[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(counters, h->counters.p, sizeof(counters), hipMemcpyDeviceToHost, h->stream));
+  std::vector<unsigned long long> counters((size_t)UIS_MAX_GROUPS * 4, 0ull);
+  HIPCHK(hipMemcpyAsync(counters.data(), h->counters.p, (size_t)G * 4 * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(h->last_overflow.data(), h->overflow.p, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), h->beam_scores_out.p, (size_t)U * B * 4, hipMemcpyDeviceToHost,
                         h->stream));
@@ -370,16 +485,20 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
     stats->n_steps = (int32_t)maxT;
     stats->decode_ms = ms;
-    stats->rnn_rows = (int64_t)counters[0];
-    stats->rnn_rows_nodedup = (int64_t)counters[1];
-    stats->candidates = (int64_t)counters[2];
-    stats->max_clusters_seen = (int32_t)counters[3];
+    for (int g = 0; g < G; ++g) {
+      stats->rnn_rows += (int64_t)counters[4 * g + 0];
+      stats->rnn_rows_nodedup += (int64_t)counters[4 * g + 1];
+      stats->candidates += (int64_t)counters[4 * g + 2];
+      stats->max_clusters_seen = std::max(stats->max_clusters_seen, (int32_t)counters[4 * g + 3]);
+    }
     stats->n_overflow = n_over;
+    stats->n_streams = G;
     if (profile) {
       for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
         float t = 0.0f;
         HIPCHK(hipEventElapsedTime(&t, h->prof.ev[i], h->prof.ev[i + 1]));
         const int c = h->prof.cls[i / 2];
+        if (c < 0) continue;
         stats->kernel_ms[c] += t;
         stats->kernel_launches[c] += 1;
       }
@@ -417,6 +536,10 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
   if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+  if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
+  for (GraphCache& gc : h->gcache) if (gc.exec) (void)hipGraphExecDestroy(gc.exec);
+  for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
+  for (hipStream_t sg : h->gstreams) { (void)hipStreamSynchronize(sg); (void)hipStreamDestroy(sg); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -445,7 +568,8 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   h->alpha = d->crp_alpha;
   auto bail = [&](int rc) { uis_destroy(h); return rc; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(UIS_ERR_HIP, "stream create failed"));
-  if (hipEventCreate(&h->ev_begin) != hipSuccess || hipEventCreate(&h->ev_end) != hipSuccess)
+  if (hipEventCreate(&h->ev_begin) != hipSuccess || hipEventCreate(&h->ev_end) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) != hipSuccess)
     return bail(fail(UIS_ERR_HIP, "event create failed"));
   DevModel& m = h->m;
   m.D = D; m.H = H; m.depth = depth;

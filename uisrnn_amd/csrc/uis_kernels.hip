@@ -61,66 +61,89 @@ __device__ __forceinline__ float wave_weighted_mse(const float* __restrict__ mea
 
 #define UIS_STAGE 4   // k-blocks fetched per pipeline stage
 
-template <int NG>
-__device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NG], const f32x4* bp, int kb0, int kb1,
-                                             f32x4 (&acc)[NG]) {
+// NA A-operand streams (feature tiles x gates) against NB B-operand streams (row tiles):
+// NA*NB accumulators, NA+NB 16-byte loads per lane per k-block.
+template <int NA, int NB>
+__device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NA], const f32x4* const (&bp)[NB], int kb0,
+                                             int kb1, f32x4 (&acc)[NB][NA]) {
   for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
-    f32x4 a[UIS_STAGE][NG], b[UIS_STAGE];
+    f32x4 a[UIS_STAGE][NA], b[UIS_STAGE][NB];
 #pragma unroll
     for (int u = 0; u < UIS_STAGE; ++u) {
       const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) a[u][g] = wp[g][(size_t)kk * 64];
-      b[u] = bp[(size_t)kk * 4];
+      for (int g = 0; g < NA; ++g) a[u][g] = wp[g][(size_t)kk * 64];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) b[u][r] = bp[r][(size_t)kk * 4];
     }
 #pragma unroll
     for (int u = 0; u < UIS_STAGE; ++u) {
       if (kb + u < kb1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][r], b[u][r], acc[g], 0, 0, 0);
+          for (int r = 0; r < NB; ++r) {
+#pragma unroll
+            for (int g = 0; g < NA; ++g)
+              acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][e], b[u][r][e], acc[r][g], 0, 0, 0);
+          }
         }
       }
     }
   }
 }
 
-// Split-K schedule.  bias points at this tile's 16 biases of gate 0; gate g's are
-// gate_stride floats further.  spart: LDS [UIS_KSPLIT][NG][256].  Ends with the barrier;
-// afterwards splitk_combine(t) returns element (row t>>4, feature t&15).
-template <int NG>
-__device__ __forceinline__ void splitk_tile(const float* __restrict__ Wt, int tiles_per_gate, int tile, int nKb,
-                                            const float* __restrict__ inrow, const float* __restrict__ bias,
+// Split-K schedule of a workgroup tile of R row tiles x C feature tiles x NG gates.
+// A stream index a = c*NG + g.  bias points at feature tile `tile0`'s 16 biases of gate 0;
+// tile c is 16 floats further, gate g gate_stride floats further.  inrow[r] is this lane's
+// row of row tile r.  spart: LDS [UIS_KSPLIT][R][C*NG][256].  Ends with the barrier;
+// afterwards splitk_combine() returns element (row t>>4, feature t&15) of a sub-tile.
+template <int NG, int R, int C>
+__device__ __forceinline__ void splitk_tile(const float* __restrict__ Wt, int tiles_per_gate, int tile0, int nKb,
+                                            const float* const (&inrow)[R], const float* __restrict__ bias,
                                             int gate_stride, float* spart) {
+  constexpr int NA = C * NG;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int q = lane >> 4;
   const int per = uis_kseg_blocks(nKb);
   const int kb0 = w * per;
   const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
-  const f32x4* wp[NG];
+  const f32x4* wp[NA];
+  const f32x4* bp[R];
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
-    wp[g] = reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile) * nKb) * 64 + lane;
-  const f32x4* bp = reinterpret_cast<const f32x4*>(inrow) + q;
-  f32x4 acc[NG];
+  for (int c = 0; c < C; ++c)
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
-    acc[g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q)
-                    : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if (kb0 < kb1) chain_blocks<NG>(wp, bp, kb0, kb1, acc);
+    for (int g = 0; g < NG; ++g)
+      wp[c * NG + g] =
+          reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile0 + c) * nKb) * 64 + lane;
 #pragma unroll
-  for (int g = 0; g < NG; ++g)
-    *reinterpret_cast<f32x4*>(spart + ((size_t)(w * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[g];
+  for (int r = 0; r < R; ++r) bp[r] = reinterpret_cast<const f32x4*>(inrow[r]) + q;
+  f32x4 acc[R][NA];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        acc[r][c * NG + g] =
+            w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + c * 16 + 4 * q)
+                   : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (kb0 < kb1) chain_blocks<NA, R>(wp, bp, kb0, kb1, acc);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * R + r) * NA + a) * 256) + (lane & 15) * 16 + 4 * q) =
+          acc[r][a];
   __syncthreads();
 }
 
-template <int NG>
-__device__ __forceinline__ float splitk_combine(const float* spart, int g, int t) {
-  float v = spart[(size_t)g * 256 + t];
+// element (row t>>4, feature t&15) of row tile r, A stream a, combined in segment order
+template <int R, int NA>
+__device__ __forceinline__ float splitk_combine(const float* spart, int r, int a, int t) {
+  float v = spart[(size_t)(r * NA + a) * 256 + t];
 #pragma unroll
-  for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) v = v + spart[(size_t)(sgm * NG + g) * 256 + t];
+  for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) v = v + spart[(size_t)((sgm * R + r) * NA + a) * 256 + t];
   return v;
 }
 
@@ -131,19 +154,19 @@ __device__ __forceinline__ f32x4 fullk_tile(const float* __restrict__ Wt, int ti
   const int q = lane >> 4;
   const int per = uis_kseg_blocks(nKb);
   const f32x4* wp[1] = {reinterpret_cast<const f32x4*>(Wt) + ((size_t)tile * nKb) * 64 + lane};
-  const f32x4* bp = reinterpret_cast<const f32x4*>(inrow) + q;
+  const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(inrow) + q};
   f32x4 total = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 1
   for (int sgm = 0; sgm < UIS_KSPLIT; ++sgm) {
     const int kb0 = sgm * per;
     const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
-    f32x4 acc[1];
-    acc[0] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (kb0 < kb1) chain_blocks<1>(wp, bp, kb0, kb1, acc);
-    if (sgm == 0) total = acc[0];
+    f32x4 acc[1][1];
+    acc[0][0] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (kb0 < kb1) chain_blocks<1, 1>(wp, bp, kb0, kb1, acc);
+    if (sgm == 0) total = acc[0][0];
     else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) total[i] = total[i] + acc[0][i];
+      for (int i = 0; i < 4; ++i) total[i] = total[i] + acc[0][0][i];
     }
   }
   return total;
@@ -188,114 +211,186 @@ __global__ __launch_bounds__(256) void k_dense_input_proj(DevModel m, const floa
   if (valid) *reinterpret_cast<f32x4*>(gi0 + (size_t)row * m.G + f) = v;
 }
 
-// Common prologue of the per-step kernels: which tile is this workgroup, which rnn rows.
+// Common prologue of the per-step kernels.  A workgroup owns RT consecutive row tiles and CT
+// consecutive feature tiles; which ones follows from blockIdx alone.  The row count (written
+// by this step's select) and the row descriptors are fetched together, so only ONE global
+// round trip precedes the operand stream.  Rows at or beyond the count hold descriptors of
+// an earlier step (or zeros): they still name valid slots, so their lanes stream valid
+// memory and their results are simply not stored.
 struct StepTile {
-  int rt, ft, row0, nrows;
+  int rt0, ft0, row0, nrows;
   bool active;
 };
-__device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft) {
+template <int RT, int CT>
+__device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft, RnnRow (&lane_row)[RT]) {
   StepTile t;
+  const int max_rt = (st.U * st.B + 15) >> 4;
+  const int n_rg = (max_rt + RT - 1) / RT, n_fg = (nft + CT - 1) / CT;
+  int rg, fg;
+  dense_block_map(blockIdx.x, n_rg, n_fg, rg, fg);
+  t.rt0 = rg * RT; t.ft0 = fg * CT;
+  t.row0 = t.rt0 * 16;
+  const bool in_grid = rg < n_rg && fg < n_fg;
+#pragma unroll
+  for (int r = 0; r < RT; ++r) lane_row[r] = st.rows[in_grid ? t.row0 + 16 * r + (threadIdx.x & 15) : 0];
   t.nrows = st.nrows[par];
-  const int nrt = (t.nrows + 15) >> 4;
-  t.active = (int)blockIdx.x < dense_grid_blocks(nrt, nft);
-  t.rt = 0; t.ft = 0;
-  if (t.active) {
-    dense_block_map(blockIdx.x, nrt, nft, t.rt, t.ft);
-    t.active = t.rt < nrt && t.ft < nft;
-  }
-  t.row0 = t.rt * 16;
+  t.active = in_grid && t.row0 < t.nrows;
   return t;
 }
-__device__ __forceinline__ int clamp_row(int row, int nrows) { return row < nrows ? row : nrows - 1; }
+__host__ __device__ inline int step_grid_blocks(int max_rows, int nft, int RT, int CT) {
+  const int max_rt = (max_rows + 15) >> 4;
+  return dense_grid_blocks((max_rt + RT - 1) / RT, (nft + CT - 1) / CT);
+}
+
+// Tile shapes: a workgroup owns RT row tiles (x CT feature tiles for the head).  RT = CT = 1
+// keeps the most workgroups in flight and wins while a launch is latency bound (up to a few
+// hundred rnn rows); RT = CT = 2 re-uses operands out of registers and wins once the L2->CU
+// stream is the limit (measured crossover ~1000 rows).  The host picks per decode.
+
+__device__ __forceinline__ const float* hid_ptr(const DevModel& m, const DecodeState& st, const RnnRow& r, int slot,
+                                                int layer) {
+  return st.pool_hid + ((size_t)r.utt * st.S + slot) * m.depth * m.Hp + (size_t)layer * m.Hp;
+}
 
 // Input-side gates of GRU layer `layer` >= 1: gi_up[row][G] = b_ih + W_ih h'_{layer-1}
 __global__ __launch_bounds__(512) void k_dense_upper_in(DevModel m, DecodeState st, int par, int layer) {
   __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
-  const StepTile tl = step_tile(st, par, m.G / 16);
+  RnnRow rb[1];
+  const StepTile tl = step_tile<1, 1>(st, par, m.G / 16, rb);
   if (!tl.active) return;
-  const int lane = threadIdx.x & 63, t = threadIdx.x;
-  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
-  const float* in = st.pool_hid + ((size_t)rb.utt * st.S + rb.dst) * m.depth * m.Hp + (size_t)(layer - 1) * m.Hp;
-  splitk_tile<1>(m.wih[layer], 0, tl.ft, m.Hp / 16, in, m.bih[layer] + tl.ft * 16, 0, spart);
+  const int t = threadIdx.x;
+  const float* in[1] = {hid_ptr(m, st, rb[0], rb[0].dst, layer - 1)};
+  splitk_tile<1, 1, 1>(m.wih[layer], 0, tl.ft0, m.Hp / 16, in, m.bih[layer] + tl.ft0 * 16, 0, spart);
   if (t >= 256) return;
   const int row = tl.row0 + (t >> 4);
   if (row >= tl.nrows) return;
-  st.gi_up[(size_t)row * m.G + tl.ft * 16 + (t & 15)] = splitk_combine<1>(spart, 0, t);
+  st.gi_up[(size_t)row * m.G + tl.ft0 * 16 + (t & 15)] = splitk_combine<1, 1>(spart, 0, 0, t);
 }
 
 // GRU layer: gh = b_hh + W_hh h_src (three gate chains per unit), gates, h' -> dst slot.
+template <int RT>
 __global__ __launch_bounds__(512) void k_dense_gru(DevModel m, DecodeState st, int par, int layer) {
-  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 3 * 256];
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * RT * 3 * 256];
   const int nft = m.Hp / 16;
-  const StepTile tl = step_tile(st, par, nft);
+  RnnRow rb[RT];
+  const StepTile tl = step_tile<RT, 1>(st, par, nft, rb);
   if (!tl.active) return;
-  const int lane = threadIdx.x & 63, t = threadIdx.x;
-  const size_t slot_stride = (size_t)m.depth * m.Hp;
-  // epilogue operands of element (row t>>4, unit t&15): fetched now, used after the chains
-  const int erow = tl.row0 + (t >> 4);
-  const bool ework = t < 256 && erow < tl.nrows;
-  const int j = tl.ft * 16 + (t & 15);
-  RnnRow re{};
-  float gir = 0.0f, giz = 0.0f, gin = 0.0f, hprev = 0.0f;
-  if (ework) {
-    re = st.rows[erow];
-    const float* gi = layer == 0 ? st.gi0 + (size_t)re.frame * m.G : st.gi_up + (size_t)erow * m.G;
-    const float* hs = re.src >= 0
-        ? st.pool_hid + ((size_t)re.utt * st.S + re.src) * slot_stride + (size_t)layer * m.Hp
-        : m.h1 + (size_t)layer * m.Hp;
-    gir = gi[j]; giz = gi[m.Hp + j]; gin = gi[2 * m.Hp + j]; hprev = hs[j];
+  const int t = threadIdx.x;
+  // epilogue operands: thread t owns element (row t>>4 of row tile (t>>8) + 2k, unit t&15);
+  // fetched now, used after the chains
+  const int j = tl.ft0 * 16 + (t & 15);
+  constexpr int EPT = (RT + 1) / 2;  // elements per thread (512 threads cover 2 row tiles)
+  RnnRow re[EPT];
+  float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
+  bool ework[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int r = (t >> 8) + 2 * k;
+    const int erow = tl.row0 + 16 * r + ((t & 255) >> 4);
+    ework[k] = r < RT && erow < tl.nrows;
+    gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
+    re[k] = RnnRow{};
+    if (ework[k]) {
+      re[k] = st.rows[erow];
+      const float* gi = layer == 0 ? st.gi0 + (size_t)re[k].frame * m.G : st.gi_up + (size_t)erow * m.G;
+      const float* hs = re[k].src >= 0 ? hid_ptr(m, st, re[k], re[k].src, layer) : m.h1 + (size_t)layer * m.Hp;
+      gir[k] = gi[j]; giz[k] = gi[m.Hp + j]; gin[k] = gi[2 * m.Hp + j]; hprev[k] = hs[j];
+    }
   }
-  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
-  const float* hsrc = rb.src >= 0
-      ? st.pool_hid + ((size_t)rb.utt * st.S + rb.src) * slot_stride + (size_t)layer * m.Hp
-      : m.h1 + (size_t)layer * m.Hp;
-  splitk_tile<3>(m.whh[layer], nft, tl.ft, m.Hp / 16, hsrc, m.bhh[layer] + tl.ft * 16, m.Hp, spart);
-  if (!ework) return;
-  const float ghr = splitk_combine<3>(spart, 0, t);
-  const float ghz = splitk_combine<3>(spart, 1, t);
-  const float ghn = splitk_combine<3>(spart, 2, t);
-  const float out = j < m.H ? uis_gru_unit(gir, giz, gin, ghr, ghz, ghn, hprev) : 0.0f;
-  st.pool_hid[((size_t)re.utt * st.S + re.dst) * slot_stride + (size_t)layer * m.Hp + j] = out;
+  const float* hsrc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+    hsrc[r] = rb[r].src >= 0 ? hid_ptr(m, st, rb[r], rb[r].src, layer) : m.h1 + (size_t)layer * m.Hp;
+  splitk_tile<3, RT, 1>(m.whh[layer], nft, tl.ft0, m.Hp / 16, hsrc, m.bhh[layer] + tl.ft0 * 16, m.Hp, spart);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    if (!ework[k]) continue;
+    const int r = (t >> 8) + 2 * k, e = t & 255;
+    const float ghr = splitk_combine<RT, 3>(spart, r, 0, e);
+    const float ghz = splitk_combine<RT, 3>(spart, r, 1, e);
+    const float ghn = splitk_combine<RT, 3>(spart, r, 2, e);
+    const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+    const_cast<float*>(hid_ptr(m, st, re[k], re[k].dst, layer))[j] = out;
+  }
 }
 
 // a1[row] = relu(b1 + W1 h'_top)
+template <int RT, int CT>
 __global__ __launch_bounds__(512) void k_dense_head1(DevModel m, DecodeState st, int par) {
-  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
-  const StepTile tl = step_tile(st, par, m.Hp / 16);
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * RT * CT * 256];
+  const int nft = m.Hp / 16;
+  RnnRow rb[RT];
+  const StepTile tl = step_tile<RT, CT>(st, par, nft, rb);
   if (!tl.active) return;
-  const int lane = threadIdx.x & 63, t = threadIdx.x;
-  const RnnRow rb = st.rows[clamp_row(tl.row0 + (lane & 15), tl.nrows)];
-  const float* in = st.pool_hid + ((size_t)rb.utt * st.S + rb.dst) * m.depth * m.Hp + (size_t)(m.depth - 1) * m.Hp;
-  splitk_tile<1>(m.w1, 0, tl.ft, m.Hp / 16, in, m.b1 + tl.ft * 16, 0, spart);
-  if (t >= 256) return;
-  const int row = tl.row0 + (t >> 4);
-  if (row >= tl.nrows) return;
-  const float v = splitk_combine<1>(spart, 0, t);
-  st.a1[(size_t)row * m.Hp + tl.ft * 16 + (t & 15)] = v > 0.0f ? v : 0.0f;
+  const int t = threadIdx.x;
+  const float* in[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) in[r] = hid_ptr(m, st, rb[r], rb[r].dst, m.depth - 1);
+  // a feature-tile pair may stick out past the last tile: stream tile nft-1 twice, store once
+  const int ft0 = tl.ft0 + CT <= nft ? tl.ft0 : nft - CT < 0 ? 0 : nft - CT;
+  if (nft < CT) {  // fewer feature tiles than a workgroup covers (tiny models): one at a time
+    for (int c = 0; c < nft; ++c) {
+      splitk_tile<1, RT, 1>(m.w1, 0, c, m.Hp / 16, in, m.b1 + c * 16, 0, spart);
+      for (int e = t; e < RT * 256; e += 512) {
+        const int r = e >> 8, row = tl.row0 + 16 * r + ((e & 255) >> 4);
+        if (row < tl.nrows) {
+          const float v = splitk_combine<RT, 1>(spart, r, 0, e & 255);
+          st.a1[(size_t)row * m.Hp + c * 16 + (e & 15)] = v > 0.0f ? v : 0.0f;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  splitk_tile<1, RT, CT>(m.w1, 0, ft0, m.Hp / 16, in, m.b1 + ft0 * 16, 0, spart);
+  for (int e = t; e < RT * CT * 256; e += 512) {
+    const int r = e / (CT * 256), c = (e / 256) % CT, el = e & 255;
+    const int row = tl.row0 + 16 * r + (el >> 4);
+    if (row < tl.nrows) {
+      const float v = splitk_combine<RT, CT>(spart, r, c, el);
+      st.a1[(size_t)row * m.Hp + (ft0 + c) * 16 + (el & 15)] = v > 0.0f ? v : 0.0f;
+    }
+  }
 }
 
 // m = b2 + W2 a1; running-mean update (uisrnn.py:425-429) -> dst slot
+template <int RT>
 __global__ __launch_bounds__(512) void k_dense_head2(DevModel m, DecodeState st, int par) {
-  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 256];
-  const StepTile tl = step_tile(st, par, m.Dp / 16);
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * RT * 256];
+  RnnRow rb[RT];
+  const StepTile tl = step_tile<RT, 1>(st, par, m.Dp / 16, rb);
   if (!tl.active) return;
-  const int lane = threadIdx.x & 63, t = threadIdx.x;
-  const int erow = tl.row0 + (t >> 4);
-  const bool ework = t < 256 && erow < tl.nrows;
-  const int f = tl.ft * 16 + (t & 15);
-  RnnRow re{};
-  float old = 0.0f;
-  if (ework) {
-    re = st.rows[erow];
-    if (re.src >= 0) old = st.pool_mean[((size_t)re.utt * st.S + re.src) * m.Dp + f];
+  const int t = threadIdx.x;
+  const int f = tl.ft0 * 16 + (t & 15);
+  constexpr int EPT = (RT + 1) / 2;
+  RnnRow re[EPT];
+  float old[EPT];
+  bool ework[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int r = (t >> 8) + 2 * k;
+    const int erow = tl.row0 + 16 * r + ((t & 255) >> 4);
+    ework[k] = r < RT && erow < tl.nrows;
+    old[k] = 0.0f;
+    re[k] = RnnRow{};
+    if (ework[k]) {
+      re[k] = st.rows[erow];
+      if (re[k].src >= 0) old[k] = st.pool_mean[((size_t)re[k].utt * st.S + re[k].src) * m.Dp + f];
+    }
   }
-  const int brow = clamp_row(tl.row0 + (lane & 15), tl.nrows);
-  splitk_tile<1>(m.w2, 0, tl.ft, m.Hp / 16, st.a1 + (size_t)brow * m.Hp, m.b2 + tl.ft * 16, 0, spart);
-  if (!ework) return;
-  float v = splitk_combine<1>(spart, 0, t);
-  if (re.src >= 0) v = uis_mean_update(old, v, re.nprev);
-  if (f >= m.D) v = 0.0f;
-  st.pool_mean[((size_t)re.utt * st.S + re.dst) * m.Dp + f] = v;
+  const float* in[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) in[r] = st.a1 + (size_t)(tl.row0 + 16 * r + (t & 15)) * m.Hp;
+  splitk_tile<1, RT, 1>(m.w2, 0, tl.ft0, m.Hp / 16, in, m.b2 + tl.ft0 * 16, 0, spart);
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    if (!ework[k]) continue;
+    const int r = (t >> 8) + 2 * k;
+    float v = splitk_combine<RT, 1>(spart, r, 0, t & 255);
+    if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
+    if (f >= m.D) v = 0.0f;
+    st.pool_mean[((size_t)re[k].utt * st.S + re[k].dst) * m.Dp + f] = v;
+  }
 }
 
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
@@ -329,7 +424,7 @@ __global__ void k_pad_frames(const float* __restrict__ src, float* __restrict__ 
 // (beam_set = [BeamState()], uisrnn.py:528).
 __global__ void k_init_state(DecodeState st) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull; }
+  if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull; }  // this group's
   if (u >= st.U) return;
   st.utt_step[u] = 0;
   st.overflow[u] = 0;
@@ -349,8 +444,8 @@ __global__ void k_init_state(DecodeState st) {
 // Dynamic LDS layout is carved by select_lds_bytes() below.
 
 struct SelectLds {
-  int off_x, off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_base, off_score;
-  int off_live, off_livelist, off_mse, off_key, off_cscore, off_win, off_src, off_dst, off_lead, off_free, off_misc;
+  int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_base, off_score;
+  int off_live, off_livelist, off_mse, off_cnt, off_key, off_cscore, off_win, off_src, off_dst, off_lead, off_free, off_misc;
   int total;
 };
 
@@ -359,7 +454,6 @@ __host__ __device__ inline SelectLds select_lds_layout(int Dp, int B, int Kmax, 
   int o = 0;
   auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
   const int C = B * (Kmax + 1);
-  l.off_x = take(Dp * 4);
   l.off_wgt = take(Dp * 4);
   l.off_slot = take(B * Kmax * 4);
   l.off_blk = take(B * Kmax * 4);
@@ -371,6 +465,7 @@ __host__ __device__ inline SelectLds select_lds_layout(int Dp, int B, int Kmax, 
   l.off_live = take(S * 4);
   l.off_livelist = take(S * 4);
   l.off_mse = take(S * 4);
+  l.off_cnt = take(S * 4);
   l.off_key = take(C * 8);
   l.off_cscore = take(C * 4);
   l.off_win = take(B * 4);
@@ -383,21 +478,16 @@ __host__ __device__ inline SelectLds select_lds_layout(int Dp, int B, int Kmax, 
   return l;
 }
 
+// Memory round trips on the critical path: (1) step counter, offsets and the whole beam
+// tables; (2) the frame, the live cluster states (+ frame counts), the prior-table entries
+// and the fresh-cluster MSE -- all issued before the first of them is consumed.
 __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u = blockIdx.x, tid = threadIdx.x;
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
-  const long N = (long)(st.off[u + 1] - st.off[u]);
-  const long T = (long)st.tau * N;
-  const int step = st.utt_step[u];
-  // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
-  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
-  if (step >= T) return;  // utterance finished (uniform over the workgroup)
-  const long frame = st.off[u] + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
   const int nxt = par ^ 1;
 
   const SelectLds L = select_lds_layout(m.Dp, B, Kmax, S);
-  float* sx = reinterpret_cast<float*>(smem_raw + L.off_x);
   float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
   int* sslot = reinterpret_cast<int*>(smem_raw + L.off_slot);
   int* sblk = reinterpret_cast<int*>(smem_raw + L.off_blk);
@@ -409,6 +499,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
   int* slivelist = reinterpret_cast<int*>(smem_raw + L.off_livelist);
   float* smse = reinterpret_cast<float*>(smem_raw + L.off_mse);
+  int* scnt = reinterpret_cast<int*>(smem_raw + L.off_cnt);
   unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem_raw + L.off_key);
   float* scscore = reinterpret_cast<float*>(smem_raw + L.off_cscore);
   int* swin = reinterpret_cast<int*>(smem_raw + L.off_win);
@@ -416,16 +507,18 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   int* sdst = reinterpret_cast<int*>(smem_raw + L.off_dst);
   int* slead = reinterpret_cast<int*>(smem_raw + L.off_lead);
   int* sfree = reinterpret_cast<int*>(smem_raw + L.off_free);
-  int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite [2] nlead
+  int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite [2] nlead [3] nfree
 
   const size_t bcur = ((size_t)par * U + u) * B;
   const size_t bnxt = ((size_t)nxt * U + u) * B;
-  const int nb = st.beam_n[(size_t)par * U + u];
 
-  // ---- stage the frame, the weights and the WHOLE beam tables with independent loads
-  // (entries beyond K_b / nb are garbage and never used) so only one global round trip
-  // precedes the cluster-state reads
-  for (int i = tid; i < m.Dp; i += 256) { sx[i] = st.x[(size_t)frame * m.Dp + i]; swgt[i] = m.wgt[i]; }
+  // ---- round trip 1 (entries of the tables beyond K_b / nb are garbage and never used)
+  const int step = st.utt_step[u];
+  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
+  const int nb = st.beam_n[(size_t)par * U + u];
+  // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
+  if (u == 0 && tid == 0) st.nrows[nxt] = 0;
+  for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
     sblk[e] = st.beam_blk[bcur * Kmax + e];
@@ -434,8 +527,12 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     sK[b] = st.beam_K[bcur + b]; slast[b] = st.beam_last[bcur + b];
     ssum[b] = st.beam_sum[bcur + b]; sscore[b] = st.beam_score[bcur + b];
   }
-  for (int s = tid; s < S; s += 256) slive[s] = 0;
+  for (int sl = tid; sl < S; sl += 256) slive[sl] = 0;
   if (tid < 16) smisc[tid] = 0;
+  const long N = off1 - off0;
+  const long T = (long)st.tau * N;
+  if (step >= T) return;  // utterance finished (uniform over the workgroup)
+  const long frame = off0 + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
   __syncthreads();
   for (int e = tid; e < nb * Kmax; e += 256) {
     const int b = e / Kmax, c = e - b * Kmax;
@@ -447,10 +544,22 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     sbase[nb] = acc;
   }
   __syncthreads();
-  for (int s = tid; s < S; s += 256)
-    if (slive[s]) slivelist[atomicAdd(&smisc[0], 1)] = s;
+  for (int sl = tid; sl < S; sl += 256)
+    if (slive[sl]) slivelist[atomicAdd(&smisc[0], 1)] = sl;
   __syncthreads();
   const int nlive = smisc[0];
+  const int C = sbase[nb];
+
+  // ---- round trip 2, part 1: this thread's candidate (the first 256) -- prior-table entries
+  const float mse_new = st.mse0[frame];
+  int my_b = 0, my_c = 0;
+  double my_lb = 0.0, my_ld = 0.0;
+  if (tid < C) {
+    while (tid >= sbase[my_b + 1]) ++my_b;
+    my_c = tid - sbase[my_b];
+    my_ld = st.logden[ssum[my_b]];
+    if (my_c < sK[my_b] && my_c != slast[my_b]) my_lb = st.logblk[sblk[my_b * Kmax + my_c]];
+  }
 
   // ---- A: weighted MSE of the frame against every live cluster state.
   // 16 lanes per cluster state (16 states per pass over the workgroup): physical lane p
@@ -458,57 +567,64 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   // the first two butterfly levels are register adds and the last four stay inside a
   // 16-lane row.
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  const float* xrow = st.x + (size_t)frame * m.Dp;
   {
     const int grp = tid >> 4, p = tid & 15;
     for (int i0 = 0; i0 < nlive; i0 += 16) {
       const int i = i0 + grp;
       const bool act = i < nlive;
-      const int s = slivelist[act ? i : 0];
-      const float* mean = pmean + (size_t)s * m.Dp;
+      const int sl = slivelist[act ? i : 0];
+      const float* mean = pmean + (size_t)sl * m.Dp;
+      const int cnt = (p == 0) ? st.pool_cnt[(size_t)u * S + sl] : 0;
       float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       float first_sq = 0.0f;
       for (int q = 0; q < m.Dp; q += 256) {
-        f32x4 mv[4];
+        f32x4 mv[4], xv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int d = q + 4 * (p + 16 * k);
-          mv[k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          const bool in = d < m.Dp;
+          mv[k] = in ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int d = q + 4 * (p + 16 * k);
           if (d < m.Dp) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + d);
             const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[e2], wv[e2]);
-            if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0]; first_sq = d0 * d0; }
+            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
+            if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
           }
         }
       }
       float t = (v[0] + v[2]) + (v[1] + v[3]);   // butterfly levels 32 and 16
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-      if (p == 0 && act) smse[s] = uis_mse_finish(t, first_sq, m.D);
+      if (p == 0 && act) { smse[sl] = uis_mse_finish(t, first_sq, m.D); scnt[sl] = cnt; }
     }
   }
   __syncthreads();
 
   // ---- B: candidate scores
-  const int C = sbase[nb];
-  const float mse_new = st.mse0[frame];
   for (int i = tid; i < C; i += 256) {
-    int b = 0;
-    while (i >= sbase[b + 1]) ++b;
-    const int c = i - sbase[b];
+    int b, c;
+    double lb, ld;
+    if (i == tid) { b = my_b; c = my_c; lb = my_lb; ld = my_ld; }
+    else {
+      b = 0;
+      while (i >= sbase[b + 1]) ++b;
+      c = i - sbase[b];
+      ld = st.logden[ssum[b]];
+      lb = (c < sK[b] && c != slast[b]) ? st.logblk[sblk[b * Kmax + c]] : 0.0;
+    }
     float mse; double prior;
     if (c < sK[b]) {  // existing cluster, uisrnn.py:409-420
       mse = smse[sslot[b * Kmax + c]];
-      prior = (c == slast[b]) ? m.lp_stay
-                              : (m.lp_sw + st.logblk[sblk[b * Kmax + c]]) - st.logden[ssum[b]];
+      prior = (c == slast[b]) ? m.lp_stay : (m.lp_sw + lb) - ld;
     } else {          // new cluster, uisrnn.py:440-446
       mse = mse_new;
-      prior = (m.lp_sw + m.l_alpha) - st.logden[ssum[b]];
+      prior = (m.lp_sw + m.l_alpha) - ld;
     }
     const float sc = sscore[b] + uis_step_loss(mse, prior);  // float32 accumulate, uisrnn.py:452
     scscore[i] = sc;
@@ -519,6 +635,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   __syncthreads();
 
   // ---- C: rank by counting (keys are unique)
+  const int lane = tid & 63, wave = tid >> 6;
   const int nfin = smisc[1];
   const int keep = nfin < B ? nfin : B;  // uisrnn.py:551-552
   for (int i = tid; i < C; i += 256) {
@@ -612,7 +729,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     atomicMax(&st.counters[3], (unsigned long long)Knew);
     if (slead[r] == r) {  // emit the rnn row
       const int src = ssrc[r];
-      const int nprev = src >= 0 ? st.pool_cnt[(size_t)u * S + src] : 0;
+      const int nprev = src >= 0 ? scnt[src] : 0;
       st.pool_cnt[(size_t)u * S + sdst[r]] = nprev + 1;
       const int pos = atomicAdd(&st.nrows[par], 1);
       RnnRow rr; rr.utt = u; rr.src = src; rr.dst = sdst[r]; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
