@@ -29,8 +29,11 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
   dec = decoder or _capi.Decoder(params)
   frames, offsets = oracle_lib.pack(seqs)
   cap = max(int(ref['max_clusters'].max()) if len(seqs) else 1, 1)
+  # intermediate look-ahead levels hold hypotheses with up to look_ahead - 1 more clusters
+  # than any survivor
   out = dec.decode(frames, offsets, beam_size, look_ahead, test_iteration,
-                   max_clusters=max_clusters or max(cap, 4), flags=flags,
+                   max_clusters=max_clusters or max(cap + look_ahead - 1, 4),
+                   flags=flags,
                    want_beam_scores=True, n_streams=n_streams)
   assert out['status'] == 0
   assert not out['overflow'].any()
@@ -76,16 +79,39 @@ def test_golden_cases_bit_exact(name, oracle_lib):
   case = golden_util.load_case(name)
   dec = _capi.Decoder(case['params'])
   for run in case['runs']:
-    if run['look_ahead'] != 1:
-      continue
-    out, _ = _compare(case['params'], case['seqs'], run['beam_size'], 1,
-                      run['test_iteration'], oracle_lib, decoder=dec)
+    out, _ = _compare(case['params'], case['seqs'], run['beam_size'],
+                      run['look_ahead'], run['test_iteration'], oracle_lib,
+                      decoder=dec)
     # and against the reference's own outputs stored in the fixture
     offsets = np.cumsum([0] + [len(s) for s in case['seqs']])
     for u in range(len(case['seqs'])):
       assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]],
                             run['labels'][u])
     np.testing.assert_allclose(out['scores'], run['best'], rtol=1e-4)
+
+
+def test_tracker_golden_look_ahead(oracle_lib):
+  """D=256/H=512 fixture (labels and scores recorded from the reference), L = 1 and 2."""
+  case = golden_util.load_case('tracker_d256')
+  dec = _capi.Decoder(case['params'])
+  for run in case['runs']:
+    out, _ = _compare(case['params'], case['seqs'], run['beam_size'],
+                      run['look_ahead'], run['test_iteration'], oracle_lib,
+                      decoder=dec)
+    offsets = np.cumsum([0] + [len(s) for s in case['seqs']])
+    for u in range(len(case['seqs'])):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]],
+                            run['labels'][u])
+    np.testing.assert_allclose(out['scores'], run['best'], rtol=1e-4)
+
+
+def test_look_ahead_wide_beam(oracle_lib):
+  """BASELINE config #3 shape at a size the oracle finishes: beam 50, look_ahead 2."""
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(7000, 3, [30, 17, 24], 256)
+  out, _ = _compare(params, seqs, 50, 2, 2, oracle_lib, max_clusters=12)
+  assert out['stats']['rnn_rows'] < out['stats']['rnn_rows_nodedup']
+  _compare(params, seqs[:2], 20, 3, 1, oracle_lib, max_clusters=8)
 
 
 def test_tracker_d256_bit_exact(oracle_lib):

@@ -61,6 +61,7 @@ struct DevBuf {
 
 #define UIS_WIDE_TILE_ROWS 1024   // rnn rows per step above which the 2x2 tiles win
 #define UIS_MAX_GROUPS 8
+#define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
 
 struct GraphCache {
@@ -87,6 +88,7 @@ struct uis_handle {
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
+  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base;
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -230,7 +232,7 @@ int rnn_step_once(uis_handle* h, const float* d_x, const float* d_hin, float* d_
   HIPCHK(hipMemcpyAsync(d_nrows, nr, sizeof(nr), hipMemcpyHostToDevice, h->stream));
   LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(1, m.G / 16), dim3(256), 0, m, d_x, d_gi0, 1L);
   DecodeState st{};
-  st.U = 1; st.B = 1; st.Kmax = 1; st.S = 1; st.L = 1; st.tau = 1;
+  st.U = 1; st.B = 1; st.Kmax = 1; st.S = 1; st.L = 1; st.tau = 1; st.max_rows = 1;
   st.gi0 = d_gi0; st.pool_mean = d_mean; st.pool_hid = d_hout; st.rows = d_rows; st.nrows = d_nrows;
   st.gi_up = d_gi_up; st.a1 = d_a1;
   const float* saved_h1 = m.h1;
@@ -271,10 +273,11 @@ struct GroupPlan {
 // The kernels of `nsteps` consecutive decode steps (starting at an even step) on `stream`.
 int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t select_lds, int nsteps) {
   const DevModel& m = h->m;
-  const long max_rows = (long)st.U * st.B;
+  const long max_rows = st.max_rows;
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
-    LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
+    if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
+    else LAUNCH(UIS_K_EXPAND, k_window, dim3(st.U), dim3(256), 0, m, st, par);
     int rc = launch_rnn(h, lch, st, par, max_rows);
     if (rc) return rc;
   }
@@ -289,7 +292,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   int Kmax = opts->max_clusters > 0 ? opts->max_clusters : 16;
   if (B < 1 || B > 256) return fail(UIS_ERR_UNSUPPORTED, "beam_size must be in [1, 256]");
   if (L < 1 || tau < 1) return fail(UIS_ERR_INVALID_ARG, "look_ahead and test_iteration must be >= 1");
-  if (L != 1) return fail(UIS_ERR_UNSUPPORTED, "look_ahead > 1 is not built yet");
+  if (L > UIS_MAX_LOOKAHEAD) return fail(UIS_ERR_UNSUPPORTED, "look_ahead must be <= 8");
   if (Kmax > 4096) return fail(UIS_ERR_UNSUPPORTED, "max_clusters must be <= 4096");
   if (offsets[0] != 0) return fail(UIS_ERR_INVALID_ARG, "offsets[0] must be 0");
   int64_t maxN = 0;
@@ -310,15 +313,38 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipSetDevice(h->device));
 
   const int U = n_utt;
-  const int S = B * Kmax + B;
+  // look_ahead >= 2: capacity of an intermediate level = every assignment of the window's first
+  // j frames, N_j = B * prod_{i=1..j} (Kmax + i), capped; the slot pool holds the beam's states,
+  // every level's new ones and the winners'.
+  int64_t NC = B, S64 = (int64_t)B * Kmax + B;
+  if (L > 1) {
+    int64_t nj = B;
+    NC = 0;
+    for (int j2 = 1; j2 < L; ++j2) {
+      nj = std::min<int64_t>(nj * (Kmax + j2), UIS_LEVEL_CAP);
+      NC = std::max(NC, nj);
+      S64 += nj;
+    }
+  }
+  if (S64 > 0x3fffffff) return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters ^ look_ahead too large");
+  const int S = (int)S64;
   const bool profile = (opts->flags & UIS_FLAG_PROFILE) != 0;
   const bool use_graph = !profile && (opts->flags & UIS_FLAG_GRAPH) != 0;
   Launcher lch{h, h->stream, profile};
   h->prof.used = 0; h->prof.cls.clear();
 
-  const SelectLds lds = select_lds_layout(m.Dp, B, Kmax, S);
-  if (lds.total > 160 * 1024)
-    return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+  SelectLds lds{};
+  if (L == 1) {
+    lds = select_lds_layout(m.Dp, B, Kmax, S);
+    if (lds.total > 160 * 1024)
+      return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+  }
+  const WindowScratch wsl = window_scratch_layout(S, (int)NC, Kmax, B);
+  {  // refuse configurations whose state would not fit the device instead of failing in hipMalloc
+    const double bytes = (double)U * S * (m.Dp + (double)m.depth * m.Hp) * 4.0 +
+                         (L > 1 ? (double)U * (wsl.total + 2.0 * NC * (Kmax * 8.0 + 32.0) + NC * (m.Hp + m.G) * 4.0) : 0.0);
+    if (bytes > 200e9) return fail(UIS_ERR_OOM, "decode state would need " + std::to_string((long long)(bytes / 1e9)) + " GB");
+  }
 
   // ---- utterance groups: independent lock-step chains, one stream each.  Measured on
   // MI355X: the device overlaps at most ~2 of these small kernels, so more
@@ -342,7 +368,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     for (int u = plan[g].u0; u < plan[g].u0 + plan[g].U; ++u)
       plan[g].maxT = std::max<int64_t>(plan[g].maxT, (int64_t)tau * (offsets[u + 1] - offsets[u]));
   }
-  const long max_rows = (long)U * B;
+  const long max_rows = (long)U * (L == 1 ? B : (long)NC);
+  // back-pointer records per utterance (look_ahead >= 2): windows x B
+  std::vector<int64_t> bp_base(U + 1, 0);
+  if (L > 1)
+    for (int u = 0; u < U; ++u)
+      bp_base[u + 1] = bp_base[u] + (((int64_t)tau * (offsets[u + 1] - offsets[u]) + L - 1) / L) * B;
 
   // ---- workspace
   int rc;
@@ -365,7 +396,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_score, (size_t)2 * U * B * 4);
   ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
   ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
-  ENSURE(bp, (size_t)std::max<int64_t>(tau * F, 1) * B * 4);
+  ENSURE(bp, L == 1 ? (size_t)std::max<int64_t>(tau * F, 1) * B * 4 : 16);
   const long rows_cap = max_rows + 48L * G;  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
@@ -373,6 +404,20 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
+  if (L > 1) {
+    ENSURE(lv_n, (size_t)2 * U * 4);
+    ENSURE(lv_K, (size_t)2 * U * NC * 4);
+    ENSURE(lv_last, (size_t)2 * U * NC * 4);
+    ENSURE(lv_sum, (size_t)2 * U * NC * 4);
+    ENSURE(lv_score, (size_t)2 * U * NC * 4);
+    ENSURE(lv_origin, (size_t)2 * U * NC * 4);
+    ENSURE(lv_path, (size_t)2 * U * NC * L * 2);
+    ENSURE(lv_slot, (size_t)2 * U * NC * Kmax * 4);
+    ENSURE(lv_blk, (size_t)2 * U * NC * Kmax * 4);
+    ENSURE(scratch, (size_t)U * wsl.total);
+    ENSURE(bp16, (size_t)std::max<int64_t>(bp_base[U], 1) * (L + 1) * 2);
+    ENSURE(bp_base, (size_t)(U + 1) * 8);
+  }
 #undef ENSURE
 
   // ---- per-decode tables
@@ -384,6 +429,8 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->off.p, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->logblk.p, logblk.data(), logblk.size() * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->logden.p, logden.data(), logden.size() * 8, hipMemcpyHostToDevice, h->stream));
+  if (L > 1)
+    HIPCHK(hipMemcpyAsync(h->bp_base.p, bp_base.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream));
 
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
@@ -405,11 +452,13 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipEventRecord(h->ev_pre, h->stream));
 
   // ---- group views of the shared buffers
+  const size_t rows_per_utt = (size_t)(L == 1 ? B : NC);
   for (int g = 0; g < G; ++g) {
     GroupPlan& gp = plan[g];
     DecodeState& st = gp.st;
     const size_t u0 = (size_t)gp.u0;
     st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags;
+    st.max_rows = (int)((size_t)gp.U * rows_per_utt);
     st.off = h->off.as<int64_t>() + u0;
     st.utt_step = h->utt_step.as<int32_t>() + u0;
     st.overflow = h->overflow.as<int32_t>() + u0;
@@ -427,11 +476,27 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.beam_slot = h->beam_slot.as<int32_t>() + 2 * u0 * B * Kmax;
     st.beam_blk = h->beam_blk.as<int32_t>() + 2 * u0 * B * Kmax;
     st.bp = h->bp.as<uint32_t>();
-    st.rows = h->rows.as<RnnRow>() + u0 * B + 48 * (size_t)g;
+    st.rows = h->rows.as<RnnRow>() + u0 * rows_per_utt + 48 * (size_t)g;
     st.nrows = h->nrows.as<int32_t>() + 2 * g;
-    st.gi_up = h->gi_up.as<float>() + (m.depth > 1 ? (u0 * B + 48 * (size_t)g) * m.G : 0);
-    st.a1 = h->a1.as<float>() + (u0 * B + 48 * (size_t)g) * m.Hp;
+    st.gi_up = h->gi_up.as<float>() + (m.depth > 1 ? (u0 * rows_per_utt + 48 * (size_t)g) * m.G : 0);
+    st.a1 = h->a1.as<float>() + (u0 * rows_per_utt + 48 * (size_t)g) * m.Hp;
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
+    if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
+      st.NC = (int)NC;
+      st.lv_n = h->lv_n.as<int32_t>() + 2 * u0;
+      st.lv_K = h->lv_K.as<int32_t>() + 2 * u0 * NC;
+      st.lv_last = h->lv_last.as<int32_t>() + 2 * u0 * NC;
+      st.lv_sum = h->lv_sum.as<int32_t>() + 2 * u0 * NC;
+      st.lv_score = h->lv_score.as<float>() + 2 * u0 * NC;
+      st.lv_origin = h->lv_origin.as<int32_t>() + 2 * u0 * NC;
+      st.lv_path = h->lv_path.as<int16_t>() + 2 * u0 * NC * L;
+      st.lv_slot = h->lv_slot.as<int32_t>() + 2 * u0 * NC * Kmax;
+      st.lv_blk = h->lv_blk.as<int32_t>() + 2 * u0 * NC * Kmax;
+      st.scratch = h->scratch.as<unsigned char>() + u0 * wsl.total;
+      st.scratch_stride = wsl.total;
+      st.bp16 = h->bp16.as<uint16_t>();
+      st.bp_base = h->bp_base.as<int64_t>() + u0;
+    }
   }
 
   // ---- lock-step decode of every group on its own stream
@@ -465,8 +530,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       for (int64_t s0 = 0; s0 < nsteps; s0 += 2)
         if ((rc = enqueue_steps(h, gl, gp.st, lds.total, 2))) return rc;
     }
-    LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
-           d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
+    if (L == 1)
+      LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
+             d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
+    else
+      LAUNCH(UIS_K_BACKTRACE, k_backtrace_window, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
+             d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
     HIPCHK(hipEventRecord(h->gdone[g], sg));
   }
   for (int g = 0; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->stream, h->gdone[g], 0));
@@ -531,7 +600,9 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores};
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores,
+                    &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
+                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);

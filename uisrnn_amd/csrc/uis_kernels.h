@@ -47,6 +47,7 @@ struct DevModel {
 // Everything the per-step kernels need about the running decode.
 struct DecodeState {
   int U, B, Kmax, S, L, tau;
+  int max_rows;           // capacity of `rows` = the most rnn rows one step can emit
   uint32_t flags;
   // utterances
   const int64_t* off;     // [U+1] frame offsets
@@ -81,4 +82,22 @@ struct DecodeState {
   float* a1;              // [U*B][Hp]  relu(linear_mean1)
   // counters (device): [0] rnn rows, [1] rnn rows without dedup, [2] candidates, [3] max K
   unsigned long long* counters;
+
+  // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
+  // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.
+  int NC;                 // level capacity per utterance
+  int32_t* lv_n;          // [2][U]
+  int32_t* lv_K;          // [2][U][NC]
+  int32_t* lv_last;       // [2][U][NC]
+  int32_t* lv_sum;        // [2][U][NC]
+  float*   lv_score;      // [2][U][NC]
+  int32_t* lv_origin;     // [2][U][NC]   beam hypothesis the node descends from
+  int16_t* lv_path;       // [2][U][NC][L] clusters chosen so far in this window
+  int32_t* lv_slot;       // [2][U][NC][Kmax]
+  int32_t* lv_blk;        // [2][U][NC][Kmax]
+  unsigned char* scratch; // per-utterance work arrays of k_window
+  size_t scratch_stride;  // bytes per utterance
+  // back-pointers per window: bp16[(bp_base[u] + w*B + r)*(L+1)] = {parent, c_1 .. c_L}
+  uint16_t* bp16;
+  const int64_t* bp_base; // [U]
 };

@@ -224,7 +224,7 @@ struct StepTile {
 template <int RT, int CT>
 __device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft, RnnRow (&lane_row)[RT]) {
   StepTile t;
-  const int max_rt = (st.U * st.B + 15) >> 4;
+  const int max_rt = (st.max_rows + 15) >> 4;
   const int n_rg = (max_rt + RT - 1) / RT, n_fg = (nft + CT - 1) / CT;
   int rg, fg;
   dense_block_map(blockIdx.x, n_rg, n_fg, rg, fg);
@@ -742,6 +742,352 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     atomicAdd(&st.counters[0], (unsigned long long)nlead);
     atomicAdd(&st.counters[1], (unsigned long long)keep);
     atomicAdd(&st.counters[2], (unsigned long long)C);
+  }
+}
+
+// ------------------------------------------------------------------ window
+//
+// look_ahead >= 2 (uisrnn.py:469-477,529-559): a window of Lw <= L frames is scored jointly.
+// Sub-step j < Lw-1 EXPANDS every hypothesis of the current level into all its finite
+// children (one per cluster assignment, in lexicographic order) and schedules the CoreRNN
+// rows that produce the children's cluster states; the last sub-step PRUNES to the beam
+// exactly like k_select.  Children of one parent share everything but one cluster state, and
+// children of different parents that extend the same cluster state share the new one too
+// (one rnn row per distinct source state), so a window costs far fewer CoreRNN evaluations
+// than the reference's enumeration.
+//
+// One workgroup per utterance; work arrays live in a per-utterance global scratch region
+// (levels can hold thousands of hypotheses), ordering steps are block scans.
+
+struct HypView {
+  int cap;
+  int32_t* n; int32_t* K; int32_t* last; int32_t* sum; float* score;
+  int32_t* slot; int32_t* blk; int32_t* origin; int16_t* path;
+};
+
+__device__ __forceinline__ HypView beam_view(const DecodeState& st, int u, int par) {
+  HypView v;
+  const size_t e = ((size_t)par * st.U + u) * st.B;
+  v.cap = st.B;
+  v.n = st.beam_n + (size_t)par * st.U + u;
+  v.K = st.beam_K + e; v.last = st.beam_last + e; v.sum = st.beam_sum + e; v.score = st.beam_score + e;
+  v.slot = st.beam_slot + e * st.Kmax; v.blk = st.beam_blk + e * st.Kmax;
+  v.origin = nullptr; v.path = nullptr;
+  return v;
+}
+__device__ __forceinline__ HypView level_view(const DecodeState& st, int u, int buf) {
+  HypView v;
+  const size_t e = ((size_t)buf * st.U + u) * st.NC;
+  v.cap = st.NC;
+  v.n = st.lv_n + (size_t)buf * st.U + u;
+  v.K = st.lv_K + e; v.last = st.lv_last + e; v.sum = st.lv_sum + e; v.score = st.lv_score + e;
+  v.slot = st.lv_slot + e * st.Kmax; v.blk = st.lv_blk + e * st.Kmax;
+  v.origin = st.lv_origin + e; v.path = st.lv_path + e * st.L;
+  return v;
+}
+
+struct WindowScratch {
+  size_t live, livelist, mse, cnt, first, cbase, key, cscore, win, src, dst, lead, ord, freelist, total;
+};
+__host__ __device__ inline WindowScratch window_scratch_layout(int S, int NC, int Kmax, int B) {
+  WindowScratch w;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return r; };
+  const size_t in_cap = (size_t)(NC > B ? NC : B);
+  const size_t C = in_cap * (size_t)(Kmax + 1);
+  const size_t out_cap = in_cap;
+  w.live = take((size_t)S * 4);
+  w.livelist = take((size_t)S * 4);
+  w.mse = take((size_t)S * 4);
+  w.cnt = take((size_t)S * 4);
+  w.first = take((size_t)(S + 1) * 4);
+  w.cbase = take((in_cap + 1) * 4);
+  w.key = take(C * 8);
+  w.cscore = take(C * 4);
+  w.win = take(out_cap * 4);
+  w.src = take(out_cap * 4);
+  w.dst = take(out_cap * 4);
+  w.lead = take(out_cap * 4);
+  w.ord = take(out_cap * 4);
+  w.freelist = take(out_cap * 4);
+  w.total = o;
+  return w;
+}
+
+// Exclusive prefix sums over i in [0, n) of val(i) by 256 threads (contiguous chunk each);
+// emit(i, prefix) is called for every i; returns the total.  lds4: 4 ints of LDS.
+template <typename V, typename E>
+__device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (n + 255) >> 8;
+  const int lo = tid * chunk < n ? tid * chunk : n;
+  const int hi = lo + chunk < n ? lo + chunk : n;
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += val(i);
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) lds4[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { const int c = lds4[w]; if (w < wave) base += c; total += c; }
+  int run = base + incl - cnt;
+  for (int i = lo; i < hi; ++i) { emit(i, run); run += val(i); }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int par) {
+  __shared__ int lds4[4];
+  __shared__ int lds_misc[8];  // [0] nlive [1] nfinite
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int B = st.B, Kmax = st.Kmax, S = st.S, L = st.L, NC = st.NC;
+  const int step = st.utt_step[u];
+  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
+  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
+  const long N = off1 - off0;
+  const long T = (long)st.tau * N;
+  if (step >= T) return;
+  const long frame = off0 + (step % N);
+  const long win = step / L;
+  const long t0 = win * L;
+  const int Lw = (int)((T - t0) < L ? (T - t0) : L);   // ragged last window, uisrnn.py:532-533
+  const int j = (int)(step - t0);
+  const bool last = j == Lw - 1;
+  const int wpar = (int)(win & 1);
+  const HypView in = j == 0 ? beam_view(st, u, wpar) : level_view(st, u, (j - 1) & 1);
+  const HypView out = last ? beam_view(st, u, wpar ^ 1) : level_view(st, u, j & 1);
+  const int n_in = *in.n;
+
+  unsigned char* scr = st.scratch + (size_t)u * st.scratch_stride;
+  const WindowScratch W = window_scratch_layout(S, NC, Kmax, B);
+  int* live = reinterpret_cast<int*>(scr + W.live);
+  int* livelist = reinterpret_cast<int*>(scr + W.livelist);
+  float* mse = reinterpret_cast<float*>(scr + W.mse);
+  int* cntv = reinterpret_cast<int*>(scr + W.cnt);
+  int* first = reinterpret_cast<int*>(scr + W.first);
+  int* cbase = reinterpret_cast<int*>(scr + W.cbase);
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(scr + W.key);
+  float* cscore = reinterpret_cast<float*>(scr + W.cscore);
+  int* winv = reinterpret_cast<int*>(scr + W.win);
+  int* srcv = reinterpret_cast<int*>(scr + W.src);
+  int* dstv = reinterpret_cast<int*>(scr + W.dst);
+  int* leadv = reinterpret_cast<int*>(scr + W.lead);
+  int* ordv = reinterpret_cast<int*>(scr + W.ord);
+  int* freelist = reinterpret_cast<int*>(scr + W.freelist);
+
+  // ---- live cluster states of the input level, candidate offsets
+  for (int sl = tid; sl <= S; sl += 256) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
+  if (tid < 8) lds_misc[tid] = 0;
+  __syncthreads();
+  for (int e = tid; e < n_in * Kmax; e += 256) {
+    const int i = e / Kmax, c = e - i * Kmax;
+    if (c < in.K[i]) live[in.slot[(size_t)i * Kmax + c]] = 1;
+  }
+  const int C = block_scan(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
+  if (tid == 0) cbase[n_in] = C;
+  for (int sl = tid; sl < S; sl += 256)
+    if (live[sl]) livelist[atomicAdd(&lds_misc[0], 1)] = sl;
+  __syncthreads();
+  const int nlive = lds_misc[0];
+
+  // ---- weighted MSE of the frame against every live cluster state (as k_select, phase A)
+  const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  const float* xrow = st.x + (size_t)frame * m.Dp;
+  {
+    const int grp = tid >> 4, p = tid & 15;
+    for (int i0 = 0; i0 < nlive; i0 += 16) {
+      const int i = i0 + grp;
+      const bool act = i < nlive;
+      const int sl = livelist[act ? i : 0];
+      const float* mean = pmean + (size_t)sl * m.Dp;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float first_sq = 0.0f;
+      for (int q = 0; q < m.Dp; q += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = q + 4 * (p + 16 * k);
+          if (d < m.Dp) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + d);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + d);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(m.wgt + d);
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[e2], xv[e2], wv[e2]);
+            if (q == 0 && k == 0) { const float d0 = mv[0] - xv[0]; first_sq = d0 * d0; }
+          }
+        }
+      }
+      float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+      if (p == 0 && act) { mse[sl] = uis_mse_finish(t, first_sq, m.D); cntv[sl] = st.pool_cnt[(size_t)u * S + sl]; }
+    }
+  }
+  __syncthreads();
+
+  // ---- candidate scores
+  const float mse_new = st.mse0[frame];
+  auto node_of = [&](int i) {  // largest node with cbase[node] <= i
+    int lo = 0, hi = n_in;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cbase[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+  };
+  for (int i = tid; i < C; i += 256) {
+    const int b = node_of(i);
+    const int c = i - cbase[b];
+    const int Kb = in.K[b];
+    float ms; double prior;
+    if (c < Kb) {
+      ms = mse[in.slot[(size_t)b * Kmax + c]];
+      prior = (c == in.last[b]) ? m.lp_stay
+                                : (m.lp_sw + st.logblk[in.blk[(size_t)b * Kmax + c]]) - st.logden[in.sum[b]];
+    } else {
+      ms = mse_new;
+      prior = (m.lp_sw + m.l_alpha) - st.logden[in.sum[b]];
+    }
+    const float sc = in.score[b] + uis_step_loss(ms, prior);
+    cscore[i] = sc;
+    const bool fin = uis_isfinite(sc);
+    key[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
+  }
+  __syncthreads();
+
+  // ---- which candidates go on: all finite ones in order (expand) or the B best (prune)
+  int keep;
+  if (!last) {
+    const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; },
+                                [&](int i, int pre) { if (key[i] != ~0ull && pre < NC) winv[pre] = i; }, lds4);
+    keep = nfin;
+    if (keep > NC) { keep = NC; if (tid == 0) st.overflow[u] = 1; }
+  } else {
+    const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
+    keep = nfin < B ? nfin : B;
+    for (int i = tid; i < C; i += 256) {
+      const unsigned long long k = key[i];
+      if (k == ~0ull) continue;
+      int rank = 0;
+      for (int j2 = 0; j2 < C && rank < keep; ++j2) rank += key[j2] < k;
+      if (rank < keep) winv[rank] = i;
+    }
+  }
+  __syncthreads();
+
+  // ---- source cluster state per survivor; one rnn row per distinct source (index S = fresh cluster)
+  const bool nodedup = (st.flags & 1u) != 0;
+  for (int r = tid; r < keep; r += 256) {
+    const int i = winv[r];
+    const int b = node_of(i);
+    const int c = i - cbase[b];
+    const int src = c < in.K[b] ? in.slot[(size_t)b * Kmax + c] : S;
+    srcv[r] = src;
+    if (!nodedup) atomicMin(&first[src], r);
+  }
+  __syncthreads();
+  for (int r = tid; r < keep; r += 256) leadv[r] = nodedup ? r : first[srcv[r]];
+  __syncthreads();
+  const int nlead = block_scan(keep, [&](int r) { return leadv[r] == r ? 1 : 0; },
+                               [&](int r, int pre) { ordv[r] = pre; }, lds4);
+  block_scan(S, [&](int sl) { return live[sl] ? 0 : 1; },
+             [&](int sl, int pre) { if (!live[sl] && pre < nlead) freelist[pre] = sl; }, lds4);
+  for (int r = tid; r < keep; r += 256) if (leadv[r] == r) dstv[r] = freelist[ordv[r]];
+  __syncthreads();
+  for (int r = tid; r < keep; r += 256) if (leadv[r] != r) dstv[r] = dstv[leadv[r]];
+  __syncthreads();
+
+  // ---- write the next level / the next beam
+  for (long e = tid; e < (long)keep * Kmax; e += 256) {
+    const int r = (int)(e / Kmax), c2 = (int)(e - (long)r * Kmax);
+    const int i = winv[r];
+    const int b = node_of(i);
+    const int c = i - cbase[b];
+    const int Kb = in.K[b];
+    const bool is_new = c == Kb;
+    const int Knew = Kb + (is_new ? 1 : 0);
+    if (c2 < Knew) {
+      int slot, blk;
+      if (c2 == c) { slot = dstv[r]; blk = is_new ? 1 : in.blk[(size_t)b * Kmax + c] + (c != in.last[b] ? 1 : 0); }
+      else { slot = in.slot[(size_t)b * Kmax + c2]; blk = in.blk[(size_t)b * Kmax + c2]; }
+      out.slot[(size_t)r * Kmax + c2] = slot;
+      out.blk[(size_t)r * Kmax + c2] = blk;
+    }
+  }
+  uint16_t* bp = st.bp16 + ((size_t)st.bp_base[u] + (size_t)win * B) * (L + 1);
+  for (int r = tid; r < keep; r += 256) {
+    const int i = winv[r];
+    const int b = node_of(i);
+    const int c = i - cbase[b];
+    const int Kb = in.K[b];
+    const bool is_new = c == Kb;
+    int Knew = Kb + (is_new ? 1 : 0);
+    if (Knew > Kmax) { Knew = Kmax; st.overflow[u] = 1; }
+    out.K[r] = Knew;
+    out.last[r] = c;
+    out.sum[r] = in.sum[b] + ((is_new || c != in.last[b]) ? 1 : 0);
+    out.score[r] = cscore[i];
+    const int origin = in.origin ? in.origin[b] : b;
+    if (!last) {
+      out.origin[r] = origin;
+      for (int k = 0; k < j; ++k) out.path[(size_t)r * L + k] = in.path[(size_t)b * L + k];
+      out.path[(size_t)r * L + j] = (int16_t)c;
+    } else {
+      uint16_t* rec = bp + (size_t)r * (L + 1);
+      rec[0] = (uint16_t)origin;
+      for (int k = 0; k < j; ++k) rec[1 + k] = (uint16_t)in.path[(size_t)b * L + k];
+      rec[1 + j] = (uint16_t)c;
+      for (int k = j + 1; k < L; ++k) rec[1 + k] = 0xffffu;
+      atomicMax(&st.counters[3], (unsigned long long)Knew);  // surviving hypotheses only
+    }
+    if (leadv[r] == r) {
+      const int src = srcv[r];
+      const int nprev = src < S ? cntv[src] : 0;
+      st.pool_cnt[(size_t)u * S + dstv[r]] = nprev + 1;
+      const int pos = atomicAdd(&st.nrows[par], 1);
+      RnnRow rr; rr.utt = u; rr.src = src < S ? src : -1; rr.dst = dstv[r]; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
+      st.rows[pos] = rr;
+    }
+  }
+  if (tid == 0) {
+    *out.n = keep;
+    st.utt_step[u] = step + 1;
+    atomicAdd(&st.counters[0], (unsigned long long)nlead);
+    atomicAdd(&st.counters[1], (unsigned long long)keep);
+    atomicAdd(&st.counters[2], (unsigned long long)C);
+  }
+}
+
+// look_ahead >= 2: trace[-N:] from the per-window back-pointers
+__global__ void k_backtrace_window(DecodeState st, int32_t* __restrict__ labels, float* __restrict__ scores,
+                                   float* __restrict__ beam_scores) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= st.U) return;
+  const int L = st.L;
+  const long N = (long)(st.off[u + 1] - st.off[u]);
+  const long T = (long)st.tau * N;
+  const long n_win = (T + L - 1) / L;
+  const int par = (int)(n_win & 1);
+  const int nb = N > 0 ? st.beam_n[(size_t)par * st.U + u] : 0;
+  const size_t e = ((size_t)par * st.U + u) * st.B;
+  if (beam_scores)
+    for (int b = 0; b < st.B; ++b) beam_scores[(size_t)u * st.B + b] = b < nb ? st.beam_score[e + b] : INFINITY;
+  if (scores) scores[u] = nb > 0 ? st.beam_score[e] : (N > 0 ? INFINITY : 0.0f);
+  if (N == 0) return;
+  int32_t* out = labels + st.off[u];
+  if (nb == 0) { for (long i = 0; i < N; ++i) out[i] = -1; return; }
+  int r = 0;
+  for (long w = n_win - 1; w >= 0; --w) {
+    const long t0 = w * L;
+    if (t0 + L <= T - N) break;
+    const uint16_t* rec = st.bp16 + ((size_t)st.bp_base[u] + (size_t)w * st.B + r) * (L + 1);
+    const int Lw = (int)((T - t0) < L ? (T - t0) : L);
+    for (int k = 0; k < Lw; ++k) {
+      const long tt = t0 + k;
+      if (tt >= T - N) out[tt - (T - N)] = (int32_t)rec[1 + k];
+    }
+    r = (int)rec[0];
   }
 }
 
