@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference interface: arguments, errors, weights, C ABI surface.
+
+No GPU needed.  Expected strings / defaults are the reference's
+(uisrnn/arguments.py:30-205, uisrnn/uisrnn.py:510-521,585-590,614-615).
+"""
+
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+import uisrnn_amd
+from uisrnn_amd import _capi
+from uisrnn_amd import arguments
+from uisrnn_amd import synth
+from uisrnn_amd import weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**over):
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model_args.observation_dim = 16
+  model_args.rnn_hidden_size = 8
+  model_args.transition_bias = 0.2
+  model_args.sigma2 = 0.05
+  for key, val in over.items():
+    setattr(model_args, key, val)
+  return model_args, inference_args
+
+
+def test_parse_arguments_defaults():
+  model_args, training_args, inference_args = uisrnn_amd.parse_arguments([])
+  assert vars(model_args) == dict(
+      observation_dim=256, rnn_hidden_size=512, rnn_depth=1, rnn_dropout=0.2,
+      transition_bias=None, crp_alpha=1.0, sigma2=None, verbosity=3,
+      enable_cuda=True)
+  assert vars(inference_args) == dict(beam_size=10, look_ahead=1,
+                                      test_iteration=2)
+  assert training_args.optimizer == 'adam'
+  assert training_args.train_iteration == 20000
+  assert training_args.learning_rate == 1e-3
+  assert training_args.enforce_cluster_id_uniqueness is True
+
+
+def test_parse_arguments_flags_and_str2bool():
+  model_args, _, inference_args = uisrnn_amd.parse_arguments(
+      ['--observation_dim', '32', '-s', '5', '--look_ahead', '2',
+       '--enable_cuda', 'no', '--transition_bias', '0.1'])
+  assert model_args.observation_dim == 32 and model_args.enable_cuda is False
+  assert model_args.transition_bias == 0.1
+  assert inference_args.beam_size == 5 and inference_args.look_ahead == 2
+  assert arguments.str2bool('Yes') is True and arguments.str2bool('0') is False
+  with pytest.raises(Exception):
+    arguments.str2bool('maybe')
+  with pytest.raises(SystemExit):
+    uisrnn_amd.parse_arguments(['--no_such_flag', '1'])
+
+
+def test_predict_argument_errors():
+  """Same exception types and messages as uisrnn/uisrnn.py:510-521,590,614-615."""
+  model_args, inference_args = _args()
+  model = uisrnn_amd.UISRNN(model_args)
+  with pytest.raises(TypeError, match='test_sequence should be a numpy array of float type.'):
+    model.predict_single([[1.0] * 16], inference_args)
+  with pytest.raises(TypeError, match='numpy array of float type'):
+    model.predict_single(np.zeros((4, 16), dtype=np.float32), inference_args)
+  with pytest.raises(ValueError, match='test_sequence must be 2-dim array.'):
+    model.predict_single(np.zeros(16), inference_args)
+  with pytest.raises(ValueError, match='does not match the dimension specified by args.observation_dim'):
+    model.predict_single(np.zeros((4, 15)), inference_args)
+  with pytest.raises(ValueError):
+    model.predict([np.zeros((4, 16)), np.zeros((4, 3))], inference_args)
+  with pytest.raises(TypeError, match='test_sequences should be either a list or numpy array.'):
+    model.predict('abc', inference_args)
+  with pytest.raises(TypeError, match='test_sequences must be a list.'):
+    uisrnn_amd.parallel_predict(model, np.zeros((4, 16)), inference_args)
+  assert model.predict([], inference_args) == []
+  with pytest.raises(NotImplementedError):
+    model.fit(np.zeros((4, 16)), ['a'] * 4, None)
+
+
+def test_untrained_transition_bias_raises_like_reference():
+  model_args, inference_args = _args(transition_bias=None)
+  model = uisrnn_amd.UISRNN(model_args)
+  with pytest.raises(TypeError):
+    model.predict(np.zeros((4, 16)), inference_args)
+
+
+@pytest.mark.skipif(_capi.load_library().uis_device_count() > 0,
+                    reason='a GPU is visible: covered by the gpu tests')
+def test_no_gpu_fails_loudly():
+  """No silent CPU fallback: without a device the decode path raises."""
+  model_args, inference_args = _args()
+  model = uisrnn_amd.UISRNN(model_args)
+  with pytest.raises(_capi.HipLibraryError, match='no HIP device|no CPU fallback'):
+    model.predict(np.zeros((4, 16)), inference_args)
+
+
+def test_product_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'uisrnn_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for name in files:
+      if name.endswith(('.py', '.hip', '.h')):
+        text = open(os.path.join(dirpath, name)).read()
+        assert not re.search(r'^\s*(from|import)\s+oracle', text, re.M), name
+        assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), name
+        assert 'liboracle' not in text, name
+        assert not re.search(r'uis_oracle_\w+\s*\(', text), name  # no calls into the checker
+
+
+def test_library_exports_every_declared_symbol():
+  header = open(os.path.join(ROOT, 'include', 'uisrnn_hip.h')).read()
+  declared = set(re.findall(r'^\s*(?:const\s+char\*|int32_t|void)\s+(uis_\w+)\s*\(',
+                            header, re.M))
+  assert declared == set(_capi.EXPORTED_SYMBOLS)
+  lib = _capi.load_library()
+  for name in declared:
+    assert hasattr(lib, name), name
+  assert lib.uis_abi_version() == 1
+  version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', open(
+      os.path.join(ROOT, 'include', 'uis_numerics.h')).read()).group(1))
+  assert lib.uis_numerics_version() == version
+
+
+def test_struct_layouts_match_header():
+  """ctypes mirrors of the header structs (LP64): sizes and a few offsets."""
+  assert ctypes.sizeof(_capi.ModelDesc) == 16 + 10 * 8 + 16
+  assert _capi.ModelDesc.transition_bias.offset == 96
+  assert ctypes.sizeof(_capi.DecodeOpts) == 32
+  assert _capi.Stats.kernel_ms.offset == 40
+  assert ctypes.sizeof(_capi.Stats) == 40 + 8 * 8 + 8 * 8 + 8
+
+
+def test_c_abi_rejects_bad_arguments_without_a_device():
+  lib = _capi.load_library()
+  assert lib.uis_create(None, 0, None) == _capi.UIS_ERR_INVALID_ARG
+  assert b'null' in lib.uis_last_error()
+  params = weights.init_params(4, 4, 1, sigma2=0.1, transition_bias=1.5, seed=0)
+  desc, keep = _capi.make_desc(params)
+  handle = ctypes.c_void_p()
+  rc = lib.uis_create(ctypes.byref(desc), 0, ctypes.byref(handle))
+  assert rc == _capi.UIS_ERR_INVALID_ARG  # transition_bias outside (0, 1)
+  del keep
+
+
+def test_params_round_trips(tmp_path):
+  params = weights.init_params(6, 5, 2, sigma2=0.3, transition_bias=0.25,
+                               crp_alpha=1.5, seed=3)
+  assert params['gru_weight_ih'][0].shape == (15, 6)
+  assert params['gru_weight_ih'][1].shape == (15, 5)
+  state = weights.state_dict_from_params(params)
+  assert set(state) == {
+      'gru.weight_ih_l0', 'gru.weight_hh_l0', 'gru.bias_ih_l0', 'gru.bias_hh_l0',
+      'gru.weight_ih_l1', 'gru.weight_hh_l1', 'gru.bias_ih_l1', 'gru.bias_hh_l1',
+      'linear_mean1.weight', 'linear_mean1.bias', 'linear_mean2.weight',
+      'linear_mean2.bias'}
+  back = weights.params_from_state(state, params['rnn_init_hidden'],
+                                   params['sigma2'], 0.25, 1.5)
+  assert back['rnn_depth'] == 2 and back['observation_dim'] == 6
+  # the reference's checkpoint format (uisrnn/uisrnn.py:141-147)
+  path = str(tmp_path / 'model.uisrnn')
+  weights.save_checkpoint(params, path)
+  import torch
+  raw = torch.load(path, weights_only=False)
+  assert set(raw) == {'rnn_state_dict', 'rnn_init_hidden', 'transition_bias',
+                      'transition_bias_denominator', 'crp_alpha', 'sigma2'}
+  assert raw['rnn_init_hidden'].shape == (2, 1, 5)
+  loaded = weights.load_checkpoint(path)
+  for key in ('linear_mean2_weight', 'sigma2', 'rnn_init_hidden'):
+    assert np.array_equal(loaded[key], params[key])
+  assert np.array_equal(loaded['gru_weight_hh'][1], params['gru_weight_hh'][1])
+  assert loaded['transition_bias'] == 0.25 and loaded['crp_alpha'] == 1.5
+  # and through the model object
+  model_args, _ = _args(observation_dim=6, rnn_hidden_size=5, rnn_depth=2)
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load(path)
+  assert model.transition_bias == 0.25
+  assert model.rnn_init_hidden.shape == (2, 1, 5)
+  model.save(str(tmp_path / 'again.uisrnn'))
+
+
+def test_synthetic_generators_are_deterministic():
+  a, ida = synth.make_utterance(7, 50, 32)
+  b, idb = synth.make_utterance(7, 50, 32)
+  assert a.dtype == np.float64 and a.shape == (50, 32)
+  assert np.array_equal(a, b) and np.array_equal(ida, idb)
+  p1 = synth.tracker_params(32, 48, 2, seed=1)
+  p2 = synth.tracker_params(32, 48, 2, seed=1)
+  assert np.array_equal(p1['gru_weight_hh'][1], p2['gru_weight_hh'][1])
+  assert p1['gru_weight_ih'][1].shape == (144, 48)
+  with pytest.raises(ValueError):
+    synth.tracker_params(64, 32)
+  assert synth.relabel_first_occurrence([5, 5, 2, 5, 9]) == [0, 0, 1, 0, 2]
+
+
+def test_tracker_model_diarizes_synthetic_speech(oracle_lib):
+  """The closed-form benchmark model behaves like a trained one (accuracy ~1)."""
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, ids = synth.make_utterances(100, 3, 120, 256)
+  out = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=3)
+  for labels, truth in zip(out['labels'], ids):
+    acc = uisrnn_amd.compute_sequence_match_accuracy(labels.tolist(),
+                                                     truth.tolist())
+    assert acc > 0.97
+  assert out['max_clusters'].max() <= 7
+
+
+def test_sequence_match_accuracy_known_answers():
+  """Known answers of the reference's tests/evals_test.py:36-82."""
+  acc = uisrnn_amd.compute_sequence_match_accuracy
+  assert acc([0, 0, 1, 2, 2], [3, 3, 4, 4, 1]) == 0.8
+  assert acc([0, 0, 0, 1, 2], [3, 3, 3, 4, 1]) == 1.0
+  assert acc([1, 1], [1, 2]) == 0.5
+  assert acc(['a', 'b', 'b'], [1, 2, 2]) == 1.0
+  a, b = [0, 1, 1, 2, 0, 3], [4, 4, 5, 6, 4, 4]
+  assert acc(a, b) == acc(b, a)
+  with pytest.raises(TypeError):
+    acc(np.array([0, 1]), [0, 1])
+  with pytest.raises(ValueError):
+    acc([0, 1], [0])
+  with pytest.raises(ValueError):
+    acc([], [])

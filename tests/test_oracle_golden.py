@@ -1,0 +1,127 @@
+"""The CPU oracle against the reference's own outputs (tests/golden/*.npz).
+
+The fixtures were produced by importing google/uis-rnn in the dev container
+(tests/golden/make_golden.py).  Parity bar (BASELINE.json north_star): cluster-id
+sequences identical, log-scores within RELATIVE 1e-4 (scores are float32
+accumulations that reach 1e4..1e5; the observed error is <= 3e-7).
+"""
+
+import numpy as np
+import pytest
+
+import golden_util
+
+RTOL = 1e-4
+CASES = golden_util.case_names()
+
+
+def test_fixtures_present():
+  assert set(CASES) >= {'tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
+                        'd20_h24_depth3', 'tracker_d256'}
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_decode_matches_reference(name, oracle_lib):
+  case = golden_util.load_case(name)
+  for run in case['runs']:
+    out = oracle_lib.decode(case['params'], case['seqs'], run['beam_size'],
+                            run['look_ahead'], run['test_iteration'],
+                            n_threads=4)
+    for u, ref_labels in enumerate(run['labels']):
+      assert np.array_equal(out['labels'][u], ref_labels), (name, run, u)
+    np.testing.assert_allclose(out['scores'], run['best'], rtol=RTOL)
+    # the whole final beam, not just the winner
+    fin = np.isfinite(run['beam'])
+    assert np.array_equal(np.isfinite(out['beam_scores']), fin)
+    np.testing.assert_allclose(out['beam_scores'][fin], run['beam'][fin],
+                               rtol=RTOL)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_core_rnn_matches_reference(name, oracle_lib):
+  """CoreRNN.forward (uisrnn/uisrnn.py:45-52) on recorded inputs."""
+  case = golden_util.load_case(name)
+  unit = case['unit']
+  for x, h, mean_ref, h_ref in zip(unit['unit_x'], unit['unit_h'],
+                                   unit['unit_mean'], unit['unit_hout']):
+    mean, hout = oracle_lib.rnn_step(case['params'], x, h)
+    np.testing.assert_allclose(mean, mean_ref, rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(hout, h_ref, rtol=RTOL, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_weighted_mse_matches_reference(name, oracle_lib):
+  """loss_func.weighted_mse_loss incl. the exact-zero quirk (loss_func.py:36,41)."""
+  case = golden_util.load_case(name)
+  unit = case['unit']
+  saw_inf = False
+  for a, b, ref in zip(unit['mse_a'], unit['mse_b'], unit['mse_val']):
+    got = oracle_lib.weighted_mse(case['params'], a, b)
+    if np.isinf(ref):
+      saw_inf = True
+      assert np.isinf(got) and got > 0
+    else:
+      np.testing.assert_allclose(got, ref, rtol=1e-5)
+  assert saw_inf  # the fixture contains a first-difference-zero row
+
+
+def test_constants_are_rnn_of_zero_input(oracle_lib):
+  """(m0, h1) = CoreRNN(0, rnn_init_hidden), uisrnn/uisrnn.py:435-439."""
+  case = golden_util.load_case('toy_d2_depth2')  # non-zero rnn_init_hidden, depth 2
+  params = case['params']
+  m0, h1 = oracle_lib.constants(params)
+  mean, hout = oracle_lib.rnn_step(
+      params, np.zeros(params['observation_dim'], np.float32),
+      params['rnn_init_hidden'])
+  assert np.array_equal(m0, mean) and np.array_equal(h1, hout)
+
+
+def test_edge_cases(oracle_lib):
+  case = golden_util.load_case('tiny_d16')
+  params = case['params']
+  seq = case['seqs'][0]
+  # no utterances, empty utterance, one frame
+  out = oracle_lib.decode(params, [], 10, 1, 2)
+  assert out['labels'] == []
+  out = oracle_lib.decode(params, [seq[:0], seq[:1], seq], 10, 1, 2)
+  assert len(out['labels'][0]) == 0 and out['scores'][0] == 0.0
+  assert out['labels'][1].tolist() == [0] or len(out['labels'][1]) == 1
+  # a list decodes like its elements one by one, in any thread count
+  one = [oracle_lib.decode(params, [s], 10, 1, 2)['labels'][0]
+         for s in case['seqs']]
+  many = oracle_lib.decode(params, case['seqs'], 10, 1, 2, n_threads=3)
+  for a, b in zip(one, many['labels']):
+    assert np.array_equal(a, b)
+  # beam 1 is greedy: still a valid labelling
+  greedy = oracle_lib.decode(params, [seq], 1, 1, 1)['labels'][0]
+  assert greedy[0] == 0 and greedy.max() <= len(set(greedy.tolist()))
+
+
+def test_labels_are_first_appearance_ordered(oracle_lib):
+  """With test_iteration=1 the trace starts at 0 and new ids appear in order (quirk 9)."""
+  case = golden_util.load_case('d32_lookahead3')
+  for look_ahead in (1, 2, 3):
+    out = oracle_lib.decode(case['params'], case['seqs'], 5, look_ahead, 1)
+    for labels in out['labels']:
+      seen = -1
+      for lab in labels:
+        assert lab <= seen + 1
+        seen = max(seen, lab)
+
+
+def test_ragged_last_window(oracle_lib):
+  """tau*N not a multiple of look_ahead: the last window is shorter (uisrnn.py:532-533)."""
+  case = golden_util.load_case('d32_lookahead3')
+  seq = case['seqs'][0][:7]
+  out = oracle_lib.decode(case['params'], [seq], 4, 3, 1)
+  assert len(out['labels'][0]) == 7
+  assert np.isfinite(out['scores'][0])
+
+
+def test_numerics_version_matches_header(oracle_lib):
+  import os
+  import re
+  header = open(os.path.join(os.path.dirname(__file__), '..', 'include',
+                             'uis_numerics.h')).read()
+  version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', header).group(1))
+  assert oracle_lib.numerics_version() == version

@@ -5,8 +5,10 @@ are the decode-path subset of uisrnn/__init__.py:26-30.
 """
 
 from uisrnn_amd import arguments
+from uisrnn_amd import evals
 from uisrnn_amd import uisrnn as _uisrnn
 
 parse_arguments = arguments.parse_arguments
+compute_sequence_match_accuracy = evals.compute_sequence_match_accuracy
 UISRNN = _uisrnn.UISRNN
 parallel_predict = _uisrnn.parallel_predict
