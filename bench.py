@@ -42,6 +42,25 @@ CONFIG = dict(workload='configs[1]: 64 utt x 500 frames x 256-dim, beam 10, '
               test_iteration=2, model='closed-form tracker (uisrnn_amd.synth)')
 
 
+def committed_traffic(kernel):
+  """HBM bytes per launch of `kernel` from the newest committed PMC run (profiles/), or None.
+
+  PMC counters cannot be read from inside the benchmark process; they are collected with
+  rocprofv3 in separate passes (tools/gpu_pmc.sh) and committed.  FETCH_SIZE is doubled
+  (gfx950 counts 64 B per 128-B request for wide coalesced reads).
+  """
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
+  if not files:
+    return None
+  try:
+    entry = json.load(open(files[-1]))['kernels'][kernel]
+    return {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
+            'source': os.path.relpath(files[-1], ROOT)}
+  except (KeyError, ValueError):
+    return None
+
+
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -151,7 +170,8 @@ def main():
     roofline = {
         'bound': 'mfma', 'kernel': 'k_dense_gru', 'achieved': round(achieved, 3),
         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        'traffic': committed_traffic('k_dense_gru'),
         'avg_launch_us': round(avg_us, 3), 'launches': gru_launches,
         'rows_per_launch_algorithmic': round(rows_algo, 1),
         'rows_per_launch_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
