@@ -73,6 +73,9 @@ def parse():
   ap.add_argument('--cpu_sample', type=int, default=0,
                   help='utterances in the CPU-baseline sample (0 = auto)')
   ap.add_argument('--flags', type=int, default=0, help='UIS_FLAG_* for the timed run')
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                  help='collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to '
+                       'exercise the multi-rank path on a box with fewer GPUs than ranks)')
   ap.add_argument('--streams', type=int, default=0,
                   help='utterance groups decoded concurrently (0 = library default)')
   return ap.parse_args()
@@ -86,17 +89,23 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  n_dev = torch.cuda.device_count()
+  if n_dev < 1:
+    raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
+  dev_index = local_rank if args.backend == 'nccl' else local_rank % n_dev
+  torch.cuda.set_device(dev_index)
   if world > 1:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local_rank))
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world,
+                              device_id=torch.device('cuda', dev_index))
+    else:
+      dist.init_process_group('gloo', rank=rank, world_size=world)
   else:
     dist = None
-    torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
+  dev = torch.device('cuda', dev_index)
 
   dim, hid = CONFIG['observation_dim'], CONFIG['rnn_hidden_size']
   n_utt, n_frames = args.utterances, args.frames
@@ -106,11 +115,12 @@ def main():
   offsets = np.arange(n_utt + 1, dtype=np.int64) * n_frames
   total_frames = n_utt * n_frames
 
-  decoder = _capi.Decoder(params, device=local_rank)
+  decoder = _capi.Decoder(params, device=dev_index)
   d_frames = torch.from_numpy(frames).to(dev)
   d_labels = torch.empty(total_frames, dtype=torch.int32, device=dev)
   d_scores = torch.empty(n_utt, dtype=torch.float32, device=dev)
-  gathered = (torch.empty(world * total_frames, dtype=torch.int32, device=dev)
+  gather_dev = dev if args.backend == 'nccl' else torch.device('cpu')
+  gathered = (torch.empty(world * total_frames, dtype=torch.int32, device=gather_dev)
               if world > 1 else None)
   beam, look, tau = args.beam_size, CONFIG['look_ahead'], CONFIG['test_iteration']
 
@@ -121,8 +131,9 @@ def main():
                                 n_streams=args.streams)
     if out['status'] != 0:
       raise RuntimeError('decode hit the cluster cap in the benchmark workload')
-    if world > 1:
-      dist.all_gather_into_tensor(gathered, d_labels)  # the final gather (RCCL)
+    if world > 1:  # the final gather: the only collective of the path (RCCL over xGMI)
+      dist.all_gather_into_tensor(
+          gathered, d_labels if args.backend == 'nccl' else d_labels.cpu())
     return out
 
   for _ in range(args.warmup):
@@ -139,7 +150,7 @@ def main():
     dist.barrier()
   elapsed = time.perf_counter() - t0
   if world > 1:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 

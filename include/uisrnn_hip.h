@@ -83,6 +83,9 @@ typedef struct uis_decode_opts {
                                     results are bit-identical either way)            */
 #define UIS_FLAG_GRAPH      0x2u /* replay the per-step kernels from a captured hipGraph
                                     (32 steps per graph) instead of launching eagerly  */
+#define UIS_FLAG_GENERIC_SELECT 0x8u /* use the general score/prune kernel even where the
+                                    wave-synchronous fast path applies (A/B switch;
+                                    results are bit-identical either way)            */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

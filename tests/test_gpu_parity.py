@@ -154,6 +154,16 @@ def test_wide_tiles_bit_exact(oracle_lib):
   _compare(params, seqs, 10, 1, 2, oracle_lib)
 
 
+def test_generic_select_flag_is_bit_identical(oracle_lib):
+  """k_select_fast (default where it applies) and the general k_select agree with the oracle."""
+  params = synth.tracker_params(256, 512, 1, seed=4)
+  seqs, _ = synth.make_utterances(8000, 9, [60, 33, 80, 12, 45, 1, 64, 27, 50], 256)
+  _compare(params, seqs, 10, 1, 2, oracle_lib)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_GENERIC_SELECT)
+  _compare(params, seqs, 32, 1, 1, oracle_lib, max_clusters=7)     # 32 * 8 = 256 candidates: fast path limit
+  _compare(params, seqs, 70, 1, 1, oracle_lib, max_clusters=8)     # beyond it: general kernel
+
+
 def _many_cluster_case():
   """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
   from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel

@@ -276,7 +276,9 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
   const long max_rows = st.max_rows;
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
-    if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
+    if (st.L == 1 && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
+      LAUNCH(UIS_K_SELECT, k_select_fast, dim3(st.U), dim3(256), (size_t)fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).total, m, st, par);
+    else if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
     else LAUNCH(UIS_K_EXPAND, k_window, dim3(st.U), dim3(256), 0, m, st, par);
     int rc = launch_rnn(h, lch, st, par, max_rows);
     if (rc) return rc;
@@ -402,7 +404,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
   ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : 16);
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
-  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8);
+  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 64 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
@@ -547,6 +549,16 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), h->beam_scores_out.p, (size_t)U * B * 4, hipMemcpyDeviceToHost,
                         h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+#if defined(UIS_SELECT_TIMING)
+  {
+    unsigned long long tc[24];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    const double launches = (double)maxT * U;
+    fprintf(stderr, "[select timing] cycles per workgroup-launch:");
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, (double)tc[16 + k] / launches);
+    fprintf(stderr, "\n");
+  }
+#endif
   int n_over = 0;
   for (int u = 0; u < U; ++u) n_over += h->last_overflow[u] != 0;
   if (stats) {
@@ -670,6 +682,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, hinit, &d_hinit))) return bail(rc);
   if ((rc = upload(h, std::vector<float>(m.Dp, 0.0f), &m.m0))) return bail(rc);
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return bail(fail(UIS_ERR_HIP, std::string("hipFuncSetAttribute(k_select): ") + hipGetErrorString(e)));
   if ((rc = bootstrap_constants(h, d_hinit))) return bail(rc);

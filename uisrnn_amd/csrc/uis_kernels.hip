@@ -424,7 +424,11 @@ __global__ void k_pad_frames(const float* __restrict__ src, float* __restrict__ 
 // (beam_set = [BeamState()], uisrnn.py:528).
 __global__ void k_init_state(DecodeState st) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull; }  // this group's
+  if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull;  // this group's
+#if defined(UIS_SELECT_TIMING)
+    for (int i = 16; i < 24; ++i) st.counters[i] = 0ull;
+#endif
+  }
   if (u >= st.U) return;
   st.utt_step[u] = 0;
   st.overflow[u] = 0;
@@ -481,9 +485,21 @@ __host__ __device__ inline SelectLds select_lds_layout(int Dp, int B, int Kmax, 
 // Memory round trips on the critical path: (1) step counter, offsets and the whole beam
 // tables; (2) the frame, the live cluster states (+ frame counts), the prior-table entries
 // and the fresh-cluster MSE -- all issued before the first of them is consumed.
+// Diagnostic build (-DUIS_SELECT_TIMING): thread 0 of every workgroup adds the shader-clock
+// cycles of each phase to counters[16 + phase]; decode_impl prints the averages.
+#if defined(UIS_SELECT_TIMING)
+#define TSTAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_now_ = __builtin_readcyclecounter(); \
+    atomicAdd(&st.counters[16 + (k)], t_now_ - t_prev_); t_prev_ = t_now_; } } while (0)
+#else
+#define TSTAMP(k) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int par) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int u = blockIdx.x, tid = threadIdx.x;
+#if defined(UIS_SELECT_TIMING)
+  unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
   const int nxt = par ^ 1;
 
@@ -534,6 +550,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   if (step >= T) return;  // utterance finished (uniform over the workgroup)
   const long frame = off0 + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
   __syncthreads();
+  TSTAMP(0);
   for (int e = tid; e < nb * Kmax; e += 256) {
     const int b = e / Kmax, c = e - b * Kmax;
     if (c < sK[b]) slive[sslot[e]] = 1;
@@ -549,6 +566,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   __syncthreads();
   const int nlive = smisc[0];
   const int C = sbase[nb];
+  TSTAMP(1);
 
   // ---- round trip 2, part 1: this thread's candidate (the first 256) -- prior-table entries
   const float mse_new = st.mse0[frame];
@@ -606,6 +624,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   }
   __syncthreads();
 
+  TSTAMP(2);
   // ---- B: candidate scores
   for (int i = tid; i < C; i += 256) {
     int b, c;
@@ -634,6 +653,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   }
   __syncthreads();
 
+  TSTAMP(3);
   // ---- C: rank by counting (keys are unique)
   const int lane = tid & 63, wave = tid >> 6;
   const int nfin = smisc[1];
@@ -647,6 +667,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   }
   __syncthreads();
 
+  TSTAMP(4);
   // ---- D: winners -> (parent, cluster, source slot); dedup rows by source slot
   const bool nodedup = (st.flags & 1u) != 0;
   if (tid < keep) {
@@ -693,6 +714,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   if (tid < keep && slead[tid] != tid) sdst[tid] = sdst[slead[tid]];
   __syncthreads();
 
+  TSTAMP(5);
   // next beam tables (BeamState copy + the list updates of uisrnn.py:425-433,451)
   for (int e = tid; e < keep * Kmax; e += 256) {
     const int r = e / Kmax, c2 = e - r * Kmax;
@@ -736,6 +758,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
       st.rows[pos] = rr;
     }
   }
+  TSTAMP(6);
   if (tid == 0) {
     st.beam_n[(size_t)nxt * U + u] = keep;
     st.utt_step[u] = step + 1;
@@ -743,6 +766,367 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     atomicAdd(&st.counters[1], (unsigned long long)keep);
     atomicAdd(&st.counters[2], (unsigned long long)C);
   }
+  TSTAMP(7);
+}
+
+// ------------------------------------------------------------- select, fast path
+//
+// Same result as k_select for the common shape: at most 64 hypotheses, at most 256 candidates
+// (thread i owns candidate i), at most 1024 slots.  Six workgroup barriers instead of fifteen:
+// prefix sums, leader election, free-slot choice and the table writes are done by wave 0 with
+// ballots and shuffles, and the row-counter atomic is issued as soon as the row count is known
+// so its round trip overlaps the table writes.
+
+__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {  // n-th (0-based) set bit
+  for (int i = 0; i < n; ++i) mask &= mask - 1;
+  return __ffsll((long long)mask) - 1;
+}
+
+struct FastLds {
+  int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_base, off_score;
+  int off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc;
+  int total;
+};
+__host__ __device__ inline FastLds fast_lds_layout(int Dp, int B, int Kmax, int S) {
+  FastLds l;
+  int o = 0;
+  auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+  l.off_wgt = take(Dp * 4);
+  l.off_slot = take(B * Kmax * 4);
+  l.off_blk = take(B * Kmax * 4);
+  l.off_K = take(B * 4);
+  l.off_last = take(B * 4);
+  l.off_sum = take(B * 4);
+  l.off_base = take((B + 1) * 4);
+  l.off_score = take(B * 4);
+  l.off_live = take(S * 4);
+  l.off_livelist = take(S * 4);
+  l.off_mse = take(S * 4);
+  l.off_cnt = take(S * 4);
+  l.off_key = take(256 * 8);
+  l.off_win = take(64 * 4);
+  l.off_wscore = take(64 * 4);
+  l.off_misc = take(16 * 4);
+  l.total = o;
+  return l;
+}
+__host__ __device__ inline bool select_fast_ok(int B, int Kmax, int S) {
+  return B <= 64 && B * (Kmax + 1) <= 256 && S <= 1024;
+}
+
+__global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(UIS_SELECT_TIMING)
+  unsigned long long t_prev_ = __builtin_readcyclecounter();
+#endif
+  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int nxt = par ^ 1;
+  const FastLds L = fast_lds_layout(m.Dp, B, Kmax, S);
+  float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
+  int* sslot = reinterpret_cast<int*>(smem_raw + L.off_slot);
+  int* sblk = reinterpret_cast<int*>(smem_raw + L.off_blk);
+  int* sK = reinterpret_cast<int*>(smem_raw + L.off_K);
+  int* slast = reinterpret_cast<int*>(smem_raw + L.off_last);
+  int* ssum = reinterpret_cast<int*>(smem_raw + L.off_sum);
+  int* sbase = reinterpret_cast<int*>(smem_raw + L.off_base);
+  float* sscore = reinterpret_cast<float*>(smem_raw + L.off_score);
+  int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
+  int* slivelist = reinterpret_cast<int*>(smem_raw + L.off_livelist);
+  float* smse = reinterpret_cast<float*>(smem_raw + L.off_mse);
+  int* scnt = reinterpret_cast<int*>(smem_raw + L.off_cnt);
+  unsigned long long* skey = reinterpret_cast<unsigned long long*>(smem_raw + L.off_key);
+  int* swin = reinterpret_cast<int*>(smem_raw + L.off_win);
+  float* swscore = reinterpret_cast<float*>(smem_raw + L.off_wscore);
+  int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite
+
+  const size_t bcur = ((size_t)par * U + u) * B;
+  const size_t bnxt = ((size_t)nxt * U + u) * B;
+
+  // ---- round trip 1
+  const int step = st.utt_step[u];
+  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
+  const int nb = st.beam_n[(size_t)par * U + u];
+  if (u == 0 && tid == 0) st.nrows[nxt] = 0;
+  for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
+  for (int e = tid; e < B * Kmax; e += 256) {
+    sslot[e] = st.beam_slot[bcur * Kmax + e];
+    sblk[e] = st.beam_blk[bcur * Kmax + e];
+  }
+  int myK = 0;
+  if (tid < B) {
+    myK = st.beam_K[bcur + tid];
+    sK[tid] = myK; slast[tid] = st.beam_last[bcur + tid];
+    ssum[tid] = st.beam_sum[bcur + tid]; sscore[tid] = st.beam_score[bcur + tid];
+  }
+  for (int sl = tid; sl < S; sl += 256) slive[sl] = 0;
+  if (tid < 16) smisc[tid] = 0;
+  const long N = off1 - off0;
+  const long T = (long)st.tau * N;
+  if (step >= T) return;
+  const long frame = off0 + (step % N);
+  // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
+  if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
+    const int v = lane < nb ? myK + 1 : 0;
+    int excl = 0, total = 0;
+    for (int j2 = 0; j2 < nb; ++j2) {
+      const int kj = __builtin_amdgcn_readlane(v, j2);
+      if (lane > j2) excl += kj;
+      total += kj;
+    }
+    if (lane < nb) sbase[lane] = excl;
+    if (lane == 0) sbase[nb] = total;
+  }
+  __syncthreads();  // (1) tables staged
+  TSTAMP(0);
+  for (int e = tid; e < nb * Kmax; e += 256) {
+    const int b = e / Kmax, c = e - b * Kmax;
+    if (c < sK[b]) slive[sslot[e]] = 1;
+  }
+  __syncthreads();  // (2) live flags
+  for (int base = 0; base < S; base += 256) {  // compaction: ballot per wave, one LDS atomic per wave
+    const int sl = base + tid;
+    const bool lv = sl < S && slive[sl] != 0;
+    const unsigned long long mask = __ballot(lv);
+    int wbase = 0;
+    if (lane == 0 && mask) wbase = atomicAdd(&smisc[0], __popcll(mask));
+    wbase = __shfl(wbase, 0, 64);
+    if (lv) slivelist[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = sl;
+  }
+  __syncthreads();  // (3) live list
+  TSTAMP(1);
+  const int nlive = smisc[0];
+  const int C = sbase[nb];
+
+  // ---- round trip 2: this thread's candidate (prior-table entries), then the cluster states
+  const float mse_new = st.mse0[frame];
+  int my_b = 0, my_c = 0;
+  double my_lb = 0.0, my_ld = 0.0;
+  if (tid < C) {
+    for (int j2 = 1; j2 < nb; ++j2) my_b += tid >= sbase[j2];  // independent LDS reads
+    my_c = tid - sbase[my_b];
+    my_ld = st.logden[ssum[my_b]];
+    if (my_c < sK[my_b] && my_c != slast[my_b]) my_lb = st.logblk[sblk[my_b * Kmax + my_c]];
+  }
+  const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  const float* xrow = st.x + (size_t)frame * m.Dp;
+  {
+    const int grp = tid >> 4, p = tid & 15;
+    if (m.Dp <= 256) {  // one 256-float chunk: keep the frame in registers, two slots per lane in flight
+      f32x4 xv[4], wv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = 4 * (p + 16 * k);
+        const bool in = d < m.Dp;
+        xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        wv[k] = in ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      for (int i0 = 0; i0 < nlive; i0 += 32) {
+        int sl[2]; bool act[2]; int cnt[2]; f32x4 mv[2][4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int i = i0 + 16 * h2 + grp;
+          act[h2] = i < nlive;
+          sl[h2] = slivelist[act[h2] ? i : 0];
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float* mean = pmean + (size_t)sl[h2] * m.Dp;
+          cnt[h2] = (p == 0) ? st.pool_cnt[(size_t)u * S + sl[h2]] : 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = 4 * (p + 16 * k);
+            mv[h2][k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = 4 * (p + 16 * k);
+            if (d < m.Dp) {
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[h2][k][e2], xv[k][e2], wv[k][e2]);
+            }
+          }
+          const float d0 = mv[h2][0][0] - xv[0][0];
+          float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+          if (p == 0 && act[h2]) { smse[sl[h2]] = uis_mse_finish(t, d0 * d0, m.D); scnt[sl[h2]] = cnt[h2]; }
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < nlive; i0 += 16) {
+        const int i = i0 + grp;
+        const bool act = i < nlive;
+        const int sl = slivelist[act ? i : 0];
+        const float* mean = pmean + (size_t)sl * m.Dp;
+        const int cnt = (p == 0) ? st.pool_cnt[(size_t)u * S + sl] : 0;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float first_sq = 0.0f;
+        for (int q = 0; q < m.Dp; q += 256) {
+          f32x4 mv[4], xv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = q + 4 * (p + 16 * k);
+            const bool in = d < m.Dp;
+            mv[k] = in ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = q + 4 * (p + 16 * k);
+            if (d < m.Dp) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
+              if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
+            }
+          }
+        }
+        float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+        if (p == 0 && act) { smse[sl] = uis_mse_finish(t, first_sq, m.D); scnt[sl] = cnt; }
+      }
+    }
+  }
+  __syncthreads();  // (4) MSE per live slot
+  TSTAMP(2);
+
+  // ---- candidate score (thread i = candidate i), finite count
+  float my_sc = 0.0f;
+  unsigned long long my_key = ~0ull;
+  if (tid < C) {
+    float mse; double prior;
+    if (my_c < sK[my_b]) {
+      mse = smse[sslot[my_b * Kmax + my_c]];
+      prior = (my_c == slast[my_b]) ? m.lp_stay : (m.lp_sw + my_lb) - my_ld;
+    } else {
+      mse = mse_new;
+      prior = (m.lp_sw + m.l_alpha) - my_ld;
+    }
+    my_sc = sscore[my_b] + uis_step_loss(mse, prior);
+    if (uis_isfinite(my_sc)) my_key = ((unsigned long long)uis_score_key(my_sc) << 32) | (unsigned)tid;
+  }
+  skey[tid] = my_key;
+  {
+    const unsigned long long fm = __ballot(my_key != ~0ull);
+    if (lane == 0 && fm) atomicAdd(&smisc[1], __popcll(fm));
+  }
+  __syncthreads();  // (5) keys
+  TSTAMP(3);
+  const int nfin = smisc[1];
+  const int keep = nfin < B ? nfin : B;
+  if (my_key != ~0ull) {  // rank by counting; keys are unique; two keys per 16-byte LDS read
+    int rank = 0;
+    const int C2 = (C + 1) & ~1;  // skey[C] (if C is odd) holds ~0ull or a non-candidate's ~0ull
+#pragma unroll 8
+    for (int j2 = 0; j2 < C2; j2 += 2) {
+      const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(skey + j2);
+      rank += (kk.x < my_key) + (kk.y < my_key);
+    }
+    if (rank < keep) { swin[rank] = tid; swscore[rank] = my_sc; }
+  }
+  __syncthreads();  // (6) winners
+  if (wave != 0) return;
+  TSTAMP(4);
+
+  // ---- wave 0: lane r = winner r
+  const bool nodedup = (st.flags & 1u) != 0;
+  const int r = lane;
+  const bool isw = r < keep;
+  int wb = 0, wc = 0, src = -2, Kb = 0;
+  if (isw) {
+    const int i = swin[r];
+    for (int j2 = 1; j2 < nb; ++j2) wb += i >= sbase[j2];
+    wc = i - sbase[wb];
+    Kb = sK[wb];
+    src = wc < Kb ? sslot[wb * Kmax + wc] : -1;
+  }
+  int lead = r;
+  if (!nodedup) {
+    for (int r2 = keep - 1; r2 >= 0; --r2) {  // lowest rank with the same source wins
+      const int s2 = __builtin_amdgcn_readlane(src, r2);
+      if (isw && s2 == src) lead = r2;
+    }
+  }
+  const bool is_lead = isw && lead == r;
+  const unsigned long long lmask = __ballot(is_lead);
+  const int nlead = __popcll(lmask);
+  const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
+  // reserve the rnn rows now; the returned position is needed only at the very end
+  int row_base = 0;
+  if (lane == 0) row_base = atomicAdd(&st.nrows[par], nlead);
+  // the ord-th free slot (not referenced by the current beam), in slot order
+  int dst = -1;
+  {
+    int want = is_lead ? ord : -1;
+    for (int base = 0; base < S; base += 64) {
+      const int sl = base + lane;
+      const unsigned long long fm = __ballot(sl < S && slive[sl] == 0);
+      const int cnt = __popcll(fm);
+      if (want >= 0 && want < cnt) { dst = base + nth_set_bit(fm, want); want = -1; }
+      else if (want >= cnt) want -= cnt;
+      if (__ballot(want >= 0) == 0ull) break;
+    }
+  }
+  {
+    const int dl = __shfl(dst, lead, 64);
+    if (isw && !is_lead) dst = dl;
+  }
+  TSTAMP(5);
+  // next beam tables: entry (r, c2) for every winner, 64 entries per round
+  for (int e0 = 0; e0 < keep * Kmax; e0 += 64) {
+    const int e = e0 + lane;
+    const int rr = e / Kmax, c2 = e - rr * Kmax;
+    // fetch winner rr's facts from its lane
+    const int rb = __shfl(wb, rr, 64), rc = __shfl(wc, rr, 64), rK = __shfl(Kb, rr, 64), rd = __shfl(dst, rr, 64);
+    if (e < keep * Kmax) {
+      const bool is_new = rc == rK;
+      const int Knew = rK + (is_new ? 1 : 0);
+      if (c2 < Knew) {
+        int slot, blk;
+        if (c2 == rc) { slot = rd; blk = is_new ? 1 : sblk[rb * Kmax + rc] + (rc != slast[rb] ? 1 : 0); }
+        else { slot = sslot[rb * Kmax + c2]; blk = sblk[rb * Kmax + c2]; }
+        st.beam_slot[(bnxt + rr) * Kmax + c2] = slot;
+        st.beam_blk[(bnxt + rr) * Kmax + c2] = blk;
+      }
+    }
+  }
+  int Kmaxseen = 0;
+  if (isw) {
+    const bool is_new = wc == Kb;
+    int Knew = Kb + (is_new ? 1 : 0);
+    if (Knew > Kmax) { Knew = Kmax; st.overflow[u] = 1; }
+    Kmaxseen = Knew;
+    st.beam_K[bnxt + r] = Knew;
+    st.beam_last[bnxt + r] = wc;
+    st.beam_sum[bnxt + r] = ssum[wb] + ((is_new || wc != slast[wb]) ? 1 : 0);
+    st.beam_score[bnxt + r] = swscore[r];
+    st.bp[((size_t)st.tau * st.off[u] + step) * B + r] = ((unsigned)wb << 16) | (unsigned)wc;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(Kmaxseen, off, 64); Kmaxseen = o > Kmaxseen ? o : Kmaxseen; }
+  TSTAMP(6);
+  row_base = __shfl(row_base, 0, 64);
+  if (is_lead) {
+    const int nprev = src >= 0 ? scnt[src] : 0;
+    st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
+    RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
+    st.rows[row_base + ord] = rr;
+  }
+  if (lane == 0) {
+    st.beam_n[(size_t)nxt * U + u] = keep;
+    st.utt_step[u] = step + 1;
+    atomicMax(&st.counters[3], (unsigned long long)Kmaxseen);
+    atomicAdd(&st.counters[0], (unsigned long long)nlead);
+    atomicAdd(&st.counters[1], (unsigned long long)keep);
+    atomicAdd(&st.counters[2], (unsigned long long)C);
+  }
+  TSTAMP(7);
 }
 
 // ------------------------------------------------------------------ window
