@@ -551,8 +551,9 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipStreamSynchronize(h->stream));
 #if defined(UIS_SELECT_TIMING)
   {
-    unsigned long long tc[24];
+    unsigned long long tc[48];
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+
     const double launches = (double)maxT * U;
     fprintf(stderr, "[select timing] cycles per workgroup-launch:");
     for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, (double)tc[16 + k] / launches);

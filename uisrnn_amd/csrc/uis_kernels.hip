@@ -426,7 +426,7 @@ __global__ void k_init_state(DecodeState st) {
   int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u == 0) { st.nrows[0] = 0; st.nrows[1] = 0; for (int i = 0; i < 4; ++i) st.counters[i] = 0ull;  // this group's
 #if defined(UIS_SELECT_TIMING)
-    for (int i = 16; i < 24; ++i) st.counters[i] = 0ull;
+    for (int i = 16; i < 48; ++i) st.counters[i] = 0ull;
 #endif
   }
   if (u >= st.U) return;
