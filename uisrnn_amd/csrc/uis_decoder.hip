@@ -279,7 +279,7 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
     if (st.L == 1 && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
       LAUNCH(UIS_K_SELECT, k_select_fast, dim3(st.U), dim3(256), (size_t)fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).total, m, st, par);
     else if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
-    else LAUNCH(UIS_K_EXPAND, k_window, dim3(st.U), dim3(256), 0, m, st, par);
+    else LAUNCH(UIS_K_EXPAND, k_window, dim3(st.U), dim3(256), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
     int rc = launch_rnn(h, lch, st, par, max_rows);
     if (rc) return rc;
   }
@@ -684,6 +684,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, std::vector<float>(m.Dp, 0.0f), &m.m0))) return bail(rc);
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return bail(fail(UIS_ERR_HIP, std::string("hipFuncSetAttribute(k_select): ") + hipGetErrorString(e)));
   if ((rc = bootstrap_constants(h, d_hinit))) return bail(rc);

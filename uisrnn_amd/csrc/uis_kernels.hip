@@ -1171,7 +1171,10 @@ __device__ __forceinline__ HypView level_view(const DecodeState& st, int u, int 
 }
 
 struct WindowScratch {
-  size_t live, livelist, mse, cnt, first, cbase, key, cscore, win, src, dst, lead, ord, freelist, total;
+  // hot block (LDS when it fits, see window_lds_bytes): flags, per-slot values, candidate keys
+  size_t live, livelist, mse, cnt, first, cbase, key, hot_total;
+  // cold block (always global scratch)
+  size_t cscore, win, src, dst, lead, ord, freelist, total;
 };
 __host__ __device__ inline WindowScratch window_scratch_layout(int S, int NC, int Kmax, int B) {
   WindowScratch w;
@@ -1186,7 +1189,8 @@ __host__ __device__ inline WindowScratch window_scratch_layout(int S, int NC, in
   w.cnt = take((size_t)S * 4);
   w.first = take((size_t)(S + 1) * 4);
   w.cbase = take((in_cap + 1) * 4);
-  w.key = take(C * 8);
+  w.key = take((C + 2) * 8);
+  w.hot_total = o;
   w.cscore = take(C * 4);
   w.win = take(out_cap * 4);
   w.src = take(out_cap * 4);
@@ -1196,6 +1200,10 @@ __host__ __device__ inline WindowScratch window_scratch_layout(int S, int NC, in
   w.freelist = take(out_cap * 4);
   w.total = o;
   return w;
+}
+// dynamic LDS to launch k_window with: the hot block if it fits next to the static LDS, else 0
+__host__ __device__ inline size_t window_lds_bytes(const WindowScratch& w) {
+  return w.hot_total <= 150 * 1024 ? w.hot_total : 0;
 }
 
 // Exclusive prefix sums over i in [0, n) of val(i) by 256 threads (contiguous chunk each);
@@ -1249,13 +1257,15 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
 
   unsigned char* scr = st.scratch + (size_t)u * st.scratch_stride;
   const WindowScratch W = window_scratch_layout(S, NC, Kmax, B);
-  int* live = reinterpret_cast<int*>(scr + W.live);
-  int* livelist = reinterpret_cast<int*>(scr + W.livelist);
-  float* mse = reinterpret_cast<float*>(scr + W.mse);
-  int* cntv = reinterpret_cast<int*>(scr + W.cnt);
-  int* first = reinterpret_cast<int*>(scr + W.first);
-  int* cbase = reinterpret_cast<int*>(scr + W.cbase);
-  unsigned long long* key = reinterpret_cast<unsigned long long*>(scr + W.key);
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+  unsigned char* hot = window_lds_bytes(W) ? wlds : scr;  // same choice as the host's launch
+  int* live = reinterpret_cast<int*>(hot + W.live);
+  int* livelist = reinterpret_cast<int*>(hot + W.livelist);
+  float* mse = reinterpret_cast<float*>(hot + W.mse);
+  int* cntv = reinterpret_cast<int*>(hot + W.cnt);
+  int* first = reinterpret_cast<int*>(hot + W.first);
+  int* cbase = reinterpret_cast<int*>(hot + W.cbase);
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(hot + W.key);
   float* cscore = reinterpret_cast<float*>(scr + W.cscore);
   int* winv = reinterpret_cast<int*>(scr + W.win);
   int* srcv = reinterpret_cast<int*>(scr + W.src);
@@ -1350,11 +1360,18 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   } else {
     const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
     keep = nfin < B ? nfin : B;
+    if (tid == 0) key[C] = ~0ull;  // pad to an even count for the paired reads below
+    __syncthreads();
+    const int C2 = (C + 1) & ~1;
     for (int i = tid; i < C; i += 256) {
       const unsigned long long k = key[i];
       if (k == ~0ull) continue;
-      int rank = 0;
-      for (int j2 = 0; j2 < C && rank < keep; ++j2) rank += key[j2] < k;
+      int rank = 0;  // no early exit: the reads are independent and pipeline
+#pragma unroll 8
+      for (int j2 = 0; j2 < C2; j2 += 2) {
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(key + j2);
+        rank += (kk.x < k) + (kk.y < k);
+      }
       if (rank < keep) winv[rank] = i;
     }
   }
