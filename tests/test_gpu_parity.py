@@ -193,3 +193,53 @@ def test_cluster_cap_is_reported(oracle_lib):
   assert out['overflow'].tolist() == [1, 0]
   # the utterance that fit is still decoded correctly
   assert np.array_equal(out['labels'][offsets[1]:offsets[2]], ref['labels'][1])
+
+
+def test_python_surface_and_demo_flow(tmp_path, oracle_lib):
+  """uisrnn_amd.UISRNN.predict / parallel_predict / save+load, as the reference's demo uses them."""
+  import subprocess
+  import sys as _sys
+  import uisrnn_amd
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  model.load_params(params)
+  seqs, _ = synth.make_utterances(9000, 5, [60, 33, 1, 80, 45], 256)
+  ref = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=4)
+  got = model.predict(seqs, inference_args)
+  assert got == [l.tolist() for l in ref['labels']]
+  assert model.predict(seqs[0], inference_args) == ref['labels'][0].tolist()
+  assert uisrnn_amd.parallel_predict(model, seqs, inference_args, num_processes=2) == got
+  assert all(isinstance(v, int) for v in got[0])
+  # checkpoint round trip in the reference's format keeps the predictions
+  path = str(tmp_path / 'm.uisrnn')
+  model.save(path)
+  other = uisrnn_amd.UISRNN(model_args)
+  other.load(path)
+  assert other.predict(seqs, inference_args) == got
+  # look_ahead through the Python surface, and the cluster-cap retry of the host layer
+  inference_args.look_ahead = 2
+  inference_args.beam_size = 5
+  ref2 = oracle_lib.decode(params, seqs, 5, 2, 2, n_threads=4)
+  assert model.predict(seqs, inference_args) == [l.tolist() for l in ref2['labels']]
+  inference_args.look_ahead = 1
+  inference_args.beam_size = 8
+  inference_args.max_clusters = 2  # forces the retry loop (the data needs more)
+  many, rng = _many_cluster_case()
+  mseqs = [rng.standard_normal((30, 64)), rng.standard_normal((12, 64))]
+  margs, _, _ = uisrnn_amd.parse_arguments(['--observation_dim', '64', '--rnn_hidden_size', '48'])
+  mmodel = uisrnn_amd.UISRNN(margs)
+  mmodel.load_params(many)
+  refm = oracle_lib.decode(many, mseqs, 8, 1, 2)
+  assert mmodel.predict(mseqs, inference_args) == [l.tolist() for l in refm['labels']]
+  # the demo script end to end
+  out = subprocess.run([_sys.executable, 'demo.py', '--test_data', str(tmp_path / 'none.npz')],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+  assert out.returncode != 0  # missing file is an error, not a silent fallback
+  root = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+  out = subprocess.run([_sys.executable, __import__('os').path.join(root, 'demo.py')],
+                       capture_output=True, text=True, cwd=root)
+  assert out.returncode == 0, out.stderr[-2000:]
+  assert 'averaged accuracy' in out.stdout
+  acc = float(out.stdout.split('averaged accuracy')[1].split(',')[0])
+  assert acc > 0.97
