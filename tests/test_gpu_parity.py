@@ -243,3 +243,28 @@ def test_python_surface_and_demo_flow(tmp_path, oracle_lib):
   assert 'averaged accuracy' in out.stdout
   acc = float(out.stdout.split('averaged accuracy')[1].split(',')[0])
   assert acc > 0.97
+
+
+def test_non_finite_input_empties_the_beam(oracle_lib):
+  """A nan frame makes every candidate non-finite: no survivors, labels -1, like the oracle;
+  the Python surface raises IndexError like the reference's beam_set[0] (uisrnn.py:561)."""
+  import uisrnn_amd
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(9500, 3, [20, 15, 10], 256)
+  seqs[1][7, 3] = np.nan
+  ref = oracle_lib.decode(params, seqs, 10, 1, 2)
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  out = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True)
+  assert out['status'] == 0
+  for u in range(3):
+    assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u])
+  assert (ref['labels'][1] == -1).all() and np.isinf(out['scores'][1])
+  assert (ref['labels'][0] >= 0).all()
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  with pytest.raises(IndexError):
+    model.predict(seqs, inference_args)
+  assert model.predict([seqs[0], seqs[2]], inference_args) == [
+      ref['labels'][0].tolist(), ref['labels'][2].tolist()]

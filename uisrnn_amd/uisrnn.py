@@ -158,7 +158,14 @@ class UISRNN:
         if out['overflow'][k]:
           still.append(u)
         else:
-          results[u] = out['labels'][sub_off[k]:sub_off[k + 1]].tolist()
+          labels = out['labels'][sub_off[k]:sub_off[k + 1]]
+          if labels.size and labels[0] < 0:
+            # every candidate of some step was non-finite (nan/inf in the input or the
+            # weights): the reference ends up indexing an empty beam_set
+            # (uisrnn/uisrnn.py:561) and raises the same exception type
+            raise IndexError('list index out of range (the beam became empty: '
+                             'non-finite scores in utterance {})'.format(u))
+          results[u] = labels.tolist()
       pending = still
       if pending:
         # a surviving hypothesis opened more clusters than the device tables
