@@ -59,17 +59,17 @@ __device__ __forceinline__ float wave_weighted_mse(const float* __restrict__ mea
 //   fullk_tile   -- input projection (tens of thousands of rows, once per decode): one
 //                   wave walks all segments of its tile and combines on the fly.
 
-#define UIS_STAGE 4   // k-blocks fetched per pipeline stage
+#define UIS_STAGE 4   // most k-blocks fetched per pipeline stage
 
 // NA A-operand streams (feature tiles x gates) against NB B-operand streams (row tiles):
-// NA*NB accumulators, NA+NB 16-byte loads per lane per k-block.
-template <int NA, int NB>
-__device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NA], const f32x4* const (&bp)[NB], int kb0,
-                                             int kb1, f32x4 (&acc)[NB][NA]) {
-  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
-    f32x4 a[UIS_STAGE][NA], b[UIS_STAGE][NB];
+// NA*NB accumulators, NA+NB 16-byte loads per lane per k-block, STG k-blocks per stage.
+template <int NA, int NB, int STG>
+__device__ __forceinline__ void chain_blocks_stg(const f32x4* const (&wp)[NA], const f32x4* const (&bp)[NB], int kb0,
+                                                 int kb1, f32x4 (&acc)[NB][NA]) {
+  for (int kb = kb0; kb < kb1; kb += STG) {
+    f32x4 a[STG][NA], b[STG][NB];
 #pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
+    for (int u = 0; u < STG; ++u) {
       const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
 #pragma unroll
       for (int g = 0; g < NA; ++g) a[u][g] = wp[g][(size_t)kk * 64];
@@ -77,7 +77,7 @@ __device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NA], const
       for (int r = 0; r < NB; ++r) b[u][r] = bp[r][(size_t)kk * 4];
     }
 #pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
+    for (int u = 0; u < STG; ++u) {
       if (kb + u < kb1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -91,6 +91,16 @@ __device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NA], const
       }
     }
   }
+}
+// stage depth = the segment length when that is short (a deeper stage would only re-request
+// the segment's last block): 1, 2 or UIS_STAGE k-blocks
+template <int NA, int NB>
+__device__ __forceinline__ void chain_blocks(const f32x4* const (&wp)[NA], const f32x4* const (&bp)[NB], int kb0,
+                                             int kb1, f32x4 (&acc)[NB][NA]) {
+  const int len = kb1 - kb0;
+  if (len >= UIS_STAGE) chain_blocks_stg<NA, NB, UIS_STAGE>(wp, bp, kb0, kb1, acc);
+  else if (len >= 2) chain_blocks_stg<NA, NB, 2>(wp, bp, kb0, kb1, acc);
+  else chain_blocks_stg<NA, NB, 1>(wp, bp, kb0, kb1, acc);
 }
 
 // Split-K schedule of a workgroup tile of R row tiles x C feature tiles x NG gates.
@@ -128,7 +138,7 @@ __device__ __forceinline__ void splitk_tile(const float* __restrict__ Wt, int ti
         acc[r][c * NG + g] =
             w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + c * 16 + 4 * q)
                    : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  if (kb0 < kb1) chain_blocks<NA, R>(wp, bp, kb0, kb1, acc);
+  if (kb0 < kb1) chain_blocks_stg<NA, R, UIS_STAGE>(wp, bp, kb0, kb1, acc);  // per-step kernels: one code path
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
