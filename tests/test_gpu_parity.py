@@ -268,3 +268,22 @@ def test_non_finite_input_empties_the_beam(oracle_lib):
     model.predict(seqs, inference_args)
   assert model.predict([seqs[0], seqs[2]], inference_args) == [
       ref['labels'][0].tolist(), ref['labels'][2].tolist()]
+
+
+def test_parallel_predict_worker_threads(oracle_lib):
+  """parallel_predict shards over devices with one handle + thread each; on a one-GPU box the
+  same device index is given twice/thrice to exercise exactly that path."""
+  import uisrnn_amd
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  model.load_params(params)
+  lengths = [70, 12, 45, 90, 33, 5, 64, 51, 20]
+  seqs, _ = synth.make_utterances(9700, len(lengths), lengths, 256)
+  want = [l.tolist() for l in oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=4)['labels']]
+  assert uisrnn_amd.parallel_predict(model, seqs, inference_args) == want
+  assert uisrnn_amd.parallel_predict(model, seqs, inference_args, devices=[0, 0]) == want
+  assert uisrnn_amd.parallel_predict(model, seqs, inference_args, devices=[0, 0, 0]) == want
+  assert uisrnn_amd.parallel_predict(model, seqs[:1], inference_args, devices=[0, 0]) == want[:1]
+  with pytest.raises(ValueError):
+    uisrnn_amd.parallel_predict(model, [np.zeros((3, 5))], inference_args, devices=[0, 0])

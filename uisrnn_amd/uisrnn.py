@@ -39,6 +39,7 @@ class UISRNN:
     self.device_index = int(getattr(args, 'device_index', 0))
     self.verbosity = getattr(args, 'verbosity', 3)
     self._decoder = None
+    self._extra_decoders = {}
     self.last_stats = None
 
   # ---- the attributes callers of the reference read and write
@@ -83,6 +84,9 @@ class UISRNN:
     if self._decoder is not None:
       self._decoder.close()
     self._decoder = None
+    for dec in self._extra_decoders.values():
+      dec.close()
+    self._extra_decoders = {}
 
   def load_params(self, params):
     """Install a parameter dict (uisrnn_amd.weights) wholesale."""
@@ -106,13 +110,17 @@ class UISRNN:
 
   fit_concatenated = fit
 
-  def _get_decoder(self):
+  def _get_decoder(self, device=None):
     if self.params['transition_bias'] is None:
       # the reference fails in np.log(None) (uisrnn.py:416-418)
       raise TypeError('transition_bias is None: fit or load a model first.')
-    if self._decoder is None:
-      self._decoder = _capi.Decoder(self.params, self.device_index)
-    return self._decoder
+    if device is None or device == self.device_index:
+      if self._decoder is None:
+        self._decoder = _capi.Decoder(self.params, self.device_index)
+      return self._decoder
+    if device not in self._extra_decoders:  # one handle per further GPU (parallel_predict)
+      self._extra_decoders[device] = _capi.Decoder(self.params, device)
+    return self._extra_decoders[device]
 
   def _check_sequence(self, test_sequence):
     """The reference's argument checks, uisrnn/uisrnn.py:510-521."""
@@ -125,9 +133,9 @@ class UISRNN:
       raise ValueError('test_sequence does not match the dimension specified '
                        'by args.observation_dim.')
 
-  def _decode_batch(self, sequences, args, flags=0):
+  def _decode_batch(self, sequences, args, flags=0, device=None):
     """Decode a list of validated sequences in one lock-step batch."""
-    decoder = self._get_decoder()
+    decoder = self._get_decoder(device)
     n_utt = len(sequences)
     lens = np.array([s.shape[0] for s in sequences], dtype=np.int64)
     offsets = np.zeros(n_utt + 1, dtype=np.int64)
@@ -215,17 +223,88 @@ class UISRNN:
     raise TypeError('test_sequences should be either a list or numpy array.')
 
 
-def parallel_predict(model, test_sequences, args, num_processes=4):
+def parallel_predict(model, test_sequences, args, num_processes=4, devices=None):
   """Drop-in for uisrnn.parallel_predict (uisrnn/uisrnn.py:593-623).
 
-  The reference maps utterances over a forkserver process pool; here the
-  utterances of the list are already decoded concurrently in one GPU batch,
-  so num_processes is accepted and ignored.
+  The reference maps utterances over a forkserver process pool.  Here the
+  utterances of one GPU are already decoded concurrently in one batch, so the
+  workers are GPUs: the list is sharded (longest-processing-time) over
+  min(num_processes, visible GPUs) devices, one decoder handle and one host
+  thread per device (the C call releases the GIL), no communication during
+  decode.  With one GPU this is model.predict.
+
+  Args:
+    devices: optional explicit list of HIP device indices (repeats allowed --
+      used by the tests to exercise the path on a single-GPU box).
 
   Raises:
     TypeError: test_sequences is not a list.
   """
-  del num_processes
   if not isinstance(test_sequences, list):
     raise TypeError('test_sequences must be a list.')
-  return model.predict(test_sequences, args)
+  for test_sequence in test_sequences:
+    model._check_sequence(test_sequence)  # pylint: disable=protected-access
+  if not test_sequences:
+    return []
+  if devices is None:
+    n_dev = max(_capi.load_library().uis_device_count(), 1)
+    devices = list(range(max(1, min(int(num_processes), n_dev))))
+  if len(devices) == 1:
+    return model._decode_batch(test_sequences, args, device=devices[0])  # pylint: disable=protected-access
+  import threading  # pylint: disable=import-outside-toplevel
+  from uisrnn_amd import distributed  # pylint: disable=import-outside-toplevel
+  shards = distributed.shard_utterances(
+      [s.shape[0] for s in test_sequences], len(devices))
+  # one handle per worker, created up front on this thread (handles are not thread-safe, so
+  # a repeated device index gets its own)
+  workers = [_Worker(model, device, slot) for slot, device in enumerate(devices)]
+  results = [None] * len(test_sequences)
+  errors = []
+
+  def run(worker, shard):
+    try:
+      if shard:
+        out = worker.decode([test_sequences[i] for i in shard], args)
+        for i, labels in zip(shard, out):
+          results[i] = labels
+    except Exception as exc:  # pylint: disable=broad-except
+      errors.append(exc)
+
+  threads = [threading.Thread(target=run, args=(w, sh))
+             for w, sh in zip(workers, shards)]
+  for thread in threads:
+    thread.start()
+  for thread in threads:
+    thread.join()
+  for worker in workers:
+    worker.close()
+  if errors:
+    raise errors[0]
+  return results
+
+
+class _Worker:
+  """One decoder handle for one parallel_predict worker thread."""
+
+  def __init__(self, model, device, slot):
+    self._model = model
+    self._device = device
+    self._own = slot > 0 or device != model.device_index
+    self._decoder = (_capi.Decoder(model.params, device) if self._own
+                     else model._get_decoder(device))  # pylint: disable=protected-access
+
+  def decode(self, sequences, args):
+    if not self._own:
+      return self._model._decode_batch(sequences, args, device=self._device)  # pylint: disable=protected-access
+    shadow = UISRNN.__new__(UISRNN)
+    shadow.observation_dim = self._model.observation_dim
+    shadow.params = self._model.params
+    shadow.device_index = self._device
+    shadow._decoder = self._decoder  # pylint: disable=protected-access
+    shadow._extra_decoders = {}  # pylint: disable=protected-access
+    shadow.last_stats = None
+    return shadow._decode_batch(sequences, args)  # pylint: disable=protected-access
+
+  def close(self):
+    if self._own:
+      self._decoder.close()
