@@ -287,3 +287,24 @@ def test_parallel_predict_worker_threads(oracle_lib):
   assert uisrnn_amd.parallel_predict(model, seqs[:1], inference_args, devices=[0, 0]) == want[:1]
   with pytest.raises(ValueError):
     uisrnn_amd.parallel_predict(model, [np.zeros((3, 5))], inference_args, devices=[0, 0])
+
+
+def test_empty_inputs_through_the_c_abi():
+  """No utterances / only empty utterances: no kernels to run, well-defined outputs."""
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  dec = _capi.Decoder(params)
+  out = dec.decode(np.zeros((0, 256), np.float32), np.zeros(1, np.int64), 10, 1, 2)
+  assert out['status'] == 0 and out['labels'].size == 0 and out['scores'].size == 0
+  out = dec.decode(np.zeros((0, 256), np.float32), np.zeros(4, np.int64), 10, 2, 2,
+                   want_beam_scores=True)
+  assert out['status'] == 0 and out['scores'].tolist() == [0.0, 0.0, 0.0]
+  assert np.isinf(out['beam_scores']).all()
+  # bad options are rejected, not executed
+  lib = _capi.load_library()
+  for kwargs in (dict(beam_size=0), dict(look_ahead=0), dict(test_iteration=0),
+                 dict(beam_size=300), dict(look_ahead=9)):
+    args = dict(beam_size=10, look_ahead=1, test_iteration=2)
+    args.update(kwargs)
+    with pytest.raises(_capi.HipLibraryError):
+      dec.decode(np.zeros((2, 256), np.float32), np.array([0, 2], np.int64), **args)
+  assert lib.uis_last_error()
