@@ -92,7 +92,9 @@ def main():
   n_dev = torch.cuda.device_count()
   if n_dev < 1:
     raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
-  dev_index = local_rank if args.backend == 'nccl' else local_rank % n_dev
+  # one GPU per rank; if the launcher narrowed visibility to one device per process the
+  # modulo maps every rank to its only device
+  dev_index = local_rank % n_dev
   torch.cuda.set_device(dev_index)
   if world > 1:
     import torch.distributed as dist
