@@ -61,6 +61,24 @@ def committed_traffic(kernel):
     return None
 
 
+def reference_rate_note():
+  """The reference's own predict() rate, recorded when the fixtures were generated.
+
+  google/uis-rnn cannot run on the GPU box (it is not shipped there); its wall time per
+  utterance was stored in tests/golden/tracker_d256.npz by make_golden.py (dev container,
+  8 vCPU Xeon, one torch thread, same model family and beam as this benchmark).
+  """
+  try:
+    data = np.load(os.path.join(ROOT, 'tests', 'golden', 'tracker_d256.npz'))
+    frames = sum(len(data['run0_labels_{}'.format(u)]) for u in range(int(data['n_utt'])))
+    secs = float(np.sum(data['run0_secs']))
+    return ('google/uis-rnn predict(): {:.1f} frames/s ({} frames in {:.0f} s, beam 10, D=256, '
+            'H=512, 1 thread, dev container; tests/golden/tracker_d256.npz)'.format(
+                frames / secs, frames, secs))
+  except Exception:  # pylint: disable=broad-except
+    return None
+
+
 def parse():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -207,6 +225,7 @@ def main():
           for u in range(sample))
       cpu = {'value': round(sample * n_frames / cpu_s, 2), 'unit': 'frames/s',
              'cores': threads, 'kind': 'port',
+             'reference_python': reference_rate_note(),
              'sample': '{} of the {} utterances, {} threads, {:.1f}s; GPU labels '
                        'identical: {}'.format(sample, n_utt, threads, cpu_s, parity)}
     result = {

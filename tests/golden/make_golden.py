@@ -293,6 +293,16 @@ def case_tracker(uisrnn):
   return params, seqs, runs, False
 
 
+@case('tracker_d256_long')
+def case_tracker_long(uisrnn):
+  """One 250-frame D=256/H=512 utterance (500 decode steps): near-ties accumulate with length."""
+  from uisrnn_amd import synth  # pylint: disable=import-outside-toplevel
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(1100, 1, [250], 256)
+  runs = [dict(beam_size=10, look_ahead=1, test_iteration=2)]
+  return params, seqs, runs, False
+
+
 def main():
   uisrnn = import_reference()
   import torch  # pylint: disable=import-outside-toplevel

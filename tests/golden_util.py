@@ -10,6 +10,8 @@ SEEDED_CASES = {
     # regenerated from seeds, see make_golden.py case_tracker
     'tracker_d256': dict(dim=256, hid=512, depth=1, seed=0, utt_seed=1000,
                          lengths=[40, 60, 25]),
+    'tracker_d256_long': dict(dim=256, hid=512, depth=1, seed=0, utt_seed=1100,
+                              lengths=[250]),
 }
 
 

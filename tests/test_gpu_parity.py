@@ -74,7 +74,7 @@ def test_rnn_step_bit_exact(oracle_lib):
 
 
 @pytest.mark.parametrize('name', ['tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
-                                  'd20_h24_depth3'])
+                                  'd20_h24_depth3', 'tracker_d256_long'])
 def test_golden_cases_bit_exact(name, oracle_lib):
   case = golden_util.load_case(name)
   dec = _capi.Decoder(case['params'])
