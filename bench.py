@@ -204,6 +204,8 @@ def main():
         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         'traffic': committed_traffic('k_dense_gru'),
         'avg_launch_us': round(avg_us, 3), 'launches': gru_launches,
+        # W_hh once + per row: h in, gi0 in (3H), h' out
+        'algorithmic_bytes_per_launch': int(4 * 3 * hid * hid + rows_algo * 4 * (hid + 3 * hid + hid)),
         'rows_per_launch_algorithmic': round(rows_algo, 1),
         'rows_per_launch_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
         'path_frac_fp32': round(value / world * flop_per_frame / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
