@@ -146,9 +146,9 @@ def test_streams_and_graph_are_bit_identical(oracle_lib):
 
 
 def test_wide_tiles_bit_exact(oracle_lib):
-  """> 1024 rnn rows per step switches the dense kernels to their 2x2 tile shape."""
+  """row capacity > 2048 switches the dense kernels to their 2x2 tile shape."""
   params = synth.tracker_params(256, 512, 1, seed=2)
-  n_utt = 112
+  n_utt = 224
   lengths = [10 + (7 * u) % 23 for u in range(n_utt)]
   seqs, _ = synth.make_utterances(6000, n_utt, lengths, 256)
   _compare(params, seqs, 10, 1, 2, oracle_lib)

@@ -108,3 +108,27 @@ def test_config5_and_config3_shapes(oracle_lib):
   for u in range(2):
     assert np.array_equal(ref['labels'][u], out['labels'][off[u]:off[u + 1]])
   assert np.array_equal(ref['beam_scores'].view(np.uint32), out['beam_scores'].view(np.uint32))
+
+
+def test_handles_release_their_memory():
+  """create / decode / destroy in a loop leaves the device memory where it was."""
+  import gc
+  import torch
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(60_000, 8, 40, 256)
+  torch.cuda.init()
+  dec = _capi.Decoder(params)
+  _decode(dec, seqs, 10, 1, 2)
+  dec.close()
+  gc.collect()
+  torch.cuda.synchronize()
+  free0, _ = torch.cuda.mem_get_info()
+  for _ in range(20):
+    dec = _capi.Decoder(params)
+    _decode(dec, seqs, 10, 1, 2)
+    _decode(dec, seqs, 5, 2, 1)
+    dec.close()
+  gc.collect()
+  torch.cuda.synchronize()
+  free1, _ = torch.cuda.mem_get_info()
+  assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)

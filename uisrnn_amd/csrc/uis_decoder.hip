@@ -59,7 +59,7 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-#define UIS_WIDE_TILE_ROWS 1024   // rnn rows per step above which the 2x2 tiles win
+#define UIS_WIDE_TILE_ROWS 2048   // row capacity (about twice the rows actually run, after dedup) above which the 2x2 tiles win
 #define UIS_MAX_GROUPS 8
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
