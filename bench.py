@@ -94,6 +94,9 @@ def parse():
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to '
                        'exercise the multi-rank path on a box with fewer GPUs than ranks)')
+  ap.add_argument('--force_dist', action='store_true',
+                  help='initialise the process group and run the gather even with one rank '
+                       '(exercises the RCCL calls on a single-GPU box)')
   ap.add_argument('--streams', type=int, default=0,
                   help='utterance groups decoded concurrently (0 = library default)')
   return ap.parse_args()
@@ -114,7 +117,8 @@ def main():
   # modulo maps every rank to its only device
   dev_index = local_rank % n_dev
   torch.cuda.set_device(dev_index)
-  if world > 1:
+  use_dist = world > 1 or args.force_dist
+  if use_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
@@ -141,7 +145,7 @@ def main():
   d_scores = torch.empty(n_utt, dtype=torch.float32, device=dev)
   gather_dev = dev if args.backend == 'nccl' else torch.device('cpu')
   gathered = (torch.empty(world * total_frames, dtype=torch.int32, device=gather_dev)
-              if world > 1 else None)
+              if use_dist else None)
   beam, look, tau = args.beam_size, CONFIG['look_ahead'], CONFIG['test_iteration']
 
   def one_step(flags):
@@ -151,14 +155,14 @@ def main():
                                 n_streams=args.streams)
     if out['status'] != 0:
       raise RuntimeError('decode hit the cluster cap in the benchmark workload')
-    if world > 1:  # the final gather: the only collective of the path (RCCL over xGMI)
+    if use_dist:  # the final gather: the only collective of the path (RCCL over xGMI)
       dist.all_gather_into_tensor(
           gathered, d_labels if args.backend == 'nccl' else d_labels.cpu())
     return out
 
   for _ in range(args.warmup):
     one_step(args.flags)
-  if world > 1:
+  if use_dist:
     dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
@@ -166,10 +170,10 @@ def main():
   for _ in range(args.steps):
     last = one_step(args.flags)
   torch.cuda.synchronize()
-  if world > 1:
+  if use_dist:
     dist.barrier()
   elapsed = time.perf_counter() - t0
-  if world > 1:
+  if use_dist:
     t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -244,7 +248,7 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(result), flush=True)
-  if world > 1:
+  if use_dist:
     dist.barrier()
     dist.destroy_process_group()
   return result
