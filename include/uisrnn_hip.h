@@ -86,6 +86,10 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_GENERIC_SELECT 0x8u /* use the general score/prune kernel even where the
                                     wave-synchronous fast path applies (A/B switch;
                                     results are bit-identical either way)            */
+#define UIS_FLAG_FUSED      0x10u /* experimental: GRU, linear_mean1 and linear_mean2 in ONE
+                                    launch per step (k_rnn_fused: XCD-local workgroup clusters
+                                    with barriers) instead of three; bit-identical results,
+                                    currently slower; depth-1 models only  */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

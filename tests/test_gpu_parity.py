@@ -164,6 +164,28 @@ def test_generic_select_flag_is_bit_identical(oracle_lib):
   _compare(params, seqs, 70, 1, 1, oracle_lib, max_clusters=8)     # beyond it: general kernel
 
 
+def test_fused_rnn_step_is_bit_identical(oracle_lib):
+  """UIS_FLAG_FUSED: k_rnn_fused (one launch per step, XCD-local clusters with barriers) vs the oracle."""
+  params = synth.tracker_params(256, 512, 1, seed=6)
+  lengths = [64, 30, 77, 12, 50, 41, 1, 90, 23, 64, 35, 18]
+  seqs, _ = synth.make_utterances(8800, len(lengths), lengths, 256)
+  dec = _capi.Decoder(params)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_FUSED)
+  _compare(params, seqs, 5, 2, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_FUSED)   # under look_ahead
+  prof = dec.decode(*oracle_lib.pack(seqs), 10, 1, 2,
+                    flags=_capi.UIS_FLAG_PROFILE | _capi.UIS_FLAG_FUSED)['stats']
+  assert prof['kernel_launches']['head1'] == 0 and prof['kernel_launches']['gru'] > 0
+  # more rows than one pass of three row tiles per cluster covers
+  many, _ = synth.make_utterances(8900, 80, 12, 256)
+  _compare(params, many, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_FUSED | _capi.UIS_FLAG_NO_DEDUP)
+  # depth-2 models are refused, not silently run unfused
+  case = golden_util.load_case('toy_d2_depth2')
+  d2 = _capi.Decoder(case['params'])
+  with pytest.raises(_capi.HipLibraryError):
+    d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_FUSED)
+
+
 def _many_cluster_case():
   """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
   from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel

@@ -15,14 +15,17 @@ __device__ __forceinline__ u32 ld_sc1(const u32* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef BARRIER_SLEEP
+#define BARRIER_SLEEP 1
+#endif
 __device__ __forceinline__ bool cluster_barrier(u32* counter, u32 target, u32* abort_flag) {
   __syncthreads();
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
-    while (ld_sc1(counter) < target) {
-      __builtin_amdgcn_s_sleep(1);
+    while (before + 1 < target && ld_sc1(counter) < target) {
+      if (BARRIER_SLEEP) __builtin_amdgcn_s_sleep(BARRIER_SLEEP);
       if (++spins > (1u << 22)) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       if ((spins & 1023u) == 0 && ld_sc1(abort_flag)) break;
     }
@@ -49,11 +52,25 @@ __global__ __launch_bounds__(512) void k_probe(u32* slabs, u32* counters, u32* a
     if (it == 8 && threadIdx.x == 0) t0 = wall_clock64();
     for (int i = threadIdx.x; i < slab_words; i += blockDim.x) my[i] = (u32)(it * 1000003 + rank * 131 + i);
     cluster_barrier(ctr, (u32)(32 * (2 * it + 1)), abort_flag);
+#if defined(READ_X4)
+    // 16-byte sc1 loads (L1 bypassed, L2 served): what an MFMA operand stream would use
+    for (int r = 0; r < 32; ++r) {
+      const u32* other = slabs + ((size_t)cluster * 32 + r) * slab_words;
+      for (int i = threadIdx.x * 4; i < slab_words; i += blockDim.x * 4) {
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v;
+        const u32* pp = other + i;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pp) : "memory");
+        for (int k = 0; k < 4; ++k) err += v[k] != (u32)(it * 1000003 + r * 131 + i + k);
+      }
+    }
+#elif !defined(SKIP_READ)
     for (int r = 0; r < 32; ++r) {
       const u32* other = slabs + ((size_t)cluster * 32 + r) * slab_words;
       for (int i = threadIdx.x; i < slab_words; i += blockDim.x)
         err += ld_sc1(other + i) != (u32)(it * 1000003 + r * 131 + i);
     }
+#endif
     cluster_barrier(ctr, (u32)(32 * (2 * it + 2)), abort_flag);   // nobody overwrites before all have read
     if (ld_sc1(abort_flag)) break;
   }

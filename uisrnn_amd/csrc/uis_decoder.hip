@@ -88,7 +88,7 @@ struct uis_handle {
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
-  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base;
+  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -194,6 +194,10 @@ struct Launcher {
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
   const int mr = (int)max_rows;
+  if (st.cl_counter) {  // UIS_FLAG_FUSED: one launch for GRU + mean head
+    LAUNCH(UIS_K_GRU, k_rnn_fused, dim3(256), dim3(512), 0, m, st, par);
+    return UIS_OK;
+  }
   const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
   for (int l = 0; l < m.depth; ++l) {
     if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
@@ -406,6 +410,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 64 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
+  // opt-in one-launch rnn step: depth-1 models whose exchanged buffers fit 31-bit byte offsets
+  const bool fused = (opts->flags & UIS_FLAG_FUSED) && m.depth == 1 && G == 1 &&
+                     (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
+  if ((opts->flags & UIS_FLAG_FUSED) && !fused)
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_FUSED needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
+  ENSURE(cluster_ctl, (size_t)(8 * 16 + 8 + 8) * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -437,6 +447,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
+  HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, (size_t)(8 * 16 + 8 + 8) * 4, h->stream));
   const float* d_x = d_frames;
   if (m.D != m.Dp && F > 0) {
     const long total = (long)F * m.Dp;
@@ -483,6 +494,11 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.gi_up = h->gi_up.as<float>() + (m.depth > 1 ? (u0 * rows_per_utt + 48 * (size_t)g) * m.G : 0);
     st.a1 = h->a1.as<float>() + (u0 * rows_per_utt + 48 * (size_t)g) * m.Hp;
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
+    if (fused) {
+      st.cl_counter = h->cluster_ctl.as<uint32_t>();
+      st.cl_xcc = st.cl_counter + 8 * 16;
+      st.cl_abort = st.cl_xcc + 8;
+    }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;
       st.lv_n = h->lv_n.as<int32_t>() + 2 * u0;
@@ -615,7 +631,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
                     &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
-                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base};
+                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);

@@ -82,6 +82,11 @@ struct DecodeState {
   float* a1;              // [U*B][Hp]  relu(linear_mean1)
   // counters (device): [0] rnn rows, [1] rnn rows without dedup, [2] candidates, [3] max K
   unsigned long long* counters;
+  // k_rnn_fused: per-XCD-cluster arrival counters [8][16] (zeroed by every step's select),
+  // the XCC id each cluster's rank 0 saw [8], and a sticky abort word
+  uint32_t* cl_counter;
+  uint32_t* cl_xcc;
+  uint32_t* cl_abort;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

@@ -403,6 +403,235 @@ __global__ __launch_bounds__(512) void k_dense_head2(DevModel m, DecodeState st,
   }
 }
 
+// ------------------------------------------------------------ fused rnn step
+//
+// OPT-IN (UIS_FLAG_FUSED): GRU, linear_mean1 and linear_mean2 of one decode step in ONE launch
+// (depth-1 models).  256 workgroups, one per CU; workgroup b belongs to cluster b & 7 -- the XCD
+// it is observed to run on -- with rank b >> 3.  A cluster owns the row tiles {k, k+8, ...} and
+// walks them through the three phases; rank r owns feature tile r (+32, ...) in every phase, so
+// within a phase the weights of a tile are streamed once for up to three row tiles.  Between
+// phases the 32 workgroups of a cluster meet at a barrier (device-scope counter, ~0.9 us
+// measured, tools/probe_cluster.hip) and read what their siblings wrote with sc1 loads (L1
+// bypassed, served by the XCD's L2, which the siblings' plain stores have reached).
+// Placement is CHECKED, not assumed: every workgroup compares its XCC id with the one its
+// cluster's rank 0 published; a mismatch or a barrier time-out sets cl_abort and the host
+// reports an error instead of results.  Arithmetic and its order are those of k_dense_gru /
+// head1 / head2 (bit-identical, tested).
+// Measured (64 utterances): 27.8 us against 24.7 us for the three separate launches -- one fat
+// workgroup per CU serialises load, MFMA and epilogue that many small workgroups overlap -- so
+// it is not the default; it is the correct, tested starting point for a persistent variant.
+
+#define UIS_FUSED_R 3   // row tiles per pass (accumulators: 3 gates x 3 tiles)
+
+__device__ __forceinline__ void cluster_barrier(const DecodeState& st, int cluster, uint32_t target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* ctr = st.cl_counter + cluster * 16;
+    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (before + 1 < target &&
+           __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
+        __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+  __syncthreads();
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 load_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */));
+}
+
+// splitk_tile with the B operand (rows) fetched by sc1 buffer loads: boff[r] = byte offset of
+// this lane's row of row tile r from the buffer base.
+template <int NG, int R>
+__device__ __forceinline__ void splitk_tile_sc1(const float* __restrict__ Wt, int tiles_per_gate, int tile0, int nKb,
+                                                __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[R],
+                                                const float* __restrict__ bias, int gate_stride, float* spart) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = lane >> 4;
+  const int per = uis_kseg_blocks(nKb);
+  const int kb0 = w * per;
+  const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
+  const f32x4* wp[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    wp[g] = reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile0) * nKb) * 64 + lane;
+  f32x4 acc[R][NG];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      acc[r][g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q)
+                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
+    f32x4 a[UIS_STAGE][NG], b[UIS_STAGE][R];
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) a[u][g] = wp[g][(size_t)kk * 64];
+#pragma unroll
+      for (int r = 0; r < R; ++r) b[u][r] = load_sc1(rsrc, boff[r] + (uint32_t)(kk * 64 + q * 16));
+    }
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      if (kb + u < kb1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+              acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][e], b[u][r][e], acc[r][g], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * R + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) =
+          acc[r][g];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void k_rnn_fused(DevModel m, DecodeState st, int par) {
+  constexpr int R = UIS_FUSED_R;
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * R * 3 * 256];
+  const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  const int t = threadIdx.x;
+  const int nrows = st.nrows[par];
+  if (nrows == 0) return;  // the same for every workgroup: nobody waits at a barrier
+  const int nrt = (nrows + 15) >> 4;
+  const int my_tiles = nrt > cluster ? (nrt - cluster + 7) >> 3 : 0;  // row tiles cluster, cluster+8, ...
+  const int nft = m.Hp / 16, nft2 = m.Dp / 16;
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  constexpr int EPT = (R + 1) / 2;
+  const size_t slot_stride = (size_t)m.Hp;  // depth 1
+
+  // ---- phase 1: GRU (B operand: source hidden states, written by earlier launches)
+  for (int ft = rank; ft < nft; ft += 32) {
+    for (int i0 = 0; i0 < my_tiles; i0 += R) {
+      const float* hsrc[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
+        const RnnRow rb = st.rows[row0 + (t & 15)];
+        hsrc[r] = rb.src >= 0 ? hid_ptr(m, st, rb, rb.src, 0) : m.h1;
+      }
+      const int j = ft * 16 + (t & 15);
+      RnnRow re[EPT]; float gir[EPT], giz[EPT], gin[EPT], hprev[EPT]; bool ework[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int r = (t >> 8) + 2 * k;
+        const int erow = (cluster + 8 * (i0 + r)) * 16 + ((t & 255) >> 4);
+        ework[k] = r < R && i0 + r < my_tiles && erow < nrows;
+        gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
+        re[k] = RnnRow{};
+        if (ework[k]) {
+          re[k] = st.rows[erow];
+          const float* gi = st.gi0 + (size_t)re[k].frame * m.G;
+          const float* hs = re[k].src >= 0 ? hid_ptr(m, st, re[k], re[k].src, 0) : m.h1;
+          gir[k] = gi[j]; giz[k] = gi[m.Hp + j]; gin[k] = gi[2 * m.Hp + j]; hprev[k] = hs[j];
+        }
+      }
+      splitk_tile<3, R, 1>(m.whh[0], nft, ft, m.Hp / 16, hsrc, m.bhh[0] + ft * 16, m.Hp, spart);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (!ework[k]) continue;
+        const int r = (t >> 8) + 2 * k, e = t & 255;
+        const float ghr = splitk_combine<R, 3>(spart, r, 0, e);
+        const float ghz = splitk_combine<R, 3>(spart, r, 1, e);
+        const float ghn = splitk_combine<R, 3>(spart, r, 2, e);
+        const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+        st.pool_hid[((size_t)re[k].utt * st.S + re[k].dst) * slot_stride + j] = out;
+      }
+      __syncthreads();  // spart is reused by the next pass
+    }
+  }
+  cluster_barrier(st, cluster, 32u);
+  if (t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+    __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+
+  // ---- phase 2: linear_mean1 + relu (B operand: the hidden states the siblings just wrote)
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  for (int ft = rank; ft < nft; ft += 32) {
+    for (int i0 = 0; i0 < my_tiles; i0 += R) {
+      uint32_t boff[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
+        const RnnRow rb = st.rows[row0 + (t & 15)];
+        boff[r] = (uint32_t)((((size_t)rb.utt * st.S + rb.dst) * slot_stride) * 4);
+      }
+      splitk_tile_sc1<1, R>(m.w1, 0, ft, m.Hp / 16, rs_hid, boff, m.b1 + ft * 16, 0, spart);
+      for (int e = t; e < R * 256; e += 512) {
+        const int r = e >> 8, row = (cluster + 8 * (i0 + r)) * 16 + ((e & 255) >> 4);
+        if (i0 + r < my_tiles && row < nrows) {
+          const float v = splitk_combine<R, 1>(spart, r, 0, e & 255);
+          st.a1[(size_t)row * m.Hp + ft * 16 + (e & 15)] = v > 0.0f ? v : 0.0f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  cluster_barrier(st, cluster, 64u);
+
+  // ---- phase 3: linear_mean2 + running-mean update (B operand: a1 rows of the siblings)
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  for (int ft = rank; ft < nft2; ft += 32) {
+    for (int i0 = 0; i0 < my_tiles; i0 += R) {
+      uint32_t boff[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
+        boff[r] = (uint32_t)(((size_t)(row0 + (t & 15)) * m.Hp) * 4);
+      }
+      const int f = ft * 16 + (t & 15);
+      RnnRow re[EPT]; float old[EPT]; bool ework[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int r = (t >> 8) + 2 * k;
+        const int erow = (cluster + 8 * (i0 + r)) * 16 + ((t & 255) >> 4);
+        ework[k] = r < R && i0 + r < my_tiles && erow < nrows;
+        old[k] = 0.0f;
+        re[k] = RnnRow{};
+        if (ework[k]) {
+          re[k] = st.rows[erow];
+          if (re[k].src >= 0) old[k] = st.pool_mean[((size_t)re[k].utt * st.S + re[k].src) * m.Dp + f];
+        }
+      }
+      splitk_tile_sc1<1, R>(m.w2, 0, ft, m.Hp / 16, rs_a1, boff, m.b2 + ft * 16, 0, spart);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (!ework[k]) continue;
+        const int r = (t >> 8) + 2 * k;
+        float v = splitk_combine<R, 1>(spart, r, 0, t & 255);
+        if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
+        if (f >= m.D) v = 0.0f;
+        st.pool_mean[((size_t)re[k].utt * st.S + re[k].dst) * m.Dp + f] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
 __global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restrict__ x,
                                               float* __restrict__ mse0, long nframes) {
@@ -544,6 +773,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   const int nb = st.beam_n[(size_t)par * U + u];
   // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
   if (u == 0 && tid == 0) st.nrows[nxt] = 0;
+  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
@@ -858,6 +1088,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
   const int nb = st.beam_n[(size_t)par * U + u];
   if (u == 0 && tid == 0) st.nrows[nxt] = 0;
+  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
@@ -1251,6 +1482,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   const int step = st.utt_step[u];
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
+  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;
   const long N = off1 - off0;
   const long T = (long)st.tau * N;
   if (step >= T) return;
