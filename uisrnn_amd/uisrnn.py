@@ -133,9 +133,13 @@ class UISRNN:
       raise ValueError('test_sequence does not match the dimension specified '
                        'by args.observation_dim.')
 
-  def _decode_batch(self, sequences, args, flags=0, device=None):
-    """Decode a list of validated sequences in one lock-step batch."""
-    decoder = self._get_decoder(device)
+  def _decode_batch(self, sequences, args, flags=0, device=None, decoder=None):
+    """Decode a list of validated sequences in one lock-step batch.
+
+    `decoder` (a _capi.Decoder built from self.params) overrides the model's own handle for
+    `device`; parallel_predict passes one per worker thread.
+    """
+    decoder = decoder or self._get_decoder(device)
     n_utt = len(sequences)
     lens = np.array([s.shape[0] for s in sequences], dtype=np.int64)
     offsets = np.zeros(n_utt + 1, dtype=np.int64)
@@ -182,7 +186,7 @@ class UISRNN:
         if cap > _MAX_CLUSTERS_LIMIT:
           raise RuntimeError(
               'more than {} clusters per hypothesis'.format(_MAX_CLUSTERS_LIMIT))
-    self.last_stats = stats
+    self.last_stats = stats  # (parallel_predict: the last worker to finish wins)
     return results
 
   def predict_single(self, test_sequence, args):
@@ -288,22 +292,15 @@ class _Worker:
 
   def __init__(self, model, device, slot):
     self._model = model
-    self._device = device
+    # the first worker on the model's own device shares the model's handle; every other
+    # worker (another device, or the same device again) owns a private one
     self._own = slot > 0 or device != model.device_index
     self._decoder = (_capi.Decoder(model.params, device) if self._own
                      else model._get_decoder(device))  # pylint: disable=protected-access
 
   def decode(self, sequences, args):
-    if not self._own:
-      return self._model._decode_batch(sequences, args, device=self._device)  # pylint: disable=protected-access
-    shadow = UISRNN.__new__(UISRNN)
-    shadow.observation_dim = self._model.observation_dim
-    shadow.params = self._model.params
-    shadow.device_index = self._device
-    shadow._decoder = self._decoder  # pylint: disable=protected-access
-    shadow._extra_decoders = {}  # pylint: disable=protected-access
-    shadow.last_stats = None
-    return shadow._decode_batch(sequences, args)  # pylint: disable=protected-access
+    return self._model._decode_batch(  # pylint: disable=protected-access
+        sequences, args, decoder=self._decoder)
 
   def close(self):
     if self._own:
