@@ -1272,7 +1272,23 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     if (rank < keep) { swin[rank] = tid; swscore[rank] = my_sc; }
   }
   __syncthreads();  // (6) winners
-  if (wave != 0) return;
+  if (wave != 0) {
+    // waves 1-3: copy the UNCHANGED entries of every winner's tables (BeamState(source),
+    // uisrnn.py:66-69) while wave 0 works out the changed ones
+    for (int e = tid - 64; e < keep * Kmax; e += 192) {
+      const int rr = e / Kmax, c2 = e - rr * Kmax;
+      const int i = swin[rr];
+      int rb = 0;
+      for (int j2 = 1; j2 < nb; ++j2) rb += i >= sbase[j2];
+      const int rc = i - sbase[rb];
+      const int Knew = sK[rb] + (rc == sK[rb] ? 1 : 0);
+      if (c2 < Knew && c2 != rc) {
+        st.beam_slot[(bnxt + rr) * Kmax + c2] = sslot[rb * Kmax + c2];
+        st.beam_blk[(bnxt + rr) * Kmax + c2] = sblk[rb * Kmax + c2];
+      }
+    }
+    return;
+  }
   TSTAMP(4);
 
   // ---- wave 0: lane r = winner r
@@ -1319,23 +1335,11 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     if (isw && !is_lead) dst = dl;
   }
   TSTAMP(5);
-  // next beam tables: entry (r, c2) for every winner, 64 entries per round
-  for (int e0 = 0; e0 < keep * Kmax; e0 += 64) {
-    const int e = e0 + lane;
-    const int rr = e / Kmax, c2 = e - rr * Kmax;
-    // fetch winner rr's facts from its lane
-    const int rb = __shfl(wb, rr, 64), rc = __shfl(wc, rr, 64), rK = __shfl(Kb, rr, 64), rd = __shfl(dst, rr, 64);
-    if (e < keep * Kmax) {
-      const bool is_new = rc == rK;
-      const int Knew = rK + (is_new ? 1 : 0);
-      if (c2 < Knew) {
-        int slot, blk;
-        if (c2 == rc) { slot = rd; blk = is_new ? 1 : sblk[rb * Kmax + rc] + (rc != slast[rb] ? 1 : 0); }
-        else { slot = sslot[rb * Kmax + c2]; blk = sblk[rb * Kmax + c2]; }
-        st.beam_slot[(bnxt + rr) * Kmax + c2] = slot;
-        st.beam_blk[(bnxt + rr) * Kmax + c2] = blk;
-      }
-    }
+  // the one changed entry of each winner's tables (the rest is being copied by waves 1-3)
+  if (isw && wc < Kmax) {
+    const bool is_new = wc == Kb;
+    st.beam_slot[(bnxt + r) * Kmax + wc] = dst;
+    st.beam_blk[(bnxt + r) * Kmax + wc] = is_new ? 1 : sblk[wb * Kmax + wc] + (wc != slast[wb] ? 1 : 0);
   }
   int Kmaxseen = 0;
   if (isw) {
