@@ -90,6 +90,11 @@ typedef struct uis_decode_opts {
                                     launch per step (k_rnn_fused: XCD-local workgroup clusters
                                     with barriers) instead of three; bit-identical results,
                                     currently slower; depth-1 models only  */
+#define UIS_FLAG_DATAFLOW   0x20u /* experimental: the workgroups of the GRU, linear_mean1 and
+                                    linear_mean2 kernels in ONE launch per step, consumer
+                                    tiles waiting on per-row-tile arrival counters instead of
+                                    kernel boundaries (k_rnn_dataflow); bit-identical results;
+                                    depth-1 models only                                      */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

@@ -186,6 +186,20 @@ def test_fused_rnn_step_is_bit_identical(oracle_lib):
     d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_FUSED)
 
 
+def test_dataflow_rnn_step_is_bit_identical(oracle_lib):
+  """UIS_FLAG_DATAFLOW: GRU / head1 / head2 workgroups in one launch with per-row-tile counters."""
+  params = synth.tracker_params(256, 512, 1, seed=6)
+  lengths = [64, 30, 77, 12, 50, 41, 1, 90, 23, 64, 35, 18]
+  seqs, _ = synth.make_utterances(8800, len(lengths), lengths, 256)
+  dec = _capi.Decoder(params)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
+  _compare(params, seqs, 5, 2, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
+  many, _ = synth.make_utterances(8900, 80, 12, 256)
+  _compare(params, many, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_DATAFLOW | _capi.UIS_FLAG_NO_DEDUP)
+  for _ in range(3):  # hand-offs are timing dependent: repeat
+    _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
+
+
 def _many_cluster_case():
   """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
   from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel

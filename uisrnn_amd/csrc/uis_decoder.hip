@@ -194,6 +194,11 @@ struct Launcher {
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
   const int mr = (int)max_rows;
+  if (st.tile_ctr) {  // UIS_FLAG_DATAFLOW: the three kernels' workgroups in one launch
+    const int blocks = 2 * step_grid_blocks(mr, m.Hp / 16, 1, 1) + step_grid_blocks(mr, m.Dp / 16, 1, 1);
+    LAUNCH(UIS_K_GRU, k_rnn_dataflow, dim3(blocks), dim3(512), 0, m, st, par);
+    return UIS_OK;
+  }
   if (st.cl_counter) {  // UIS_FLAG_FUSED: one launch for GRU + mean head
     LAUNCH(UIS_K_GRU, k_rnn_fused, dim3(256), dim3(512), 0, m, st, par);
     return UIS_OK;
@@ -415,7 +420,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                      (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
   if ((opts->flags & UIS_FLAG_FUSED) && !fused)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_FUSED needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
-  ENSURE(cluster_ctl, (size_t)(8 * 16 + 8 + 8) * 4);
+  const bool dataflow = (opts->flags & UIS_FLAG_DATAFLOW) && m.depth == 1 && G == 1 &&
+                        (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
+  if ((opts->flags & UIS_FLAG_DATAFLOW) && !dataflow)
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DATAFLOW needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
+  const int tile_cap = (int)((rows_cap + 15) / 16) + 1;
+  ENSURE(cluster_ctl, (size_t)(8 * 16 + 8 + 8 + 2 * tile_cap) * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -447,7 +457,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
-  HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, (size_t)(8 * 16 + 8 + 8) * 4, h->stream));
+  HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, (size_t)(8 * 16 + 8 + 8 + 2 * tile_cap) * 4, h->stream));
   const float* d_x = d_frames;
   if (m.D != m.Dp && F > 0) {
     const long total = (long)F * m.Dp;
@@ -497,7 +507,11 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     if (fused) {
       st.cl_counter = h->cluster_ctl.as<uint32_t>();
       st.cl_xcc = st.cl_counter + 8 * 16;
-      st.cl_abort = st.cl_xcc + 8;
+    }
+    st.cl_abort = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 8;
+    if (dataflow) {
+      st.tile_ctr = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 16;
+      st.tile_cap = tile_cap;
     }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;

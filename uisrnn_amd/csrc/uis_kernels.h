@@ -87,6 +87,10 @@ struct DecodeState {
   uint32_t* cl_counter;
   uint32_t* cl_xcc;
   uint32_t* cl_abort;
+  // k_rnn_dataflow: per-row-tile arrival counters [2][tile_cap] (GRU done, linear_mean1 done),
+  // zeroed by every step's select
+  uint32_t* tile_ctr;
+  int tile_cap;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

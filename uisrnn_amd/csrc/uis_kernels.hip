@@ -232,12 +232,13 @@ struct StepTile {
   bool active;
 };
 template <int RT, int CT>
-__device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft, RnnRow (&lane_row)[RT]) {
+__device__ __forceinline__ StepTile step_tile(const DecodeState& st, int par, int nft, RnnRow (&lane_row)[RT],
+                                              int block = -1) {
   StepTile t;
   const int max_rt = (st.max_rows + 15) >> 4;
   const int n_rg = (max_rt + RT - 1) / RT, n_fg = (nft + CT - 1) / CT;
   int rg, fg;
-  dense_block_map(blockIdx.x, n_rg, n_fg, rg, fg);
+  dense_block_map(block < 0 ? (int)blockIdx.x : block, n_rg, n_fg, rg, fg);
   t.rt0 = rg * RT; t.ft0 = fg * CT;
   t.row0 = t.rt0 * 16;
   const bool in_grid = rg < n_rg && fg < n_fg;
@@ -632,6 +633,183 @@ __global__ __launch_bounds__(512) void k_rnn_fused(DevModel m, DecodeState st, i
   }
 }
 
+// --------------------------------------------------------- dataflow rnn step
+//
+// OPT-IN (UIS_FLAG_DATAFLOW): the workgroups of k_dense_gru<1>, k_dense_head1<1,1> and
+// k_dense_head2<1> in ONE launch (depth-1 models).  Same tiles, same arithmetic; instead of a
+// kernel boundary a consumer tile waits for its row tile's producers on an arrival counter:
+// GRU tile (rt, *) -> counter[rt] -> head1 tile (rt, *) -> counter[cap + rt] -> head2 tile (rt, *).
+// Producers and consumers of a row tile sit on different XCDs, so what they exchange is stored
+// write-through (sc0 sc1) and loaded with sc0 sc1 (the reader's L2 may hold a stale copy of a
+// re-used slot), flags are device-scope atomics, and every storing wave drains its stores
+// before the flag (MI355X_MICROARCH.md, hand-off forms).  GRU workgroups come first in the
+// grid, then head1, then head2, so producers are dispatched before their consumers; a consumer
+// that waits too long sets cl_abort instead of hanging.
+
+__device__ __forceinline__ void st_wt(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 17 /* sc0 sc1 */);
+}
+__device__ __forceinline__ f32x4 ld_sys(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 17 /* sc0 sc1 */));
+}
+
+__device__ __forceinline__ void tile_signal(uint32_t* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tile_wait(const DecodeState& st, uint32_t* ctr, uint32_t target) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(12);
+      if (++spins > (1u << 19)) { __hip_atomic_store(st.cl_abort, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+  __syncthreads();
+}
+
+// splitk_tile<1, 1, 1> with the B operand loaded sc0 sc1
+__device__ __forceinline__ void splitk_tile_sys(const float* __restrict__ Wt, int tile0, int nKb,
+                                                __amdgpu_buffer_rsrc_t rsrc, uint32_t boff,
+                                                const float* __restrict__ bias, float* spart) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = lane >> 4;
+  const int per = uis_kseg_blocks(nKb);
+  const int kb0 = w * per;
+  const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wt) + ((size_t)tile0 * nKb) * 64 + lane;
+  f32x4 acc = w == 0 ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
+    f32x4 a[UIS_STAGE], b[UIS_STAGE];
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
+      a[u] = wp[(size_t)kk * 64];
+      b[u] = ld_sys(rsrc, boff + (uint32_t)(kk * 64 + q * 16));
+    }
+#pragma unroll
+    for (int u = 0; u < UIS_STAGE; ++u) {
+      if (kb + u < kb1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(spart + (size_t)w * 256 + (lane & 15) * 16 + 4 * q) = acc;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(512) void k_rnn_dataflow(DevModel m, DecodeState st, int par) {
+  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 3 * 256];
+  const int nft = m.Hp / 16, nft2 = m.Dp / 16;
+  const int g1 = step_grid_blocks(st.max_rows, nft, 1, 1);   // GRU workgroups, then head1, then head2
+  const int t = threadIdx.x;
+  const int bid = blockIdx.x;
+  const size_t slot_stride = (size_t)m.Hp;  // depth 1
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  RnnRow rb[1];
+  if (bid < g1) {
+    // ---- GRU tile (as k_dense_gru<1>, layer 0); h' stored write-through, then counter[rt]
+    const StepTile tl = step_tile<1, 1>(st, par, nft, rb, bid);
+    if (!tl.active) return;
+    // epilogue by 64 threads: thread t owns row t>>2, units 4*(t&3) .. +3 (one 16-byte store)
+    const int j = tl.ft0 * 16 + 4 * (t & 3);
+    const int erow = tl.row0 + (t >> 2);
+    const bool ework = t < 64 && erow < tl.nrows;
+    RnnRow re{};
+    f32x4 gir{}, giz{}, gin{}, hprev{};
+    if (ework) {
+      re = st.rows[erow];
+      const float* gi = st.gi0 + (size_t)re.frame * m.G;
+      const float* hs = re.src >= 0 ? hid_ptr(m, st, re, re.src, 0) : m.h1;
+      gir = *reinterpret_cast<const f32x4*>(gi + j);
+      giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j);
+      gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j);
+      hprev = *reinterpret_cast<const f32x4*>(hs + j);
+    }
+    const float* hsrc[1] = {rb[0].src >= 0 ? hid_ptr(m, st, rb[0], rb[0].src, 0) : m.h1};
+    splitk_tile<3, 1, 1>(m.whh[0], nft, tl.ft0, m.Hp / 16, hsrc, m.bhh[0] + tl.ft0 * 16, m.Hp, spart);
+    if (ework) {
+      const int el = (t >> 2) * 16 + 4 * (t & 3);
+      f32x4 gh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        gh[g] = *reinterpret_cast<const f32x4*>(spart + (size_t)g * 256 + el);
+#pragma unroll
+        for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) {
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(spart + (size_t)(sgm * 3 + g) * 256 + el);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gh[g][i] = gh[g][i] + p4[i];
+        }
+      }
+      f32x4 out;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        out[i] = j + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), rs_hid,
+                                             (uint32_t)((((size_t)re.utt * st.S + re.dst) * slot_stride + j) * 4), 0, 17);
+    }
+    tile_signal(st.tile_ctr + tl.rt0);
+    return;
+  }
+  if (bid < 2 * g1) {
+    // ---- head1 tile: waits for the nft GRU tiles of its row tile
+    const StepTile tl = step_tile<1, 1>(st, par, nft, rb, bid - g1);
+    if (!tl.active) return;
+    tile_wait(st, st.tile_ctr + tl.rt0, (uint32_t)nft);
+    const uint32_t boff = (uint32_t)((((size_t)rb[0].utt * st.S + rb[0].dst) * slot_stride) * 4);
+    splitk_tile_sys(m.w1, tl.ft0, m.Hp / 16, rs_hid, boff, m.b1 + tl.ft0 * 16, spart);
+    if (t < 64) {
+      const int row = tl.row0 + (t >> 2);
+      if (row < tl.nrows) {
+        const int el = (t >> 2) * 16 + 4 * (t & 3);
+        f32x4 v = *reinterpret_cast<const f32x4*>(spart + el);
+#pragma unroll
+        for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) {
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(spart + (size_t)sgm * 256 + el);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] + p4[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_a1,
+                                               (uint32_t)(((size_t)row * m.Hp + tl.ft0 * 16 + 4 * (t & 3)) * 4), 0, 17);
+      }
+    }
+    tile_signal(st.tile_ctr + st.tile_cap + tl.rt0);
+    return;
+  }
+  {
+    // ---- head2 tile: waits for the nft head1 tiles of its row tile; its output is read by the
+    // next launch (plain stores)
+    const StepTile tl = step_tile<1, 1>(st, par, nft2, rb, bid - 2 * g1);
+    if (!tl.active) return;
+    const int erow = tl.row0 + ((t & 255) >> 4);
+    const bool ework = t < 256 && erow < tl.nrows;
+    const int f = tl.ft0 * 16 + (t & 15);
+    RnnRow re{};
+    float old = 0.0f;
+    if (ework) {
+      re = st.rows[erow];
+      if (re.src >= 0) old = st.pool_mean[((size_t)re.utt * st.S + re.src) * m.Dp + f];
+    }
+    tile_wait(st, st.tile_ctr + st.tile_cap + tl.rt0, (uint32_t)nft);
+    const uint32_t boff = (uint32_t)(((size_t)(tl.row0 + (t & 15)) * m.Hp) * 4);
+    splitk_tile_sys(m.w2, tl.ft0, m.Hp / 16, rs_a1, boff, m.b2 + tl.ft0 * 16, spart);
+    if (ework) {
+      float v = splitk_combine<1, 1>(spart, 0, 0, t);
+      if (re.src >= 0) v = uis_mean_update(old, v, re.nprev);
+      if (f >= m.D) v = 0.0f;
+      st.pool_mean[((size_t)re.utt * st.S + re.dst) * m.Dp + f] = v;
+    }
+  }
+}
+
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
 __global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restrict__ x,
                                               float* __restrict__ mse0, long nframes) {
@@ -774,6 +952,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
   if (u == 0 && tid == 0) st.nrows[nxt] = 0;
   if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
+  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
@@ -1089,6 +1268,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   const int nb = st.beam_n[(size_t)par * U + u];
   if (u == 0 && tid == 0) st.nrows[nxt] = 0;
   if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
+  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
@@ -1487,6 +1667,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
   if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;
+  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;
   const long N = off1 - off0;
   const long T = (long)st.tau * N;
   if (step >= T) return;
