@@ -200,6 +200,28 @@ def test_dataflow_rnn_step_is_bit_identical(oracle_lib):
     _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
 
 
+def test_resident_decode_is_bit_identical(oracle_lib):
+  """UIS_FLAG_RESIDENT: the whole decode in one launch (k_decode_resident) vs the oracle."""
+  params = synth.tracker_params(256, 512, 1, seed=6)
+  lengths = [64, 30, 77, 12, 50, 41, 1, 90, 23, 64, 35, 18]      # ragged, not a multiple of 8
+  seqs, _ = synth.make_utterances(8800, len(lengths), lengths, 256)
+  dec = _capi.Decoder(params)
+  for _ in range(3):  # in-launch hand-offs are timing dependent: repeat
+    _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_RESIDENT)
+  _compare(params, seqs[:3], 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_RESIDENT)  # idle XCDs
+  _compare(params, seqs[:1], 4, 1, 3, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_RESIDENT)
+  many, _ = synth.make_utterances(8900, 300, 12, 256)   # several utterances per workgroup, > 3 row tiles per XCD
+  _compare(params, many, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_NO_DEDUP)
+  _compare(params, many, 20, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)
+  wide = synth.tracker_params(512, 512, 1, seed=7)      # observation_dim 512: one linear_mean2 tile per rank
+  seqs5, _ = synth.make_utterances(8950, 20, 25, 512)
+  _compare(wide, seqs5, 8, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)   # up to 26 clusters per hypothesis
+  with pytest.raises(_capi.HipLibraryError):  # hidden size 24: not supported, must be refused
+    case = golden_util.load_case('d20_h24_depth3')
+    d2 = _capi.Decoder(case['params'])
+    d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
+
+
 def _many_cluster_case():
   """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
   from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel

@@ -84,6 +84,7 @@ struct uis_handle {
   DevModel m{};
   std::vector<void*> model_allocs;
   double alpha = 1.0;
+  int n_cu = 0;  // compute units of the device
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
@@ -398,7 +399,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(logblk, (size_t)(maxT + 2) * 8);
   ENSURE(logden, (size_t)(maxT + 2) * 8);
   ENSURE(pool_mean, (size_t)U * S * m.Dp * 4);
-  ENSURE(pool_hid, (size_t)U * S * m.depth * m.Hp * 4);
+  ENSURE(pool_hid, ((size_t)U * S + 1) * m.depth * m.Hp * 4);  // + the slot k_decode_resident keeps h1 in
   ENSURE(pool_cnt, (size_t)U * S * 4);
   ENSURE(beam_n, (size_t)2 * U * 4);
   ENSURE(beam_K, (size_t)2 * U * B * 4);
@@ -408,7 +409,9 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
   ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
   ENSURE(bp, L == 1 ? (size_t)std::max<int64_t>(tau * F, 1) * B * 4 : 16);
-  const long rows_cap = max_rows + 48L * G;  // every group's last row tile may run past its rows
+  // k_decode_resident: one row region per XCD, a multiple of 16 rows
+  const int rx_stride = (int)(((((long)U + 7) / 8) * B + 15) / 16 * 16);
+  const long rows_cap = std::max(max_rows + 48L * G, 8L * rx_stride);  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
   ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : 16);
@@ -424,8 +427,18 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                         (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
   if ((opts->flags & UIS_FLAG_DATAFLOW) && !dataflow)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DATAFLOW needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
+  // the whole decode in one launch with register-resident weights (k_decode_resident)
+  const bool resident_ok = L == 1 && m.depth == 1 && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) && G == 1 &&
+                           select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && h->n_cu == 256 &&
+                           ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
+                           resident_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024;
+  const bool resident = (opts->flags & UIS_FLAG_RESIDENT) != 0 && resident_ok;
+  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 512 (padded), "
+                                     "observation_dim 256 or 512 (padded), one stream and a 256-CU device");
   const int tile_cap = (int)((rows_cap + 15) / 16) + 1;
-  ENSURE(cluster_ctl, (size_t)(8 * 16 + 8 + 8 + 2 * tile_cap) * 4);
+  const size_t ctl_words = (size_t)8 * 16 + 8 + 8 + 2 * tile_cap + 2 * 8 * 32;
+  ENSURE(cluster_ctl, ctl_words * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -457,7 +470,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
-  HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, (size_t)(8 * 16 + 8 + 8 + 2 * tile_cap) * 4, h->stream));
+  HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, ctl_words * 4, h->stream));
   const float* d_x = d_frames;
   if (m.D != m.Dp && F > 0) {
     const long total = (long)F * m.Dp;
@@ -513,6 +526,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       st.tile_ctr = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 16;
       st.tile_cap = tile_cap;
     }
+    if (resident) {
+      st.cl_xcc = h->cluster_ctl.as<uint32_t>() + 8 * 16;
+      st.rx_stride = rx_stride;
+      st.rx_nrows = h->cluster_ctl.as<int32_t>() + 8 * 16 + 16 + 2 * tile_cap;
+      st.rx_bar = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 16 + 2 * tile_cap + 8 * 32;
+    }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;
       st.lv_n = h->lv_n.as<int32_t>() + 2 * u0;
@@ -539,7 +558,20 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     Launcher& lch = gl;  // LAUNCH() below targets this group's stream
     HIPCHK(hipStreamWaitEvent(sg, h->ev_pre, 0));
     LAUNCH(-1, k_init_state, dim3((gp.U + 255) / 256), dim3(256), 0, gp.st);
-    if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
+    if (resident) {
+      // h1 into the extra slot, then ONE launch for every step of every utterance
+      HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
+      const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Dp, B, Kmax, S), 96 * 1024);  // one workgroup per CU
+      if (m.Dp == 256) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<256>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(UIS_K_GRU, k_decode_resident<256>, dim3(256), dim3(512), shmem, m, gp.st);
+      } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<512>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(UIS_K_GRU, k_decode_resident<512>, dim3(256), dim3(512), shmem, m, gp.st);
+      }
+    } else if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
       GraphCache& gc = h->gcache[g];
       const bool same = gc.exec && gc.lds == (size_t)lds.total && memcmp(&gc.st, &gp.st, sizeof(DecodeState)) == 0;
       if (!same) {
@@ -578,7 +610,12 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->last_overflow.data(), h->overflow.p, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), h->beam_scores_out.p, (size_t)U * B * 4, hipMemcpyDeviceToHost,
                         h->stream));
+  uint32_t abort_word = 0;
+  HIPCHK(hipMemcpyAsync(&abort_word, h->cluster_ctl.as<uint32_t>() + 8 * 16 + 8, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (abort_word)
+    return fail(UIS_ERR_HIP, abort_word == 2 ? "workgroup cluster not placed on one XCD (in-launch barrier path)"
+                                             : "in-launch barrier timed out");
 #if defined(UIS_SELECT_TIMING)
   {
     unsigned long long tc[48];
@@ -680,6 +717,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   uis_handle* h = new uis_handle();
   h->device = device;
   h->alpha = d->crp_alpha;
+  if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->n_cu = 0;
   auto bail = [&](int rc) { uis_destroy(h); return rc; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(UIS_ERR_HIP, "stream create failed"));
   if (hipEventCreate(&h->ev_begin) != hipSuccess || hipEventCreate(&h->ev_end) != hipSuccess ||

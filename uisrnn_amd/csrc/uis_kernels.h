@@ -91,6 +91,13 @@ struct DecodeState {
   // zeroed by every step's select
   uint32_t* tile_ctr;
   int tile_cap;
+  // k_decode_resident: XCD c (the 32 workgroups observed on it) owns utterances c, c+8, ... and
+  // rows [c*rx_stride, (c+1)*rx_stride) of `rows` / `a1`; its row counters (by step parity) are
+  // rx_nrows[c*32 + par], its barrier counter rx_bar[c*32].  pool_hid carries one extra slot
+  // [U*S] holding h1 so that every GRU source row lives in one buffer.
+  int rx_stride;
+  int32_t* rx_nrows;
+  uint32_t* rx_bar;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

@@ -1233,9 +1233,21 @@ __host__ __device__ inline bool select_fast_ok(int B, int Kmax, int S) {
   return B <= 64 && B * (Kmax + 1) <= 256 && S <= 1024;
 }
 
-__global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st, int par) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Where a select appends its rnn rows: the launch-per-step path has one list per utterance
+// group, the resident decode one per XCD.
+struct RowSink {
+  RnnRow* rows;
+  int32_t* count;
+};
+
+// The select of utterance u by an NT-thread workgroup.  RES: called from the resident decode --
+// the cluster means were written by other CUs of this XCD inside the same launch, so they are
+// read with sc1 loads; everything else a select reads is either immutable or was written by
+// this very workgroup.  The caller provides the workgroup barrier that ends the call.
+template <int NT, bool RES>
+__device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
+                                                 unsigned char* smem_raw, RowSink sink) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if defined(UIS_SELECT_TIMING)
   unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
@@ -1266,11 +1278,8 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   const int step = st.utt_step[u];
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
   const int nb = st.beam_n[(size_t)par * U + u];
-  if (u == 0 && tid == 0) st.nrows[nxt] = 0;
-  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
-  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
-  for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
-  for (int e = tid; e < B * Kmax; e += 256) {
+  for (int i = tid; i < m.Dp; i += NT) swgt[i] = m.wgt[i];
+  for (int e = tid; e < B * Kmax; e += NT) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
     sblk[e] = st.beam_blk[bcur * Kmax + e];
   }
@@ -1280,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     sK[tid] = myK; slast[tid] = st.beam_last[bcur + tid];
     ssum[tid] = st.beam_sum[bcur + tid]; sscore[tid] = st.beam_score[bcur + tid];
   }
-  for (int sl = tid; sl < S; sl += 256) slive[sl] = 0;
+  for (int sl = tid; sl < S; sl += NT) slive[sl] = 0;
   if (tid < 16) smisc[tid] = 0;
   const long N = off1 - off0;
   const long T = (long)st.tau * N;
@@ -1300,12 +1309,12 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   }
   __syncthreads();  // (1) tables staged
   TSTAMP(0);
-  for (int e = tid; e < nb * Kmax; e += 256) {
+  for (int e = tid; e < nb * Kmax; e += NT) {
     const int b = e / Kmax, c = e - b * Kmax;
     if (c < sK[b]) slive[sslot[e]] = 1;
   }
   __syncthreads();  // (2) live flags
-  for (int base = 0; base < S; base += 256) {  // compaction: ballot per wave, one LDS atomic per wave
+  for (int base = 0; base < S; base += NT) {  // compaction: ballot per wave, one LDS atomic per wave
     const int sl = base + tid;
     const bool lv = sl < S && slive[sl] != 0;
     const unsigned long long mask = __ballot(lv);
@@ -1330,6 +1339,8 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     if (my_c < sK[my_b] && my_c != slast[my_b]) my_lb = st.logblk[sblk[my_b * Kmax + my_c]];
   }
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   const float* xrow = st.x + (size_t)frame * m.Dp;
   {
     const int grp = tid >> 4, p = tid & 15;
@@ -1342,11 +1353,11 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
         xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         wv[k] = in ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      for (int i0 = 0; i0 < nlive; i0 += 32) {
+      for (int i0 = 0; i0 < nlive; i0 += NT / 8) {
         int sl[2]; bool act[2]; int cnt[2]; f32x4 mv[2][4];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-          const int i = i0 + 16 * h2 + grp;
+          const int i = i0 + (NT / 16) * h2 + grp;
           act[h2] = i < nlive;
           sl[h2] = slivelist[act[h2] ? i : 0];
         }
@@ -1357,7 +1368,9 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
-            mv[h2][k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (d >= m.Dp) mv[h2][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            else if (RES) mv[h2][k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl[h2]) * m.Dp + d) * 4));
+            else mv[h2][k] = *reinterpret_cast<const f32x4*>(mean + d);
           }
         }
 #pragma unroll
@@ -1379,7 +1392,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
         }
       }
     } else {
-      for (int i0 = 0; i0 < nlive; i0 += 16) {
+      for (int i0 = 0; i0 < nlive; i0 += NT / 16) {
         const int i = i0 + grp;
         const bool act = i < nlive;
         const int sl = slivelist[act ? i : 0];
@@ -1393,7 +1406,9 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
             const bool in = d < m.Dp;
-            mv[k] = in ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (!in) mv[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            else if (RES) mv[k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl) * m.Dp + d) * 4));
+            else mv[k] = *reinterpret_cast<const f32x4*>(mean + d);
             xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
 #pragma unroll
@@ -1432,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     my_sc = sscore[my_b] + uis_step_loss(mse, prior);
     if (uis_isfinite(my_sc)) my_key = ((unsigned long long)uis_score_key(my_sc) << 32) | (unsigned)tid;
   }
-  skey[tid] = my_key;
+  if (tid < 256) skey[tid] = my_key;  // candidates are threads 0..C-1, C <= 256
   {
     const unsigned long long fm = __ballot(my_key != ~0ull);
     if (lane == 0 && fm) atomicAdd(&smisc[1], __popcll(fm));
@@ -1455,7 +1470,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   if (wave != 0) {
     // waves 1-3: copy the UNCHANGED entries of every winner's tables (BeamState(source),
     // uisrnn.py:66-69) while wave 0 works out the changed ones
-    for (int e = tid - 64; e < keep * Kmax; e += 192) {
+    for (int e = tid - 64; e < keep * Kmax; e += NT - 64) {
       const int rr = e / Kmax, c2 = e - rr * Kmax;
       const int i = swin[rr];
       int rb = 0;
@@ -1496,7 +1511,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
   // reserve the rnn rows now; the returned position is needed only at the very end
   int row_base = 0;
-  if (lane == 0) row_base = atomicAdd(&st.nrows[par], nlead);
+  if (lane == 0) row_base = atomicAdd(sink.count, nlead);
   // the ord-th free slot (not referenced by the current beam), in slot order
   int dst = -1;
   {
@@ -1541,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     const int nprev = src >= 0 ? scnt[src] : 0;
     st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
     RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
-    st.rows[row_base + ord] = rr;
+    sink.rows[row_base + ord] = rr;
   }
   if (lane == 0) {
     st.beam_n[(size_t)nxt * U + u] = keep;
@@ -1552,6 +1567,293 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
     atomicAdd(&st.counters[2], (unsigned long long)C);
   }
   TSTAMP(7);
+}
+
+__global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
+  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
+  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
+  select_fast_body<256, false>(m, st, par, u, smem_raw, RowSink{st.rows, st.nrows + par});
+}
+
+// ------------------------------------------------------------ resident decode
+//
+// The whole lock-step decode (look_ahead 1, depth 1, rnn_hidden_size 512) in ONE launch with the
+// weights held in registers.  256 workgroups of 512 threads, one per CU; workgroup b belongs to
+// cluster b & 7 -- the XCD it is observed to run on, checked against HW_REG_XCC_ID -- with rank
+// b >> 3.  A cluster decodes utterances c, c+8, ... on its own: nothing is exchanged between
+// XCDs, so everything the 32 workgroups of a cluster hand each other stays in that XCD's L2
+// (plain stores, `s_waitcnt vmcnt(0)`, a cluster barrier, sc1 loads that bypass the reader's
+// L1; tools/probe_cluster.hip: 0 stale reads, ~0.9 us per barrier).
+//
+// Rank r owns feature tile r of the GRU and of linear_mean1 and (with 16 linear_mean2 tiles,
+// two ranks each taking every other row tile) tile r/2 of linear_mean2; wave w owns K segment
+// w, exactly as in splitk_tile, so a thread keeps 48 + 16 + 16 weight registers for the whole
+// decode and a step streams only the hypotheses' rows.  Per step: the ranks run the selects of
+// their utterances (select_fast_body), barrier, GRU, barrier, linear_mean1, barrier,
+// linear_mean2 + running mean, barrier.  Arithmetic and its order are those of the per-step
+// kernels (bit-identical, tested).  A barrier that does not complete sets cl_abort instead of
+// hanging; the host then reports an error.
+
+#define UIS_RES_RC 3   // row tiles per pass
+
+__device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, uint32_t target, int* s_abort) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* ctr = st.rx_bar + cluster * 32;
+    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int bad = 0;
+    while (before + 1 < target && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
+        __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = 1;
+        break;
+      }
+      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        bad = 1;
+        break;
+      }
+    }
+    *s_abort = bad;
+  }
+  __syncthreads();
+  return *s_abort != 0;
+}
+
+struct RowHead { int utt, src, dst, nprev; };
+__device__ __forceinline__ RowHead load_row_head(__amdgpu_buffer_rsrc_t rs_rows, int row) {
+  const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)row * 32u, 0, 16);
+  return RowHead{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+}
+__device__ __forceinline__ long load_row_frame(__amdgpu_buffer_rsrc_t rs_rows, int row) {
+  const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)row * 32u + 16u, 0, 16);
+  return (long)(((unsigned long long)d[1] << 32) | d[0]);
+}
+__device__ __forceinline__ float load_f32_sc1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// RC row tiles x NG gates of one feature tile, weights from registers: wave w walks its K
+// segment (PER k-blocks), partial tiles to LDS [UIS_KSPLIT][RC][NG][256], ends with the barrier.
+template <int NG, int PER, int RC>
+__device__ __forceinline__ void resident_tile(const f32x4 (&wr)[NG][PER], const f32x4 (&bias)[NG],
+                                              __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], float* spart) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4;
+  f32x4 b[RC][PER];
+#pragma unroll
+  for (int r = 0; r < RC; ++r)
+#pragma unroll
+    for (int kb = 0; kb < PER; ++kb) b[r][kb] = load_sc1(rsrc, boff[r] + (uint32_t)((w * PER + kb) * 64 + q * 16));
+  f32x4 acc[RC][NG];
+#pragma unroll
+  for (int r = 0; r < RC; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[r][g] = w == 0 ? bias[g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int kb = 0; kb < PER; ++kb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < RC; ++r)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][kb][e], b[r][kb][e], acc[r][g], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < RC; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
+  __syncthreads();
+}
+
+__host__ __device__ inline size_t resident_lds_bytes(int Dp, int B, int Kmax, int S) {
+  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4 + 64;
+}
+
+template <int DP>
+__global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState st) {
+  constexpr int HP = 512, NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
+  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
+  constexpr int EPT = (RC + 1) / 2;
+  static_assert(SH2 == 1 || SH2 == 2, "observation_dim 256 or 512 (padded)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  const int U = st.U, S = st.S;
+  const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
+  float* spart = reinterpret_cast<float*>(smem_raw + ((L.total + 255) & ~255));
+  int* s_ctl = reinterpret_cast<int*>(spart + UIS_KSPLIT * RC * 3 * 256);  // [0] abort  [1] steps
+
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = 0;
+    s_ctl[1] = 0;
+  }
+  __syncthreads();
+  {  // decode steps of this cluster = the longest of its utterances
+    int myT = 0;
+    for (int i = t; cluster + 8 * i < U; i += 512) {
+      const int u = cluster + 8 * i;
+      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      myT = T > myT ? (int)T : myT;
+    }
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+
+  // ---- this thread's share of the weights, for the whole decode
+  f32x4 wg[3][PER], w1r[1][PER], w2r[1][PER], bg[3], b1v[1], b2v[1];
+  const int ft2 = rank / SH2, tpar2 = rank % SH2;
+#pragma unroll
+  for (int kb = 0; kb < PER; ++kb) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      wg[g][kb] = reinterpret_cast<const f32x4*>(m.whh[0])[((size_t)(g * 32 + rank) * NKB + w * PER + kb) * 64 + lane];
+    w1r[0][kb] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)rank * NKB + w * PER + kb) * 64 + lane];
+    w2r[0][kb] = reinterpret_cast<const f32x4*>(m.w2)[((size_t)ft2 * NKB + w * PER + kb) * 64 + lane];
+  }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bg[g] = *reinterpret_cast<const f32x4*>(m.bhh[0] + (size_t)g * HP + rank * 16 + 4 * q);
+  b1v[0] = *reinterpret_cast<const f32x4*>(m.b1 + rank * 16 + 4 * q);
+  b2v[0] = *reinterpret_cast<const f32x4*>(m.b2 + ft2 * 16 + 4 * q);
+
+  const __amdgpu_buffer_rsrc_t rs_rows =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const int rbase = cluster * st.rx_stride;
+  const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
+  RowSink sink{st.rows + rbase, nullptr};
+  uint32_t bar = 0;
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int par = s & 1;
+    sink.count = st.rx_nrows + cluster * 32 + par;
+    for (int i = rank; cluster + 8 * i < U; i += 32) {
+      select_fast_body<512, true>(m, st, par, cluster + 8 * i, smem_raw, sink);
+      __syncthreads();
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+    const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rank == 0 && t == 0)
+      __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nrt = (nrows + 15) >> 4;
+
+    // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
+    for (int i0 = 0; i0 < nrt; i0 += RC) {
+      uint32_t boff[RC];
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const int tile = i0 + r < nrt ? i0 + r : i0;
+        const RowHead rh = load_row_head(rs_rows, rbase + 16 * tile + (t & 15));
+        boff[r] = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
+      }
+      const int j = rank * 16 + (t & 15);
+      RowHead re[EPT];
+      float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
+      bool ework[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int r = (t >> 8) + 2 * k;
+        const int lrow = 16 * (i0 + r) + ((t & 255) >> 4);
+        ework[k] = r < RC && lrow < nrows;
+        gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
+        re[k] = RowHead{0, 0, 0, 0};
+        if (ework[k]) {
+          re[k] = load_row_head(rs_rows, rbase + lrow);
+          const long frame = load_row_frame(rs_rows, rbase + lrow);
+          const float* gi = st.gi0 + (size_t)frame * m.G;
+          gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
+          hprev[k] = re[k].src >= 0 ? load_f32_sc1(st.pool_hid + ((size_t)re[k].utt * S + re[k].src) * HP + j) : m.h1[j];
+        }
+      }
+      resident_tile<3, PER, RC>(wg, bg, rs_hid, boff, spart);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (!ework[k]) continue;
+        const int r = (t >> 8) + 2 * k, e = t & 255;
+        const float ghr = splitk_combine<RC, 3>(spart, r, 0, e);
+        const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
+        const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
+        const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+        st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
+      }
+      __syncthreads();  // spart is reused by the next pass
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+
+    // ---- linear_mean1 + relu -> a1
+    for (int i0 = 0; i0 < nrt; i0 += RC) {
+      uint32_t boff[RC];
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const int tile = i0 + r < nrt ? i0 + r : i0;
+        const RowHead rh = load_row_head(rs_rows, rbase + 16 * tile + (t & 15));
+        boff[r] = (uint32_t)((((size_t)rh.utt * S + rh.dst) * HP) * 4);
+      }
+      resident_tile<1, PER, RC>(w1r, b1v, rs_hid, boff, spart);
+      for (int e = t; e < RC * 256; e += 512) {
+        const int r = e >> 8, lrow = 16 * (i0 + r) + ((e & 255) >> 4);
+        if (lrow < nrows) {
+          const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
+          st.a1[(size_t)(rbase + lrow) * HP + rank * 16 + (e & 15)] = v > 0.0f ? v : 0.0f;
+        }
+      }
+      __syncthreads();
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+
+    // ---- linear_mean2 + running mean -> dst slot; this rank's row tiles are tpar2, tpar2 + SH2, ...
+    const int my_tiles = nrt > tpar2 ? (nrt - tpar2 + SH2 - 1) / SH2 : 0;
+    for (int i0 = 0; i0 < my_tiles; i0 += RC) {
+      uint32_t boff[RC];
+#pragma unroll
+      for (int r = 0; r < RC; ++r) {
+        const int tile = tpar2 + SH2 * (i0 + r < my_tiles ? i0 + r : i0);
+        boff[r] = (uint32_t)(((size_t)(rbase + 16 * tile + (t & 15)) * HP) * 4);
+      }
+      const int f = ft2 * 16 + (t & 15);
+      RowHead re[EPT];
+      float old[EPT];
+      bool ework[EPT];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const int r = (t >> 8) + 2 * k;
+        const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
+        ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
+        old[k] = 0.0f;
+        re[k] = RowHead{0, 0, 0, 0};
+        if (ework[k]) {
+          re[k] = load_row_head(rs_rows, rbase + lrow);
+          if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
+        }
+      }
+      resident_tile<1, PER, RC>(w2r, b2v, rs_a1, boff, spart);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (!ework[k]) continue;
+        const int r = (t >> 8) + 2 * k;
+        float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
+        if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
+        if (f >= m.D) v = 0.0f;
+        st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+      }
+      __syncthreads();
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+  }
 }
 
 // ------------------------------------------------------------------ window
