@@ -414,7 +414,8 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const long rows_cap = std::max(max_rows + 48L * G, 8L * rx_stride);  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
-  ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : 16);
+  // depth 1: k_decode_resident's h' staging buffer
+  ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : (size_t)rows_cap * m.Hp * 4);
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 64 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
@@ -625,6 +626,21 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     fprintf(stderr, "[select timing] cycles per workgroup-launch:");
     for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, (double)tc[16 + k] / launches);
     fprintf(stderr, "\n");
+  }
+#endif
+#if defined(UIS_RESIDENT_TIMING)
+  if (resident) {
+    unsigned long long tc[80];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    static const char* names[8] = {"select", "barA", "gru", "barB", "head1", "barC", "head2", "barD"};
+    for (int wg = 0; wg < 2; ++wg) {
+      fprintf(stderr, "[resident timing] workgroup %3d, us per step:", wg ? 248 : 0);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.2f", names[k], (double)tc[(wg ? 64 : 48) + k] * 0.01 / (double)maxT);
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[resident timing] gru fine (wg 248): other=%.2f tile=%.2f combine=%.2f sync=%.2f\n",
+            (double)tc[72] * 0.01 / (double)maxT, (double)tc[73] * 0.01 / (double)maxT, (double)tc[74] * 0.01 / (double)maxT,
+            (double)tc[75] * 0.01 / (double)maxT);
   }
 #endif
   int n_over = 0;

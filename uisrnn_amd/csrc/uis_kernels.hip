@@ -1597,14 +1597,17 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
 // kernels (bit-identical, tested).  A barrier that does not complete sets cl_abort instead of
 // hanging; the host then reports an error.
 
-#define UIS_RES_RC 3   // row tiles per pass
+#define UIS_RES_RC 3           // row tiles per pass
+#define UIS_RES_HEAD_TILES 32  // row tiles whose descriptors are staged in LDS at a time
 
 __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, uint32_t target, int* s_abort) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t* ctr = st.rx_bar + cluster * 32;
-    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every participant sits on this XCD (checked), so the arrival is an L2 atomic (no device-scope
+    // write-through); the poll is an sc1 load: it skips this CU's L1 and is served by that L2
+    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned spins = 0;
     int bad = 0;
     while (before + 1 < target && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -1629,6 +1632,10 @@ __device__ __forceinline__ RowHead load_row_head(__amdgpu_buffer_rsrc_t rs_rows,
   const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)row * 32u, 0, 16);
   return RowHead{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
 }
+__device__ __forceinline__ RowHead lds_row_head(const u32x4* s_head, int row) {
+  const u32x4 d = s_head[row];
+  return RowHead{(int)d[0], (int)d[1], (int)d[2], (int)d[3]};
+}
 __device__ __forceinline__ long load_row_frame(__amdgpu_buffer_rsrc_t rs_rows, int row) {
   const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)row * 32u + 16u, 0, 16);
   return (long)(((unsigned long long)d[1] << 32) | d[0]);
@@ -1637,42 +1644,115 @@ __device__ __forceinline__ float load_f32_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// RC row tiles x NG gates of one feature tile, weights from registers: wave w walks its K
-// segment (PER k-blocks), partial tiles to LDS [UIS_KSPLIT][RC][NG][256], ends with the barrier.
-template <int NG, int PER, int RC>
-__device__ __forceinline__ void resident_tile(const f32x4 (&wr)[NG][PER], const f32x4 (&bias)[NG],
-                                              __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], float* spart) {
+// NV (<= RC) row tiles x NG gates of one feature tile, weights from registers: wave w walks its
+// K segment (PER k-blocks), partial tiles to LDS [UIS_KSPLIT][RC][NG][256], ends with the
+// barrier.  The rows are requested k-block-major so that the first MFMAs need only the first NV
+// loads and the rest of the stream (every CU of the XCD reads all rows, ~100 GB/s per CU out of
+// L2) arrives underneath the MFMA chain.
+// KBS = bytes between a row's consecutive k-blocks (64: a plain row; 1024: the k-block-major
+// staging layout).  `after_issue` runs once the row loads are in flight: loads it issues are
+// younger in the in-order vmcnt queue, so the MFMA chain never waits for them.
+template <int NG, int PER, int RC, int NV, int KBS, typename After>
+__device__ __forceinline__ void resident_tile_nv(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
+                                                 __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], float* spart,
+                                                 After after_issue) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4;
-  f32x4 b[RC][PER];
+  f32x4 bv[NG];  // oldest in the vmcnt queue: the chain's first operand
 #pragma unroll
-  for (int r = 0; r < RC; ++r)
+  for (int g = 0; g < NG; ++g)
+    bv[g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 b[NV][PER];
 #pragma unroll
-    for (int kb = 0; kb < PER; ++kb) b[r][kb] = load_sc1(rsrc, boff[r] + (uint32_t)((w * PER + kb) * 64 + q * 16));
-  f32x4 acc[RC][NG];
+  for (int kb = 0; kb < PER; ++kb)
 #pragma unroll
-  for (int r = 0; r < RC; ++r)
+    for (int r = 0; r < NV; ++r) b[r][kb] = load_sc1(rsrc, boff[r] + (uint32_t)((w * PER + kb) * KBS + q * 16));
+  after_issue();
+  f32x4 acc[NV][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[r][g] = w == 0 ? bias[g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[r][g] = bv[g];
 #pragma unroll
   for (int kb = 0; kb < PER; ++kb)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int r = 0; r < RC; ++r)
+      for (int r = 0; r < NV; ++r)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
           acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][kb][e], b[r][kb][e], acc[r][g], 0, 0, 0);
+#if defined(UIS_RES_DUP_MFMA)  // diagnostic: the MFMA chain a second time, result discarded
+  {
+    f32x4 acc2[NV][NG];
 #pragma unroll
-  for (int r = 0; r < RC; ++r)
+    for (int r = 0; r < NV; ++r)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc2[r][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kb = 0; kb < PER; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int r = 0; r < NV; ++r)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            acc2[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][kb][e], b[r][kb][e], acc2[r][g], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NV; ++r)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) asm volatile("" ::"v"(acc2[r][g]));
+  }
+#endif
+#if defined(UIS_RES_DUP_LOAD)  // diagnostic: the row stream a second time, result discarded
+  {
+#pragma unroll
+    for (int kb = 0; kb < PER; ++kb)
+#pragma unroll
+      for (int r = 0; r < NV; ++r) {
+        const f32x4 d = load_sc1(rsrc, boff[r] + (uint32_t)((w * PER + kb) * KBS + q * 16));
+        asm volatile("" ::"v"(d));
+      }
+  }
+#endif
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
 #pragma unroll
     for (int g = 0; g < NG; ++g)
       *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
   __syncthreads();
 }
-
-__host__ __device__ inline size_t resident_lds_bytes(int Dp, int B, int Kmax, int S) {
-  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4 + 64;
+// nvalid (wave-uniform, 1..RC) picks the straight-line variant
+template <int NG, int PER, int RC, int KBS, typename After>
+__device__ __forceinline__ void resident_tile(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
+                                              __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], int nvalid,
+                                              float* spart, After after_issue) {
+  static_assert(RC == 3, "dispatch below");
+  if (nvalid >= 3) resident_tile_nv<NG, PER, RC, 3, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+  else if (nvalid == 2) resident_tile_nv<NG, PER, RC, 2, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+  else resident_tile_nv<NG, PER, RC, 1, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
 }
+
+// LDS of k_decode_resident: select area | split-K partial tiles | control words | the rank's
+// linear_mean1 / linear_mean2 weight tiles | this step's row descriptors of the cluster (16-byte
+// head + 8-byte frame per row)
+__host__ __device__ inline size_t resident_lds_bytes(int Dp, int B, int Kmax, int S) {
+  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4 + 64 +
+         (size_t)2 * 32 * 64 * 16 + (size_t)UIS_RES_HEAD_TILES * 16 * 24;
+}
+
+// Diagnostic build (-DUIS_RESIDENT_TIMING): thread 0 of workgroup 0 (runs a select) and of
+// workgroup 248 (rank 31: never runs one at 64 utterances) accumulate wall-clock ticks (10 ns)
+// per phase into counters[48 + k] / counters[64 + k].
+#if defined(UIS_RESIDENT_TIMING)
+#define RSTAMP(k) do { if (t == 0) { const unsigned long long now_ = wall_clock64(); rt_acc[k] += now_ - rt_prev; rt_prev = now_; } } while (0)
+#else
+#define RSTAMP(k) do {} while (0)
+#endif
+#if defined(UIS_RESIDENT_TIMING)
+#define FSTAMP(k) do { if (t == 0) { const unsigned long long now_ = wall_clock64(); ft_acc[k] += now_ - rt_prev2; rt_prev2 = now_; } } while (0)
+#else
+#define FSTAMP(k) do {} while (0)
+#endif
 
 template <int DP>
 __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState st) {
@@ -1681,12 +1761,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   constexpr int EPT = (RC + 1) / 2;
   static_assert(SH2 == 1 || SH2 == 2, "observation_dim 256 or 512 (padded)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
   const int U = st.U, S = st.S;
   const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
   float* spart = reinterpret_cast<float*>(smem_raw + ((L.total + 255) & ~255));
   int* s_ctl = reinterpret_cast<int*>(spart + UIS_KSPLIT * RC * 3 * 256);  // [0] abort  [1] steps
+  f32x4* s_w1 = reinterpret_cast<f32x4*>(s_ctl + 16);                         // [NKB][64] this rank's linear_mean1 tile
+  f32x4* s_w2 = s_w1 + NKB * 64;                                             // [NKB][64] ... linear_mean2 tile
+  u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);                  // [32 tiles x 16] {utt, src, dst, nprev}
+  long* s_frame = reinterpret_cast<long*>(s_head + UIS_RES_HEAD_TILES * 16);  // [32 tiles x 16]
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -1710,20 +1794,17 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const int nsteps = s_ctl[1];
 
   // ---- this thread's share of the weights, for the whole decode
-  f32x4 wg[3][PER], w1r[1][PER], w2r[1][PER], bg[3], b1v[1], b2v[1];
+  // (W_hh: 48 registers per thread; the two mean-head tiles: 2 x 32 KB of LDS)
+  f32x4 wg[3][PER];
   const int ft2 = rank / SH2, tpar2 = rank % SH2;
 #pragma unroll
   for (int kb = 0; kb < PER; ++kb) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
       wg[g][kb] = reinterpret_cast<const f32x4*>(m.whh[0])[((size_t)(g * 32 + rank) * NKB + w * PER + kb) * 64 + lane];
-    w1r[0][kb] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)rank * NKB + w * PER + kb) * 64 + lane];
-    w2r[0][kb] = reinterpret_cast<const f32x4*>(m.w2)[((size_t)ft2 * NKB + w * PER + kb) * 64 + lane];
+    s_w1[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)rank * NKB + w * PER + kb) * 64 + lane];
+    s_w2[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w2)[((size_t)ft2 * NKB + w * PER + kb) * 64 + lane];
   }
-#pragma unroll
-  for (int g = 0; g < 3; ++g) bg[g] = *reinterpret_cast<const f32x4*>(m.bhh[0] + (size_t)g * HP + rank * 16 + 4 * q);
-  b1v[0] = *reinterpret_cast<const f32x4*>(m.b1 + rank * 16 + 4 * q);
-  b2v[0] = *reinterpret_cast<const f32x4*>(m.b2 + ft2 * 16 + 4 * q);
 
   const __amdgpu_buffer_rsrc_t rs_rows =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
@@ -1731,10 +1812,23 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  // hand-off buffers between the stages (h' -> linear_mean1, a1 -> linear_mean2), k-block major:
+  // [row tile][k block = the producer's feature tile][16 rows][16] -- a producer tile is one
+  // contiguous KiB and so is a consumer wave's 16-byte-per-lane load
+  float* const hst = st.gi_up;
+  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
   const int rbase = cluster * st.rx_stride;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rt_prev = wall_clock64();
+  unsigned long long ft_acc[4] = {0, 0, 0, 0};
+  unsigned long long rt_prev2 = rt_prev;
+#endif
 
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
@@ -1743,117 +1837,170 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       select_fast_body<512, true>(m, st, par, cluster + 8 * i, smem_raw, sink);
       __syncthreads();
     }
+    RSTAMP(0);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(1);
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
     const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rank == 0 && t == 0)
       __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nrt = (nrows + 15) >> 4;
+    // This step's row descriptors go to LDS, UIS_RES_HEAD_TILES row tiles at a time (rows past
+    // nrows: stale but valid).  Up to that many tiles -- the common case -- they are staged once
+    // for the three stages; beyond, every stage walks the row tiles in chunks and re-stages.
+    auto stage_heads = [&](int c0) {
+      const int r0 = 16 * c0, r1 = 16 * (nrt < c0 + UIS_RES_HEAD_TILES ? nrt : c0 + UIS_RES_HEAD_TILES);
+      for (int row = r0 + t; row < r1; row += 512) {
+        s_head[row - r0] = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)(rbase + row) * 32u, 0, 16);
+        s_frame[row - r0] = load_row_frame(rs_rows, rbase + row);
+      }
+      __syncthreads();
+    };
+    const bool single = nrt <= UIS_RES_HEAD_TILES;
+    if (single) stage_heads(0);
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
-    for (int i0 = 0; i0 < nrt; i0 += RC) {
-      uint32_t boff[RC];
+    for (int c0 = 0; c0 < nrt; c0 += UIS_RES_HEAD_TILES) {
+      if (!single) stage_heads(c0);
+      const int c1 = nrt < c0 + UIS_RES_HEAD_TILES ? nrt : c0 + UIS_RES_HEAD_TILES;
+      for (int i0 = c0; i0 < c1; i0 += RC) {
+        uint32_t boff[RC];
 #pragma unroll
-      for (int r = 0; r < RC; ++r) {
-        const int tile = i0 + r < nrt ? i0 + r : i0;
-        const RowHead rh = load_row_head(rs_rows, rbase + 16 * tile + (t & 15));
-        boff[r] = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
-      }
-      const int j = rank * 16 + (t & 15);
-      RowHead re[EPT];
-      float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
-      bool ework[EPT];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int r = (t >> 8) + 2 * k;
-        const int lrow = 16 * (i0 + r) + ((t & 255) >> 4);
-        ework[k] = r < RC && lrow < nrows;
-        gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
-        re[k] = RowHead{0, 0, 0, 0};
-        if (ework[k]) {
-          re[k] = load_row_head(rs_rows, rbase + lrow);
-          const long frame = load_row_frame(rs_rows, rbase + lrow);
-          const float* gi = st.gi0 + (size_t)frame * m.G;
-          gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
-          hprev[k] = re[k].src >= 0 ? load_f32_sc1(st.pool_hid + ((size_t)re[k].utt * S + re[k].src) * HP + j) : m.h1[j];
+        for (int r = 0; r < RC; ++r) {
+          const int tile = i0 + r < c1 ? i0 + r : i0;
+          const RowHead rh = lds_row_head(s_head, 16 * (tile - c0) + (t & 15));
+          boff[r] = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
         }
-      }
-      resident_tile<3, PER, RC>(wg, bg, rs_hid, boff, spart);
+        const int j = rank * 16 + (t & 15);
+        RowHead re[EPT];
+        float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
+        bool ework[EPT];
+        auto epilogue_operands = [&]() {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        if (!ework[k]) continue;
-        const int r = (t >> 8) + 2 * k, e = t & 255;
-        const float ghr = splitk_combine<RC, 3>(spart, r, 0, e);
-        const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
-        const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
-        const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
-        st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
+          for (int k = 0; k < EPT; ++k) {
+            const int r = (t >> 8) + 2 * k;
+            const int lrow = 16 * (i0 + r) + ((t & 255) >> 4);
+            ework[k] = r < RC && i0 + r < c1 && lrow < nrows;
+            gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
+            re[k] = RowHead{0, 0, 0, 0};
+            if (ework[k]) {
+              re[k] = lds_row_head(s_head, lrow - 16 * c0);
+              const long frame = s_frame[lrow - 16 * c0];
+              const float* gi = st.gi0 + (size_t)frame * m.G;
+              gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
+              hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
+            }
+          }
+        };
+        FSTAMP(0);
+        resident_tile<3, PER, RC, 64>(wg, m.bhh[0] + rank * 16, HP, rs_hid, boff, c1 - i0 < RC ? c1 - i0 : RC, spart,
+                                      epilogue_operands);
+        FSTAMP(1);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          if (!ework[k]) continue;
+          const int r = (t >> 8) + 2 * k, e = t & 255;
+          const float ghr = splitk_combine<RC, 3>(spart, r, 0, e);
+          const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
+          const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
+          const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+          st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
+          hst[((tile0 + i0 + r) * 32 + rank) * 256 + e] = out;  // the copy linear_mean1 streams
+        }
+        FSTAMP(2);
+        __syncthreads();  // spart (and, chunked, the descriptors) are reused
+        FSTAMP(3);
       }
-      __syncthreads();  // spart is reused by the next pass
     }
+    RSTAMP(2);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(3);
 
-    // ---- linear_mean1 + relu -> a1
+    // ---- linear_mean1 + relu -> a1 (needs no descriptors: row tile in, row tile out)
     for (int i0 = 0; i0 < nrt; i0 += RC) {
       uint32_t boff[RC];
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
         const int tile = i0 + r < nrt ? i0 + r : i0;
-        const RowHead rh = load_row_head(rs_rows, rbase + 16 * tile + (t & 15));
-        boff[r] = (uint32_t)((((size_t)rh.utt * S + rh.dst) * HP) * 4);
+        boff[r] = (uint32_t)((((tile0 + tile) * 32) * 256 + (t & 15) * 16) * 4);
       }
-      resident_tile<1, PER, RC>(w1r, b1v, rs_hid, boff, spart);
+      f32x4 w1r[1][PER];
+#pragma unroll
+      for (int kb = 0; kb < PER; ++kb) w1r[0][kb] = s_w1[(w * PER + kb) * 64 + lane];
+      resident_tile<1, PER, RC, 1024>(w1r, m.b1 + rank * 16, 0, rs_hst, boff, nrt - i0 < RC ? nrt - i0 : RC, spart, []() {});
       for (int e = t; e < RC * 256; e += 512) {
         const int r = e >> 8, lrow = 16 * (i0 + r) + ((e & 255) >> 4);
         if (lrow < nrows) {
           const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
-          st.a1[(size_t)(rbase + lrow) * HP + rank * 16 + (e & 15)] = v > 0.0f ? v : 0.0f;
+          st.a1[((tile0 + i0 + r) * 32 + rank) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
         }
       }
       __syncthreads();
     }
+    RSTAMP(4);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(5);
 
-    // ---- linear_mean2 + running mean -> dst slot; this rank's row tiles are tpar2, tpar2 + SH2, ...
-    const int my_tiles = nrt > tpar2 ? (nrt - tpar2 + SH2 - 1) / SH2 : 0;
-    for (int i0 = 0; i0 < my_tiles; i0 += RC) {
-      uint32_t boff[RC];
+    // ---- linear_mean2 + running mean -> dst slot; of every chunk this rank takes the row tiles
+    // c0 + tpar2, c0 + tpar2 + SH2, ... (chunks start at even tiles)
+    for (int c0 = 0; c0 < nrt; c0 += UIS_RES_HEAD_TILES) {
+      if (!single) stage_heads(c0);
+      const int c1 = nrt < c0 + UIS_RES_HEAD_TILES ? nrt : c0 + UIS_RES_HEAD_TILES;
+      const int my_tiles = c1 - c0 > tpar2 ? (c1 - c0 - tpar2 + SH2 - 1) / SH2 : 0;
+      for (int i0 = 0; i0 < my_tiles; i0 += RC) {
+        uint32_t boff[RC];
 #pragma unroll
-      for (int r = 0; r < RC; ++r) {
-        const int tile = tpar2 + SH2 * (i0 + r < my_tiles ? i0 + r : i0);
-        boff[r] = (uint32_t)(((size_t)(rbase + 16 * tile + (t & 15)) * HP) * 4);
-      }
-      const int f = ft2 * 16 + (t & 15);
-      RowHead re[EPT];
-      float old[EPT];
-      bool ework[EPT];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int r = (t >> 8) + 2 * k;
-        const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
-        ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
-        old[k] = 0.0f;
-        re[k] = RowHead{0, 0, 0, 0};
-        if (ework[k]) {
-          re[k] = load_row_head(rs_rows, rbase + lrow);
-          if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
+        for (int r = 0; r < RC; ++r) {
+          const int tile = c0 + tpar2 + SH2 * (i0 + r < my_tiles ? i0 + r : i0);
+          boff[r] = (uint32_t)((((tile0 + tile) * 32) * 256 + (t & 15) * 16) * 4);
         }
-      }
-      resident_tile<1, PER, RC>(w2r, b2v, rs_a1, boff, spart);
+        const int f = ft2 * 16 + (t & 15);
+        RowHead re[EPT];
+        float old[EPT];
+        bool ework[EPT];
+        auto epilogue_operands = [&]() {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        if (!ework[k]) continue;
-        const int r = (t >> 8) + 2 * k;
-        float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
-        if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
-        if (f >= m.D) v = 0.0f;
-        st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+          for (int k = 0; k < EPT; ++k) {
+            const int r = (t >> 8) + 2 * k;
+            const int lrow = 16 * (c0 + tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
+            ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
+            old[k] = 0.0f;
+            re[k] = RowHead{0, 0, 0, 0};
+            if (ework[k]) {
+              re[k] = lds_row_head(s_head, lrow - 16 * c0);
+              if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
+            }
+          }
+        };
+        f32x4 w2r[1][PER];
+#pragma unroll
+        for (int kb = 0; kb < PER; ++kb) w2r[0][kb] = s_w2[(w * PER + kb) * 64 + lane];
+        resident_tile<1, PER, RC, 1024>(w2r, m.b2 + ft2 * 16, 0, rs_a1, boff, my_tiles - i0 < RC ? my_tiles - i0 : RC, spart,
+                                        epilogue_operands);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          if (!ework[k]) continue;
+          const int r = (t >> 8) + 2 * k;
+          float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
+          if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
+          if (f >= m.D) v = 0.0f;
+          st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
+    RSTAMP(6);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(7);
   }
+#if defined(UIS_RESIDENT_TIMING)
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
+  {
+    for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
+    if (blockIdx.x == 248) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ window
