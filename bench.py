@@ -14,8 +14,10 @@ The frame stream and the label buffer live in HBM before the timed region
 starts (torch is used for device memory and torch.distributed only).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- the dominant kernel (k_dense_gru, hidden-side GRU GEMM) timed
-                  with HIP events on the decode stream (UIS_FLAG_PROFILE pass)
+  roofline     -- the dominant kernel timed with HIP events on the decode stream
+                  (UIS_FLAG_PROFILE pass): k_decode_resident, the one-launch beam
+                  search, where it applies (this workload); k_dense_gru, the
+                  hidden-side GRU GEMM, on the launch-per-step path (--flags 128)
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm)
                   timed on this box's host cores on a bounded sample; the GPU
                   labels are checked against it.
@@ -192,26 +194,38 @@ def main():
     n_steps = prof['n_steps']
     gru_ms = prof['kernel_ms']['gru']
     gru_launches = max(prof['kernel_launches']['gru'], 1)
+    resident = prof['kernel_launches']['select'] == 0 and prof['kernel_launches']['gru'] == 1
     # start/stop events of hipExtLaunchKernelGGL = the dispatch's own begin/end timestamps
     # (cross-check: rocprofv3 --kernel-trace average in profiles/)
     avg_us = 1e3 * gru_ms / gru_launches
-    # algorithmic work of one launch: every surviving hypothesis of every
-    # utterance takes one hidden-side GRU matvec (3H x H MACs), DESIGN.md
     rows_algo = prof['rnn_rows_nodedup'] / max(n_steps, 1)
-    flop_per_launch = 2.0 * 3 * hid * hid * rows_algo
-    achieved = flop_per_launch / (avg_us * 1e-6) / 1e12
     flop_per_frame = tau * (2.0 * (3 * hid * dim + 3 * hid * hid + hid * hid + dim * hid) * beam
                             + 3.0 * dim * beam * 5)
+    if resident:
+      # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
+      # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
+      # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
+      kernel = 'k_decode_resident'
+      flop_per_launch = 2.0 * (3 * hid * hid + hid * hid + dim * hid) * prof['rnn_rows_nodedup']
+      # weights once + per row: h in, gi0 in (3H), h' out, a1 out/in, mean in/out
+      algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) +
+                       prof['rnn_rows_nodedup'] * 4 * (hid + 3 * hid + hid + 2 * hid + 2 * dim))
+    else:
+      # one launch = one step's hidden-side GRU matvecs (3H x H MACs per surviving hypothesis)
+      kernel = 'k_dense_gru'
+      flop_per_launch = 2.0 * 3 * hid * hid * rows_algo
+      # W_hh once + per row: h in, gi0 in (3H), h' out
+      algo_bytes = int(4 * 3 * hid * hid + rows_algo * 4 * (hid + 3 * hid + hid))
+    achieved = flop_per_launch / (avg_us * 1e-6) / 1e12
     roofline = {
-        'bound': 'mfma', 'kernel': 'k_dense_gru', 'achieved': round(achieved, 3),
+        'bound': 'mfma', 'kernel': kernel, 'achieved': round(achieved, 3),
         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-        'traffic': committed_traffic('k_dense_gru'),
+        'traffic': committed_traffic(kernel),
         'avg_launch_us': round(avg_us, 3), 'launches': gru_launches,
-        # W_hh once + per row: h in, gi0 in (3H), h' out
-        'algorithmic_bytes_per_launch': int(4 * 3 * hid * hid + rows_algo * 4 * (hid + 3 * hid + hid)),
-        'rows_per_launch_algorithmic': round(rows_algo, 1),
-        'rows_per_launch_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
+        'algorithmic_bytes_per_launch': algo_bytes,
+        'rows_per_step_algorithmic': round(rows_algo, 1),
+        'rows_per_step_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
         'path_frac_fp32': round(value / world * flop_per_frame / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         'kernel_ms_profile_pass': {k: round(v, 3) for k, v in prof['kernel_ms'].items()},
     }

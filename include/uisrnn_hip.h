@@ -95,11 +95,17 @@ typedef struct uis_decode_opts {
                                     tiles waiting on per-row-tile arrival counters instead of
                                     kernel boundaries (k_rnn_dataflow); bit-identical results;
                                     depth-1 models only                                      */
-#define UIS_FLAG_RESIDENT   0x40u /* the whole decode in ONE launch (k_decode_resident): 256
-                                    workgroups, one per CU, weights held in registers, one
-                                    XCD per utterance subset, in-launch XCD barriers between
-                                    the stages of a step; bit-identical results; look_ahead 1,
-                                    rnn_depth 1, rnn_hidden_size 512, observation_dim 256/512 */
+#define UIS_FLAG_RESIDENT   0x40u /* REQUIRE the one-launch decode (k_decode_resident: 256
+                                    workgroups, one per CU, W_hh in registers and the mean-head
+                                    tiles in LDS for the whole decode, one XCD per utterance
+                                    subset, in-launch XCD barriers between the stages of a
+                                    step) and fail with UIS_ERR_UNSUPPORTED where it does not
+                                    apply.  It is the DEFAULT wherever it applies: look_ahead 1,
+                                    rnn_depth 1, rnn_hidden_size 512, observation_dim 256/512,
+                                    beam_size * (max_clusters + 1) <= 256, one stream, 256 CUs  */
+#define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
+                                    step) even where the one-launch decode applies (A/B switch;
+                                    results are bit-identical either way)                     */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

@@ -30,12 +30,13 @@ def _check(oracle_lib, dim, hid, depth, beam, look, tau, lengths, seed, flags=0,
   frames, offsets = oracle_lib.pack(seqs)
   cap = max(int(ref['max_clusters'].max()) + look - 1, 2)
   dec = _capi.Decoder(params)
-  out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, flags=flags,
-                   want_beam_scores=True)
-  assert out['status'] == 0, (dim, hid, depth, beam, look, tau)
-  for u in range(len(seqs)):
-    assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), u
-  assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  for fl in (flags, flags | _capi.UIS_FLAG_STEPWISE):  # the default path and the launch-per-step path
+    out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, flags=fl,
+                     want_beam_scores=True)
+    assert out['status'] == 0, (dim, hid, depth, beam, look, tau)
+    for u in range(len(seqs)):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), u
+    assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
 
 
 SHAPES = [
@@ -48,6 +49,9 @@ SHAPES = [
     (20, 24, 1, 2, 3, 1, [10, 4]),            # look_ahead 3
     (16, 16, 1, 64, 1, 1, [6, 6]),            # beam 64
     (128, 96, 2, 8, 1, 2, [15, 15, 2, 9]),    # Hp = 96: 6 feature tiles (no XCD map), depth 2
+    (250, 500, 1, 6, 1, 2, [9, 14, 5, 1, 20, 3, 8, 11, 2]),  # pads to 256 / 512: the one-launch decode, padded lanes
+    (512, 512, 1, 5, 1, 1, [7, 12, 30]),      # one-launch decode, observation_dim 512
+    (400, 505, 1, 4, 1, 3, [6]),              # one-launch decode, one utterance, tau 3
 ]
 
 

@@ -18,6 +18,10 @@ from uisrnn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+_PATH_FLAGS = (_capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_FUSED |
+               _capi.UIS_FLAG_DATAFLOW | _capi.UIS_FLAG_GRAPH)
+
+
 def _bits(a):
   return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
@@ -29,20 +33,26 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
   dec = decoder or _capi.Decoder(params)
   frames, offsets = oracle_lib.pack(seqs)
   cap = max(int(ref['max_clusters'].max()) if len(seqs) else 1, 1)
-  # intermediate look-ahead levels hold hypotheses with up to look_ahead - 1 more clusters
-  # than any survivor
-  out = dec.decode(frames, offsets, beam_size, look_ahead, test_iteration,
-                   max_clusters=max_clusters or max(cap + look_ahead - 1, 4),
-                   flags=flags,
-                   want_beam_scores=True, n_streams=n_streams)
-  assert out['status'] == 0
-  assert not out['overflow'].any()
-  for u in range(len(seqs)):
-    got = out['labels'][offsets[u]:offsets[u + 1]]
-    assert np.array_equal(got, ref['labels'][u]), 'labels differ, utterance %d' % u
-  assert np.array_equal(_bits(out['scores']), _bits(ref['scores']))
-  assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
-  assert out['stats']['max_clusters_seen'] == cap
+  # Where the one-launch decode (k_decode_resident) applies it is the default; a call that
+  # does not pick a path itself is checked on BOTH paths.
+  variants = [flags]
+  if not flags & _PATH_FLAGS and look_ahead == 1 and n_streams in (0, 1):
+    variants.append(flags | _capi.UIS_FLAG_STEPWISE)
+  for fl in variants:
+    # intermediate look-ahead levels hold hypotheses with up to look_ahead - 1 more clusters
+    # than any survivor
+    out = dec.decode(frames, offsets, beam_size, look_ahead, test_iteration,
+                     max_clusters=max_clusters or max(cap + look_ahead - 1, 4),
+                     flags=fl,
+                     want_beam_scores=True, n_streams=n_streams)
+    assert out['status'] == 0
+    assert not out['overflow'].any()
+    for u in range(len(seqs)):
+      got = out['labels'][offsets[u]:offsets[u + 1]]
+      assert np.array_equal(got, ref['labels'][u]), 'labels differ, utterance %d' % u
+    assert np.array_equal(_bits(out['scores']), _bits(ref['scores']))
+    assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+    assert out['stats']['max_clusters_seen'] == cap
   return out, ref
 
 

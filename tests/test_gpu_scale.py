@@ -35,7 +35,8 @@ def test_config2_full_size_properties(oracle_lib):
   again, _ = _decode(dec, seqs, 10, 1, 2)
   assert np.array_equal(out['labels'], again['labels'])
   assert np.array_equal(out['beam_scores'].view(np.uint32), again['beam_scores'].view(np.uint32))
-  for flags, streams in ((_capi.UIS_FLAG_NO_DEDUP, 0), (_capi.UIS_FLAG_GENERIC_SELECT, 0), (0, 4)):
+  for flags, streams in ((_capi.UIS_FLAG_NO_DEDUP, 0), (_capi.UIS_FLAG_GENERIC_SELECT, 0), (0, 4),
+                         (_capi.UIS_FLAG_STEPWISE, 0), (_capi.UIS_FLAG_RESIDENT, 0)):
     alt, _ = _decode(dec, seqs, 10, 1, 2, flags=flags, n_streams=streams)
     assert np.array_equal(out['labels'], alt['labels'])
     assert np.array_equal(out['beam_scores'].view(np.uint32), alt['beam_scores'].view(np.uint32))
@@ -62,8 +63,11 @@ def test_config4_shape_one_gpu_share():
   params = synth.tracker_params(256, 512, 1, seed=0)
   seqs, _ = synth.make_utterances(20_000, 1024, 100, 256)
   dec = _capi.Decoder(params)
-  out, off = _decode(dec, seqs, 10, 1, 2)
+  out, off = _decode(dec, seqs, 10, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)   # 128 utterances per XCD
   assert out['stats']['n_steps'] == 200
+  step, _ = _decode(dec, seqs, 10, 1, 2, flags=_capi.UIS_FLAG_STEPWISE)
+  assert np.array_equal(out['labels'], step['labels'])
+  assert np.array_equal(out['beam_scores'].view(np.uint32), step['beam_scores'].view(np.uint32))
   for u in (0, 511, 1023):
     alone, _ = _decode(dec, [seqs[u]], 10, 1, 2)
     assert np.array_equal(alone['labels'], out['labels'][off[u]:off[u + 1]])

@@ -31,6 +31,7 @@ UIS_FLAG_GENERIC_SELECT = 0x8
 UIS_FLAG_FUSED = 0x10
 UIS_FLAG_DATAFLOW = 0x20
 UIS_FLAG_RESIDENT = 0x40
+UIS_FLAG_STEPWISE = 0x80
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',

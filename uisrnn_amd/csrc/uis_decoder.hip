@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,7 +44,9 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool borrowed = false;  // a view into the handle's workspace arena, not an allocation of its own
   int ensure(size_t bytes) {
+    if (borrowed) { p = nullptr; cap = 0; borrowed = false; }
     if (bytes <= cap) return UIS_OK;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     size_t want = bytes + bytes / 8 + 256;
@@ -55,7 +58,7 @@ struct DevBuf {
     cap = want;
     return UIS_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -90,6 +93,7 @@ struct uis_handle {
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
+  DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -389,7 +393,9 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 
   // ---- workspace
   int rc;
-#define ENSURE(buf, bytes) if ((rc = h->buf.ensure(bytes))) return rc
+  // every buffer is a 4 KB-aligned view into ONE allocation (h->arena), sized first
+  std::vector<std::pair<DevBuf*, size_t>> want;
+#define ENSURE(buf, bytes) want.emplace_back(&h->buf, (size_t)(bytes))
   ENSURE(off, (size_t)(U + 1) * 8);
   ENSURE(utt_step, (size_t)U * 4);
   ENSURE(overflow, (size_t)U * 4);
@@ -433,10 +439,14 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                            select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && h->n_cu == 256 &&
                            ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                            resident_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024;
-  const bool resident = (opts->flags & UIS_FLAG_RESIDENT) != 0 && resident_ok;
+  // the default wherever it applies; UIS_FLAG_STEPWISE (or any of the per-step experiments) keeps
+  // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
+  const bool resident = resident_ok && !use_graph &&
+                        !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW));
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 512 (padded), "
-                                     "observation_dim 256 or 512 (padded), one stream and a 256-CU device");
+                                     "observation_dim 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
+                                     "stream, a 256-CU device and no per-step path flag");
   const int tile_cap = (int)((rows_cap + 15) / 16) + 1;
   const size_t ctl_words = (size_t)8 * 16 + 8 + 8 + 2 * tile_cap + 2 * 8 * 32;
   ENSURE(cluster_ctl, ctl_words * 4);
@@ -455,6 +465,25 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     ENSURE(bp_base, (size_t)(U + 1) * 8);
   }
 #undef ENSURE
+  {
+    const bool use_arena = getenv("UIS_NO_ARENA") == nullptr;
+    size_t total = 0;
+    for (auto& w : want) total += (w.second + 4095) & ~(size_t)4095;
+    if (use_arena) {
+      if ((rc = h->arena.ensure(total))) return rc;
+      size_t o = 0;
+      for (auto& w : want) {
+        if (w.first->p && !w.first->borrowed) (void)hipFree(w.first->p);
+        w.first->p = static_cast<char*>(h->arena.p) + o;
+        w.first->cap = w.second;
+        w.first->borrowed = true;
+        o += (w.second + 4095) & ~(size_t)4095;
+      }
+    } else {
+      for (auto& w : want)
+        if ((rc = w.first->ensure(w.second))) return rc;
+    }
+  }
 
   // ---- per-decode tables
   std::vector<double> logblk(maxT + 2), logden(maxT + 2);
@@ -698,7 +727,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
                     &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
-                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl};
+                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);

@@ -1607,10 +1607,12 @@ __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, 
     uint32_t* ctr = st.rx_bar + cluster * 32;
     // every participant sits on this XCD (checked), so the arrival is an L2 atomic (no device-scope
     // write-through); the poll is an sc1 load: it skips this CU's L1 and is served by that L2
-    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (the arrival's return value is not used -- no round trip before the first poll, which queues
+    // behind it at the same L2 channel)
+    (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned spins = 0;
     int bad = 0;
-    while (before + 1 < target && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
         __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bad = 1;
