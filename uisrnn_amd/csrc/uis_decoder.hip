@@ -423,7 +423,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // depth 1: k_decode_resident's h' staging buffer
   ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : (size_t)rows_cap * m.Hp * 4);
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
-  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 64 * 8);
+  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 96 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   // opt-in one-launch rnn step: depth-1 models whose exchanged buffers fit 31-bit byte offsets
   const bool fused = (opts->flags & UIS_FLAG_FUSED) && m.depth == 1 && G == 1 &&
@@ -657,9 +657,17 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     fprintf(stderr, "\n");
   }
 #endif
+#if defined(UIS_RESIDENT_PROBE)
+  if (resident) {
+    unsigned long long tc[88];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[resident probe] cycles per dependent load: own-table(nt)=%.0f mean(sc1)=%.0f wgt(plain)=%.0f wgt-again=%.0f\n",
+            (double)tc[80] / (double)maxT, (double)tc[81] / (double)maxT, (double)tc[82] / (double)maxT, (double)tc[83] / (double)maxT);
+  }
+#endif
 #if defined(UIS_RESIDENT_TIMING)
   if (resident) {
-    unsigned long long tc[80];
+    unsigned long long tc[88];
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
     static const char* names[8] = {"select", "barA", "gru", "barB", "head1", "barC", "head2", "barD"};
     for (int wg = 0; wg < 2; ++wg) {
@@ -667,6 +675,9 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.2f", names[k], (double)tc[(wg ? 64 : 48) + k] * 0.01 / (double)maxT);
       fprintf(stderr, "\n");
     }
+    fprintf(stderr, "[resident timing] select phases (wg 0), us per step:");
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.2f", k, (double)tc[80 + k] * 0.01 / (double)maxT);
+    fprintf(stderr, "\n");
     fprintf(stderr, "[resident timing] gru fine (wg 248): other=%.2f tile=%.2f combine=%.2f sync=%.2f\n",
             (double)tc[72] * 0.01 / (double)maxT, (double)tc[73] * 0.01 / (double)maxT, (double)tc[74] * 0.01 / (double)maxT,
             (double)tc[75] * 0.01 / (double)maxT);

@@ -1202,22 +1202,29 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {  //
 }
 
 struct FastLds {
-  int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_base, off_score;
-  int off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc;
+  int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_score, off_nb, set_stride;
+  int off_base, off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc, off_pcnt;
   int total;
 };
+// The beam tables (slot, blk, K, last, sum, score, nb) form a SET; there are two of them so that
+// the resident decode can keep the beam in LDS across steps (set = step parity).  The
+// launch-per-step kernel uses set 0 only.
 __host__ __device__ inline FastLds fast_lds_layout(int Dp, int B, int Kmax, int S) {
   FastLds l;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
   l.off_wgt = take(Dp * 4);
+  const int set0 = o;
   l.off_slot = take(B * Kmax * 4);
   l.off_blk = take(B * Kmax * 4);
   l.off_K = take(B * 4);
   l.off_last = take(B * 4);
   l.off_sum = take(B * 4);
-  l.off_base = take((B + 1) * 4);
   l.off_score = take(B * 4);
+  l.off_nb = take(16);
+  l.set_stride = o - set0;
+  o += l.set_stride;  // the second set
+  l.off_base = take((B + 1) * 4);
   l.off_live = take(S * 4);
   l.off_livelist = take(S * 4);
   l.off_mse = take(S * 4);
@@ -1225,7 +1232,8 @@ __host__ __device__ inline FastLds fast_lds_layout(int Dp, int B, int Kmax, int 
   l.off_key = take(256 * 8);
   l.off_win = take(64 * 4);
   l.off_wscore = take(64 * 4);
-  l.off_misc = take(16 * 4);
+  l.off_misc = take(64 * 4);  // [0] nlive [1] nfinite; [16..31] phase clocks of the timing build
+  l.off_pcnt = take(S * 4);   // resident decode: frames per slot (what pool_cnt holds), kept across steps
   l.total = o;
   return l;
 }
@@ -1244,24 +1252,51 @@ struct RowSink {
 // the cluster means were written by other CUs of this XCD inside the same launch, so they are
 // read with sc1 loads; everything else a select reads is either immutable or was written by
 // this very workgroup.  The caller provides the workgroup barrier that ends the call.
-template <int NT, bool RES>
+#if defined(UIS_RESIDENT_TIMING)
+// resident timing build: thread 0 accumulates wall-clock ticks (10 ns) per select phase in LDS
+#undef TSTAMP
+#define TSTAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_now_ = wall_clock64(); \
+    reinterpret_cast<unsigned long long*>(smem_raw + fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).off_misc + 64)[k] += t_now_ - t_prev_; \
+    t_prev_ = t_now_; } } while (0)
+#endif
+// KEEP (resident decode, one utterance per workgroup): the beam tables and the per-slot frame
+// counts stay in LDS from one step to the next -- a step reads table set `par` and writes set
+// `par ^ 1` -- so the only global state a select reads back is the cluster means; the caller
+// passes the step number and the utterance's frame range.
+template <int NT, bool RES, bool KEEP>
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
-                                                 unsigned char* smem_raw, RowSink sink) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                 unsigned char* smem_raw, RowSink sink, int step_in = 0,
+                                                 long off0_in = 0, long off1_in = 0) {
+  int tid_ = threadIdx.x;
+  // inside the resident decode's step loop: keep the compiler from hoisting every tid-derived
+  // address out of the loop (they would have to live -- spilled -- across the dense stages)
+  if (RES) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
 #if defined(UIS_SELECT_TIMING)
   unsigned long long t_prev_ = __builtin_readcyclecounter();
+#elif defined(UIS_RESIDENT_TIMING)
+  unsigned long long t_prev_ = wall_clock64();
 #endif
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
   const int nxt = par ^ 1;
   const FastLds L = fast_lds_layout(m.Dp, B, Kmax, S);
   float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
-  int* sslot = reinterpret_cast<int*>(smem_raw + L.off_slot);
-  int* sblk = reinterpret_cast<int*>(smem_raw + L.off_blk);
-  int* sK = reinterpret_cast<int*>(smem_raw + L.off_K);
-  int* slast = reinterpret_cast<int*>(smem_raw + L.off_last);
-  int* ssum = reinterpret_cast<int*>(smem_raw + L.off_sum);
+  unsigned char* const set_cur = smem_raw + (KEEP ? par * L.set_stride : 0);
+  unsigned char* const set_nxt = smem_raw + (KEEP ? nxt * L.set_stride : 0);
+  int* sslot = reinterpret_cast<int*>(set_cur + L.off_slot);
+  int* sblk = reinterpret_cast<int*>(set_cur + L.off_blk);
+  int* sK = reinterpret_cast<int*>(set_cur + L.off_K);
+  int* slast = reinterpret_cast<int*>(set_cur + L.off_last);
+  int* ssum = reinterpret_cast<int*>(set_cur + L.off_sum);
+  float* sscore = reinterpret_cast<float*>(set_cur + L.off_score);
+  int* nslot = reinterpret_cast<int*>(set_nxt + L.off_slot);   // KEEP: next step's tables
+  int* nblk = reinterpret_cast<int*>(set_nxt + L.off_blk);
+  int* nK = reinterpret_cast<int*>(set_nxt + L.off_K);
+  int* nlast = reinterpret_cast<int*>(set_nxt + L.off_last);
+  int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
+  float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
+  int* spcnt = reinterpret_cast<int*>(smem_raw + L.off_pcnt);
   int* sbase = reinterpret_cast<int*>(smem_raw + L.off_base);
-  float* sscore = reinterpret_cast<float*>(smem_raw + L.off_score);
   int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
   int* slivelist = reinterpret_cast<int*>(smem_raw + L.off_livelist);
   float* smse = reinterpret_cast<float*>(smem_raw + L.off_mse);
@@ -1274,20 +1309,36 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const size_t bcur = ((size_t)par * U + u) * B;
   const size_t bnxt = ((size_t)nxt * U + u) * B;
 
-  // ---- round trip 1
-  const int step = st.utt_step[u];
-  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
-  const int nb = st.beam_n[(size_t)par * U + u];
-  for (int i = tid; i < m.Dp; i += NT) swgt[i] = m.wgt[i];
-  for (int e = tid; e < B * Kmax; e += NT) {
-    sslot[e] = st.beam_slot[bcur * Kmax + e];
-    sblk[e] = st.beam_blk[bcur * Kmax + e];
-  }
-  int myK = 0;
-  if (tid < B) {
-    myK = st.beam_K[bcur + tid];
-    sK[tid] = myK; slast[tid] = st.beam_last[bcur + tid];
-    ssum[tid] = st.beam_sum[bcur + tid]; sscore[tid] = st.beam_score[bcur + tid];
+  // ---- round trip 1: every load is issued before the first result is stored to LDS (written
+  // as load-then-store pairs the compiler waits for each load before it issues the next).
+  // B * Kmax < 256 <= NT (select_fast_ok): one table entry per thread.
+  // KEEP, after the first step: nothing to fetch -- the tables are in LDS set `par`.
+  const bool fresh = !KEEP || step_in == 0;
+  int step = step_in, nb = 0, myK = 0;
+  long off0 = off0_in, off1 = off1_in;
+  const bool has_e = tid < B * Kmax, has_b = tid < B;
+  if (fresh) {
+    if (!KEEP) { step = st.utt_step[u]; off0 = (long)st.off[u]; off1 = (long)st.off[u + 1]; }
+    nb = st.beam_n[(size_t)par * U + u];
+    const int r_slot = has_e ? st.beam_slot[bcur * Kmax + tid] : 0;
+    const int r_blk = has_e ? st.beam_blk[bcur * Kmax + tid] : 0;
+    myK = has_b ? st.beam_K[bcur + tid] : 0;
+    const int r_last = has_b ? st.beam_last[bcur + tid] : 0;
+    const int r_sum = has_b ? st.beam_sum[bcur + tid] : 0;
+    const float r_score = has_b ? st.beam_score[bcur + tid] : 0.0f;
+    float r_w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r_w[k] = tid + k * NT < m.Dp ? m.wgt[tid + k * NT] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tid + k * NT < m.Dp) swgt[tid + k * NT] = r_w[k];
+    for (int i = tid + 4 * NT; i < m.Dp; i += NT) swgt[i] = m.wgt[i];  // observation_dim > 4 * NT
+    if (has_e) { sslot[tid] = r_slot; sblk[tid] = r_blk; }
+    if (has_b) { sK[tid] = myK; slast[tid] = r_last; ssum[tid] = r_sum; sscore[tid] = r_score; }
+    if (KEEP) for (int sl = tid; sl < S; sl += NT) spcnt[sl] = 0;
+  } else {
+    nb = *reinterpret_cast<const int*>(set_cur + L.off_nb);
+    myK = has_b ? sK[tid] : 0;
   }
   for (int sl = tid; sl < S; sl += NT) slive[sl] = 0;
   if (tid < 16) smisc[tid] = 0;
@@ -1364,7 +1415,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const float* mean = pmean + (size_t)sl[h2] * m.Dp;
-          cnt[h2] = (p == 0) ? st.pool_cnt[(size_t)u * S + sl[h2]] : 0;
+          cnt[h2] = (p == 0) ? (KEEP ? spcnt[sl[h2]] : st.pool_cnt[(size_t)u * S + sl[h2]]) : 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
@@ -1397,7 +1448,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
         const bool act = i < nlive;
         const int sl = slivelist[act ? i : 0];
         const float* mean = pmean + (size_t)sl * m.Dp;
-        const int cnt = (p == 0) ? st.pool_cnt[(size_t)u * S + sl] : 0;
+        const int cnt = (p == 0) ? (KEEP ? spcnt[sl] : st.pool_cnt[(size_t)u * S + sl]) : 0;
         float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float first_sq = 0.0f;
         for (int q = 0; q < m.Dp; q += 256) {
@@ -1447,26 +1498,50 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     my_sc = sscore[my_b] + uis_step_loss(mse, prior);
     if (uis_isfinite(my_sc)) my_key = ((unsigned long long)uis_score_key(my_sc) << 32) | (unsigned)tid;
   }
-  if (tid < 256) skey[tid] = my_key;  // candidates are threads 0..C-1, C <= 256
-  {
-    const unsigned long long fm = __ballot(my_key != ~0ull);
-    if (lane == 0 && fm) atomicAdd(&smisc[1], __popcll(fm));
-  }
-  __syncthreads();  // (5) keys
-  TSTAMP(3);
-  const int nfin = smisc[1];
-  const int keep = nfin < B ? nfin : B;
-  if (my_key != ~0ull) {  // rank by counting; keys are unique; two keys per 16-byte LDS read
-    int rank = 0;
-    const int C2 = (C + 1) & ~1;  // skey[C] (if C is odd) holds ~0ull or a non-candidate's ~0ull
+  int keep;
+  if (C <= 64) {
+    // every candidate is a lane of wave 0: its keys go through LDS without a workgroup barrier
+    if (wave == 0) {
+      const unsigned long long fm = __ballot(my_key != ~0ull);
+      const int nfin = __popcll(fm);
+      keep = nfin < B ? nfin : B;
+      skey[lane] = my_key;
+      if (my_key != ~0ull) {  // rank by counting; keys are unique; two keys per 16-byte LDS read
+        int rank = 0;
+        const int C2 = (C + 1) & ~1;
 #pragma unroll 8
-    for (int j2 = 0; j2 < C2; j2 += 2) {
-      const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(skey + j2);
-      rank += (kk.x < my_key) + (kk.y < my_key);
+        for (int j2 = 0; j2 < C2; j2 += 2) {
+          const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(skey + j2);
+          rank += (kk.x < my_key) + (kk.y < my_key);
+        }
+        if (rank < keep) { swin[rank] = tid; swscore[rank] = my_sc; }
+      }
+      if (lane == 0) smisc[1] = nfin;
     }
-    if (rank < keep) { swin[rank] = tid; swscore[rank] = my_sc; }
+    TSTAMP(3);
+  } else {
+    if (tid < 256) skey[tid] = my_key;  // candidates are threads 0..C-1, C <= 256
+    {
+      const unsigned long long fm = __ballot(my_key != ~0ull);
+      if (lane == 0 && fm) atomicAdd(&smisc[1], __popcll(fm));
+    }
+    __syncthreads();  // (5) keys
+    TSTAMP(3);
+    const int nfin = smisc[1];
+    keep = nfin < B ? nfin : B;
+    if (my_key != ~0ull) {  // rank by counting; keys are unique; two keys per 16-byte LDS read
+      int rank = 0;
+      const int C2 = (C + 1) & ~1;  // skey[C] (if C is odd) holds ~0ull or a non-candidate's ~0ull
+#pragma unroll 8
+      for (int j2 = 0; j2 < C2; j2 += 2) {
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(skey + j2);
+        rank += (kk.x < my_key) + (kk.y < my_key);
+      }
+      if (rank < keep) { swin[rank] = tid; swscore[rank] = my_sc; }
+    }
   }
   __syncthreads();  // (6) winners
+  { const int nfin = smisc[1]; keep = nfin < B ? nfin : B; }
   if (wave != 0) {
     // waves 1-3: copy the UNCHANGED entries of every winner's tables (BeamState(source),
     // uisrnn.py:66-69) while wave 0 works out the changed ones
@@ -1478,8 +1553,13 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
       const int rc = i - sbase[rb];
       const int Knew = sK[rb] + (rc == sK[rb] ? 1 : 0);
       if (c2 < Knew && c2 != rc) {
-        st.beam_slot[(bnxt + rr) * Kmax + c2] = sslot[rb * Kmax + c2];
-        st.beam_blk[(bnxt + rr) * Kmax + c2] = sblk[rb * Kmax + c2];
+        if (KEEP) {
+          nslot[rr * Kmax + c2] = sslot[rb * Kmax + c2];
+          nblk[rr * Kmax + c2] = sblk[rb * Kmax + c2];
+        } else {
+          st.beam_slot[(bnxt + rr) * Kmax + c2] = sslot[rb * Kmax + c2];
+          st.beam_blk[(bnxt + rr) * Kmax + c2] = sblk[rb * Kmax + c2];
+        }
       }
     }
     return;
@@ -1533,8 +1613,14 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   // the one changed entry of each winner's tables (the rest is being copied by waves 1-3)
   if (isw && wc < Kmax) {
     const bool is_new = wc == Kb;
-    st.beam_slot[(bnxt + r) * Kmax + wc] = dst;
-    st.beam_blk[(bnxt + r) * Kmax + wc] = is_new ? 1 : sblk[wb * Kmax + wc] + (wc != slast[wb] ? 1 : 0);
+    const int blk_new = is_new ? 1 : sblk[wb * Kmax + wc] + (wc != slast[wb] ? 1 : 0);
+    if (KEEP) {
+      nslot[r * Kmax + wc] = dst;
+      nblk[r * Kmax + wc] = blk_new;
+    } else {
+      st.beam_slot[(bnxt + r) * Kmax + wc] = dst;
+      st.beam_blk[(bnxt + r) * Kmax + wc] = blk_new;
+    }
   }
   int Kmaxseen = 0;
   if (isw) {
@@ -1542,11 +1628,16 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     int Knew = Kb + (is_new ? 1 : 0);
     if (Knew > Kmax) { Knew = Kmax; st.overflow[u] = 1; }
     Kmaxseen = Knew;
-    st.beam_K[bnxt + r] = Knew;
-    st.beam_last[bnxt + r] = wc;
-    st.beam_sum[bnxt + r] = ssum[wb] + ((is_new || wc != slast[wb]) ? 1 : 0);
-    st.beam_score[bnxt + r] = swscore[r];
-    st.bp[((size_t)st.tau * st.off[u] + step) * B + r] = ((unsigned)wb << 16) | (unsigned)wc;
+    const int sum_new = ssum[wb] + ((is_new || wc != slast[wb]) ? 1 : 0);
+    if (KEEP) {
+      nK[r] = Knew; nlast[r] = wc; nsum[r] = sum_new; nscore[r] = swscore[r];
+    } else {
+      st.beam_K[bnxt + r] = Knew;
+      st.beam_last[bnxt + r] = wc;
+      st.beam_sum[bnxt + r] = sum_new;
+    }
+    st.beam_score[bnxt + r] = swscore[r];  // (the final beam's scores are read back by k_backtrace)
+    st.bp[((size_t)st.tau * off0 + step) * B + r] = ((unsigned)wb << 16) | (unsigned)wc;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(Kmaxseen, off, 64); Kmaxseen = o > Kmaxseen ? o : Kmaxseen; }
@@ -1554,13 +1645,15 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   row_base = __shfl(row_base, 0, 64);
   if (is_lead) {
     const int nprev = src >= 0 ? scnt[src] : 0;
-    st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
+    if (KEEP) spcnt[dst] = nprev + 1;
+    else st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
     RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
     sink.rows[row_base + ord] = rr;
   }
   if (lane == 0) {
     st.beam_n[(size_t)nxt * U + u] = keep;
-    st.utt_step[u] = step + 1;
+    if (KEEP) *reinterpret_cast<int*>(set_nxt + L.off_nb) = keep;
+    else st.utt_step[u] = step + 1;
     atomicMax(&st.counters[3], (unsigned long long)Kmaxseen);
     atomicAdd(&st.counters[0], (unsigned long long)nlead);
     atomicAdd(&st.counters[1], (unsigned long long)keep);
@@ -1575,7 +1668,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
   if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
   if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
-  select_fast_body<256, false>(m, st, par, u, smem_raw, RowSink{st.rows, st.nrows + par});
+  select_fast_body<256, false, false>(m, st, par, u, smem_raw, RowSink{st.rows, st.nrows + par});
 }
 
 // ------------------------------------------------------------ resident decode
@@ -1598,7 +1691,7 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
 // hanging; the host then reports an error.
 
 #define UIS_RES_RC 3           // row tiles per pass
-#define UIS_RES_HEAD_TILES 32  // row tiles whose descriptors are staged in LDS at a time
+#define UIS_RES_HEAD_TILES 24  // row tiles whose descriptors are staged in LDS at a time (even)
 
 __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, uint32_t target, int* s_abort) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
@@ -1771,8 +1864,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   int* s_ctl = reinterpret_cast<int*>(spart + UIS_KSPLIT * RC * 3 * 256);  // [0] abort  [1] steps
   f32x4* s_w1 = reinterpret_cast<f32x4*>(s_ctl + 16);                         // [NKB][64] this rank's linear_mean1 tile
   f32x4* s_w2 = s_w1 + NKB * 64;                                             // [NKB][64] ... linear_mean2 tile
-  u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);                  // [32 tiles x 16] {utt, src, dst, nprev}
-  long* s_frame = reinterpret_cast<long*>(s_head + UIS_RES_HEAD_TILES * 16);  // [32 tiles x 16]
+  u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);                  // [head tiles x 16] {utt, src, dst, nprev}
+  long* s_frame = reinterpret_cast<long*>(s_head + UIS_RES_HEAD_TILES * 16);  // [head tiles x 16]
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -1781,6 +1874,9 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ctl[0] = 0;
     s_ctl[1] = 0;
+#if defined(UIS_RESIDENT_TIMING) || defined(UIS_RESIDENT_PROBE)
+    for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k] = 0;
+#endif
   }
   __syncthreads();
   {  // decode steps of this cluster = the longest of its utterances
@@ -1825,6 +1921,9 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
+  const bool keep_beam = U <= 256;
+  long my_off0 = 0, my_off1 = 0;
+  if (keep_beam && cluster + 8 * rank < U) { my_off0 = (long)st.off[cluster + 8 * rank]; my_off1 = (long)st.off[cluster + 8 * rank + 1]; }
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rt_prev = wall_clock64();
@@ -1835,9 +1934,34 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
     sink.count = st.rx_nrows + cluster * 32 + par;
-    for (int i = rank; cluster + 8 * i < U; i += 32) {
-      select_fast_body<512, true>(m, st, par, cluster + 8 * i, smem_raw, sink);
+#if defined(UIS_RESIDENT_PROBE)  // diagnostic: dependent-load latencies seen by thread 0 at the top of a step
+    if (t == 0 && blockIdx.x == 0) {
+      unsigned long long* pa = reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64);
+      const unsigned long long c0 = __builtin_readcyclecounter();
+      const int v0 = __builtin_nontemporal_load(st.utt_step + cluster);          // written by this CU last step
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long c1 = __builtin_readcyclecounter();
+      const float v1 = __hip_atomic_load(st.pool_mean + ((size_t)cluster * S) * m.Dp + (s & 63) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long c2 = __builtin_readcyclecounter();
+      const float v2 = m.wgt[(s & 7) * 32];                                      // immutable, tiny, hot
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long c3 = __builtin_readcyclecounter();
+      const float v3 = m.wgt[(s & 7) * 32 + 1];                                  // same line again: L1 hit
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long c4 = __builtin_readcyclecounter();
+      asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+      pa[0] += c1 - c0; pa[1] += c2 - c1; pa[2] += c3 - c2; pa[3] += c4 - c3;
+    }
+#endif
+    if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
+      if (cluster + 8 * rank < U) select_fast_body<512, true, true>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
       __syncthreads();
+    } else {
+      for (int i = rank; cluster + 8 * i < U; i += 32) {
+        select_fast_body<512, true, false>(m, st, par, cluster + 8 * i, smem_raw, sink);
+        __syncthreads();
+      }
     }
     RSTAMP(0);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
@@ -1996,11 +2120,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
+#if defined(UIS_RESIDENT_PROBE)
+  if (t == 0 && blockIdx.x == 0)
+    for (int k = 0; k < 8; ++k) st.counters[80 + k] = reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k];
+#endif
 #if defined(UIS_RESIDENT_TIMING)
   if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
   {
     for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
     if (blockIdx.x == 248) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
+    if (blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k];
   }
 #endif
 }
