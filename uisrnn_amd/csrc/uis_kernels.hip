@@ -1203,7 +1203,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {  //
 
 struct FastLds {
   int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_score, off_nb, set_stride;
-  int off_base, off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc, off_pcnt;
+  int off_base, off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc, off_pcnt, off_cand;
   int total;
 };
 // The beam tables (slot, blk, K, last, sum, score, nb) form a SET; there are two of them so that
@@ -1234,6 +1234,7 @@ __host__ __device__ inline FastLds fast_lds_layout(int Dp, int B, int Kmax, int 
   l.off_wscore = take(64 * 4);
   l.off_misc = take(64 * 4);  // [0] nlive [1] nfinite; [16..31] phase clocks of the timing build
   l.off_pcnt = take(S * 4);   // resident decode: frames per slot (what pool_cnt holds), kept across steps
+  l.off_cand = take(256 * 4);  // candidate i -> (hypothesis << 16) | cluster
   l.total = o;
   return l;
 }
@@ -1263,7 +1264,8 @@ struct RowSink {
 // counts stay in LDS from one step to the next -- a step reads table set `par` and writes set
 // `par ^ 1` -- so the only global state a select reads back is the cluster means; the caller
 // passes the step number and the utterance's frame range.
-template <int NT, bool RES, bool KEEP>
+// DPT: the padded observation_dim when the caller knows it at compile time (0 = read m.Dp).
+template <int NT, bool RES, bool KEEP, int DPT = 0>
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
                                                  unsigned char* smem_raw, RowSink sink, int step_in = 0,
                                                  long off0_in = 0, long off1_in = 0) {
@@ -1296,6 +1298,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
   float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
   int* spcnt = reinterpret_cast<int*>(smem_raw + L.off_pcnt);
+  unsigned* scand = reinterpret_cast<unsigned*>(smem_raw + L.off_cand);
   int* sbase = reinterpret_cast<int*>(smem_raw + L.off_base);
   int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
   int* slivelist = reinterpret_cast<int*>(smem_raw + L.off_livelist);
@@ -1364,6 +1367,12 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     const int b = e / Kmax, c = e - b * Kmax;
     if (c < sK[b]) slive[sslot[e]] = 1;
   }
+  // candidate i = sbase[b] + c  ->  (b, c): one LDS word per candidate instead of a search
+  // over the prefix sums wherever a candidate index has to be decoded
+  if (tid < nb * (Kmax + 1)) {  // <= 256 <= NT (select_fast_ok)
+    const int b = tid / (Kmax + 1), c = tid - b * (Kmax + 1);
+    if (c <= sK[b]) scand[sbase[b] + c] = ((unsigned)b << 16) | (unsigned)c;
+  }
   __syncthreads();  // (2) live flags
   for (int base = 0; base < S; base += NT) {  // compaction: ballot per wave, one LDS atomic per wave
     const int sl = base + tid;
@@ -1384,23 +1393,25 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   int my_b = 0, my_c = 0;
   double my_lb = 0.0, my_ld = 0.0;
   if (tid < C) {
-    for (int j2 = 1; j2 < nb; ++j2) my_b += tid >= sbase[j2];  // independent LDS reads
-    my_c = tid - sbase[my_b];
+    const unsigned bc = scand[tid];
+    my_b = (int)(bc >> 16);
+    my_c = (int)(bc & 0xffffu);
     my_ld = st.logden[ssum[my_b]];
     if (my_c < sK[my_b] && my_c != slast[my_b]) my_lb = st.logblk[sblk[my_b * Kmax + my_c]];
   }
-  const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
+  const int Dp = DPT ? DPT : m.Dp;
+  const float* pmean = st.pool_mean + (size_t)u * S * Dp;
   const __amdgpu_buffer_rsrc_t rs_mean =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
-  const float* xrow = st.x + (size_t)frame * m.Dp;
+  const float* xrow = st.x + (size_t)frame * Dp;
   {
     const int grp = tid >> 4, p = tid & 15;
-    if (m.Dp <= 256) {  // one 256-float chunk: keep the frame in registers, two slots per lane in flight
+    if (Dp <= 256) {  // one 256-float chunk: keep the frame in registers, two slots per lane in flight
       f32x4 xv[4], wv[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int d = 4 * (p + 16 * k);
-        const bool in = d < m.Dp;
+        const bool in = d < Dp;
         xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         wv[k] = in ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
@@ -1414,13 +1425,13 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
         }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-          const float* mean = pmean + (size_t)sl[h2] * m.Dp;
+          const float* mean = pmean + (size_t)sl[h2] * Dp;
           cnt[h2] = (p == 0) ? (KEEP ? spcnt[sl[h2]] : st.pool_cnt[(size_t)u * S + sl[h2]]) : 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
-            if (d >= m.Dp) mv[h2][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            else if (RES) mv[h2][k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl[h2]) * m.Dp + d) * 4));
+            if (d >= Dp) mv[h2][k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            else if (RES) mv[h2][k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl[h2]) * Dp + d) * 4));
             else mv[h2][k] = *reinterpret_cast<const f32x4*>(mean + d);
           }
         }
@@ -1430,7 +1441,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
-            if (d < m.Dp) {
+            if (d < Dp) {
 #pragma unroll
               for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[h2][k][e2], xv[k][e2], wv[k][e2]);
             }
@@ -1447,25 +1458,25 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
         const int i = i0 + grp;
         const bool act = i < nlive;
         const int sl = slivelist[act ? i : 0];
-        const float* mean = pmean + (size_t)sl * m.Dp;
+        const float* mean = pmean + (size_t)sl * Dp;
         const int cnt = (p == 0) ? (KEEP ? spcnt[sl] : st.pool_cnt[(size_t)u * S + sl]) : 0;
         float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float first_sq = 0.0f;
-        for (int q = 0; q < m.Dp; q += 256) {
+        for (int q = 0; q < Dp; q += 256) {
           f32x4 mv[4], xv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
-            const bool in = d < m.Dp;
+            const bool in = d < Dp;
             if (!in) mv[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            else if (RES) mv[k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl) * m.Dp + d) * 4));
+            else if (RES) mv[k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl) * Dp + d) * 4));
             else mv[k] = *reinterpret_cast<const f32x4*>(mean + d);
             xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
-            if (d < m.Dp) {
+            if (d < Dp) {
               const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
 #pragma unroll
               for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
@@ -1547,10 +1558,8 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     // uisrnn.py:66-69) while wave 0 works out the changed ones
     for (int e = tid - 64; e < keep * Kmax; e += NT - 64) {
       const int rr = e / Kmax, c2 = e - rr * Kmax;
-      const int i = swin[rr];
-      int rb = 0;
-      for (int j2 = 1; j2 < nb; ++j2) rb += i >= sbase[j2];
-      const int rc = i - sbase[rb];
+      const unsigned bc = scand[swin[rr]];
+      const int rb = (int)(bc >> 16), rc = (int)(bc & 0xffffu);
       const int Knew = sK[rb] + (rc == sK[rb] ? 1 : 0);
       if (c2 < Knew && c2 != rc) {
         if (KEEP) {
@@ -1572,9 +1581,9 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const bool isw = r < keep;
   int wb = 0, wc = 0, src = -2, Kb = 0;
   if (isw) {
-    const int i = swin[r];
-    for (int j2 = 1; j2 < nb; ++j2) wb += i >= sbase[j2];
-    wc = i - sbase[wb];
+    const unsigned bc = scand[swin[r]];
+    wb = (int)(bc >> 16);
+    wc = (int)(bc & 0xffffu);
     Kb = sK[wb];
     src = wc < Kb ? sslot[wb * Kmax + wc] : -1;
   }
@@ -1955,11 +1964,11 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     }
 #endif
     if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
-      if (cluster + 8 * rank < U) select_fast_body<512, true, true>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
+      if (cluster + 8 * rank < U) select_fast_body<512, true, true, DP>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
       __syncthreads();
     } else {
       for (int i = rank; cluster + 8 * i < U; i += 32) {
-        select_fast_body<512, true, false>(m, st, par, cluster + 8 * i, smem_raw, sink);
+        select_fast_body<512, true, false, DP>(m, st, par, cluster + 8 * i, smem_raw, sink);
         __syncthreads();
       }
     }
