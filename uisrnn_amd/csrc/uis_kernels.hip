@@ -1715,6 +1715,7 @@ __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, 
     unsigned spins = 0;
     int bad = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);  // 32 pollers per counter: a short nap between polls measured +1.5 %
       if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
         __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bad = 1;
@@ -1750,9 +1751,11 @@ __device__ __forceinline__ float load_f32_sc1(const float* p) {
 
 // NV (<= RC) row tiles x NG gates of one feature tile, weights from registers: wave w walks its
 // K segment (PER k-blocks), partial tiles to LDS [UIS_KSPLIT][RC][NG][256], ends with the
-// barrier.  The rows are requested k-block-major so that the first MFMAs need only the first NV
-// loads and the rest of the stream (every CU of the XCD reads all rows, ~100 GB/s per CU out of
-// L2) arrives underneath the MFMA chain.
+// barrier.  Every CU of the XCD reads all rows (~100 GB/s per CU out of L2): that stream, not
+// the MFMA chain, bounds a stage.  Measured and NOT adopted: pinning the request order with
+// scheduling fences (k-block-major or row-tile-major) and making every load unconditional so
+// that the vmcnt bookkeeping is exact -- both 3-10 % slower end to end than what the compiler
+// schedules from this plain form.
 // KBS = bytes between a row's consecutive k-blocks (64: a plain row; 1024: the k-block-major
 // staging layout).  `after_issue` runs once the row loads are in flight: loads it issues are
 // younger in the in-order vmcnt queue, so the MFMA chain never waits for them.
