@@ -207,9 +207,11 @@ def main():
       # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
       kernel = 'k_decode_resident'
       flop_per_launch = 2.0 * (3 * hid * hid + hid * hid + dim * hid) * prof['rnn_rows_nodedup']
-      # weights once + per row: h in, gi0 in (3H), h' out, a1 out/in, mean in/out
+      # SURVEY.md 8(d), per decode step and utterance: x_t, the candidates' means, the winners'
+      # h / mean in and out, back-pointers = 4D(1 + B*K + 2B) + 8*H*B + 8B with K = 4 clusters;
+      # the weights once.  (Served by the XCD's L2 for the most part: `traffic` is what reached HBM.)
       algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) +
-                       prof['rnn_rows_nodedup'] * 4 * (hid + 3 * hid + hid + 2 * hid + 2 * dim))
+                       n_utt * n_steps * (4 * dim * (1 + beam * 4 + 2 * beam) + 8 * hid * beam + 8 * beam))
     else:
       # one launch = one step's hidden-side GRU matvecs (3H x H MACs per surviving hypothesis)
       kernel = 'k_dense_gru'

@@ -24,10 +24,23 @@ def run(name, dim, hid, n_utt, n_frames, beam, look, tau, cap, flags=0, reps=2):
                     'cand_per_step': round(st['candidates'] / n, 1), 'maxK': st['max_clusters_seen'],
                     'kernel_us': {k: round(1e3 * v / n, 2) for k, v in prof['kernel_ms'].items() if v}}), flush=True)
 
+STEP = _capi.UIS_FLAG_STEPWISE
 which = sys.argv[1:] or ['c3', 'c5', 'c4']
+if 'c2' in which:
+  run('configs[1]: 64 utt x 500 frames, beam 10', 256, 512, 64, 500, 10, 1, 2, 16)
+  run('configs[1], launch-per-step path', 256, 512, 64, 500, 10, 1, 2, 16, flags=STEP)
+if 'small' in which:
+  run('1 utt x 500 frames, beam 10', 256, 512, 1, 500, 10, 1, 2, 16)
+  run('1 utt x 500 frames, launch-per-step path', 256, 512, 1, 500, 10, 1, 2, 16, flags=STEP)
+  run('8 utt x 500 frames, beam 10', 256, 512, 8, 500, 10, 1, 2, 16)
+  run('8 utt x 500 frames, launch-per-step path', 256, 512, 8, 500, 10, 1, 2, 16, flags=STEP)
+  run('256 utt x 200 frames, beam 10', 256, 512, 256, 200, 10, 1, 2, 16)
+  run('256 utt x 200 frames, launch-per-step path', 256, 512, 256, 200, 10, 1, 2, 16, flags=STEP)
 if 'c3' in which:
   run('configs[2]: beam 50, look_ahead 2, 16 utt x 200 frames', 256, 512, 16, 200, 50, 2, 2, 12)
 if 'c5' in which:
-  run('configs[4]: D=512 H=512 beam 20, 64 utt x 200 frames', 512, 512, 64, 200, 20, 1, 2, 12)
+  run('configs[4]: D=512 H=512 beam 20, 64 utt x 200 frames', 512, 512, 64, 200, 20, 1, 2, 11)
+  run('configs[4], launch-per-step path', 512, 512, 64, 200, 20, 1, 2, 11, flags=STEP)
 if 'c4' in which:
   run('configs[3] per-GPU share: 1024 utt x 200 frames, beam 10', 256, 512, 1024, 200, 10, 1, 2, 16)
+  run('configs[3] per-GPU share, launch-per-step path', 256, 512, 1024, 200, 10, 1, 2, 16, flags=STEP)
