@@ -106,6 +106,11 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */
+#define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
+                                    a wrong XCD, as if the (observed, not promised) workgroup
+                                    placement had changed.  The call must then fall back to the
+                                    launch-per-step path by itself -- and stay there for this
+                                    handle -- or, with UIS_FLAG_RESIDENT, fail with UIS_ERR_HIP */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

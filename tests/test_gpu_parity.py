@@ -232,6 +232,21 @@ def test_resident_decode_is_bit_identical(oracle_lib):
     d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
 
 
+def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):
+  """The one-launch decode verifies its own assumptions (XCD placement, barrier progress); a
+  failed check must cost a re-run on the launch-per-step path, not an error or a wrong answer."""
+  params = synth.tracker_params(256, 512, 1, seed=9)
+  seqs, _ = synth.make_utterances(9100, 10, [40, 12, 33, 64, 5, 21, 50, 17, 30, 8], 256)
+  dec = _capi.Decoder(params)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec,
+           flags=_capi.UIS_FLAG_NO_DEDUP | _capi.UIS_FLAG_TEST_MISPLACED)
+  st = dec.decode(*oracle_lib.pack(seqs), 10, 1, 2, flags=_capi.UIS_FLAG_PROFILE)['stats']
+  assert st['kernel_launches']['select'] > 0          # this handle now stays on the per-step path
+  with pytest.raises(_capi.HipLibraryError):          # demanded explicitly: the failure is reported
+    _capi.Decoder(params).decode(*oracle_lib.pack(seqs), 10, 1, 2,
+                                 flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_TEST_MISPLACED)
+
+
 def _many_cluster_case():
   """Untrained weights + a large crp_alpha open clusters freely (31 in 40 frames)."""
   from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel

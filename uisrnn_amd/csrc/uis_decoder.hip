@@ -88,6 +88,9 @@ struct uis_handle {
   std::vector<void*> model_allocs;
   double alpha = 1.0;
   int n_cu = 0;  // compute units of the device
+  // the one-launch decode relies on observed, not promised, placement (workgroup b on XCD b % 8,
+  // all 256 workgroups resident); when its own checks fail once, this handle stops using it
+  bool inlaunch_failed = false, resident_off = false;
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
@@ -300,7 +303,7 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
   return UIS_OK;
 }
 
-int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
+int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
   if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
   const DevModel& m = h->m;
@@ -441,7 +444,7 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                            resident_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024;
   // the default wherever it applies; UIS_FLAG_STEPWISE (or any of the per-step experiments) keeps
   // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
-  const bool resident = resident_ok && !use_graph &&
+  const bool resident = resident_ok && !use_graph && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                         !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW));
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 512 (padded), "
@@ -643,9 +646,11 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   uint32_t abort_word = 0;
   HIPCHK(hipMemcpyAsync(&abort_word, h->cluster_ctl.as<uint32_t>() + 8 * 16 + 8, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (abort_word)
+  if (abort_word) {
+    h->inlaunch_failed = true;
     return fail(UIS_ERR_HIP, abort_word == 2 ? "workgroup cluster not placed on one XCD (in-launch barrier path)"
                                              : "in-launch barrier timed out");
+  }
 #if defined(UIS_SELECT_TIMING)
   {
     unsigned long long tc[48];
@@ -713,6 +718,20 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     return fail(UIS_ERR_CLUSTER_CAP, std::to_string(n_over) + " utterance(s) needed more than max_clusters=" +
                                          std::to_string(Kmax) + " clusters per hypothesis");
   return UIS_OK;
+}
+
+// One decode; if the one-launch path was chosen automatically and its placement / barrier checks
+// failed, repeat on the launch-per-step path and stay there for this handle.
+int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
+                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
+  if (h) h->inlaunch_failed = false;
+  int rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats);
+  if (rc == UIS_ERR_HIP && h && h->inlaunch_failed && opts &&
+      !(opts->flags & (UIS_FLAG_RESIDENT | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW))) {
+    h->resident_off = true;
+    rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats);
+  }
+  return rc;
 }
 
 }  // namespace
