@@ -303,10 +303,26 @@ def case_tracker_long(uisrnn):
   return params, seqs, runs, False
 
 
+CHECKPOINT_CASE = 'd20_h24_depth3'  # depth 3, non-zero rnn_init_hidden
+
+
+def write_reference_checkpoint(uisrnn):
+  """<case>.uisrnn: the case's model written by the REFERENCE's own UISRNN.save()
+  (uisrnn/uisrnn.py:135-147) -- the file format uisrnn_amd.weights reads without torch."""
+  params = CASES[CHECKPOINT_CASE](uisrnn)[0]
+  model, _ = reference_model(uisrnn, params)
+  path = os.path.join(HERE, CHECKPOINT_CASE + '.uisrnn')
+  model.save(path)
+  print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def main():
   uisrnn = import_reference()
   import torch  # pylint: disable=import-outside-toplevel
   torch.set_num_threads(1)
+  if sys.argv[1:] == ['--checkpoint']:
+    write_reference_checkpoint(uisrnn)
+    return
   names = sys.argv[1:] or list(CASES)
   for name in names:
     params, seqs, runs, store_inputs = CASES[name](uisrnn)

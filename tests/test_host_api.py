@@ -183,6 +183,73 @@ def test_params_round_trips(tmp_path):
   model.save(str(tmp_path / 'again.uisrnn'))
 
 
+def _same_params(a, b):
+  for key, val in a.items():
+    if isinstance(val, list):
+      assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(val, b[key])), key
+    elif isinstance(val, np.ndarray):
+      assert np.array_equal(val, b[key]) and val.dtype == b[key].dtype, key
+    else:
+      assert val == b[key], key
+
+
+def test_reference_checkpoint_is_read_without_torch(monkeypatch):
+  """tests/golden/d20_h24_depth3.uisrnn was written by the REFERENCE's UISRNN.save()
+  (tests/golden/make_golden.py --checkpoint); it must load with torch unimportable and give
+  exactly the parameters the golden case was generated from."""
+  import golden_util
+  path = os.path.join(golden_util.GOLDEN_DIR, 'd20_h24_depth3.uisrnn')
+  expect = golden_util.load_case('d20_h24_depth3')['params']
+  monkeypatch.setitem(sys.modules, 'torch', None)   # `import torch` now raises ImportError
+  with pytest.raises(ImportError):
+    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  got = weights.load_checkpoint(path)
+  assert got['rnn_depth'] == 3 and got['rnn_hidden_size'] == 24 and got['observation_dim'] == 20
+  assert np.abs(got['rnn_init_hidden']).max() > 0
+  for key in ('gru_weight_ih', 'gru_weight_hh', 'gru_bias_ih', 'gru_bias_hh', 'linear_mean1_weight',
+              'linear_mean1_bias', 'linear_mean2_weight', 'linear_mean2_bias', 'rnn_init_hidden', 'sigma2'):
+    a, b = got[key], expect[key]
+    if isinstance(a, list):
+      assert all(np.array_equal(x, np.asarray(y, dtype=np.float32)) for x, y in zip(a, b)), key
+    else:
+      assert np.array_equal(a, np.asarray(b, dtype=np.float32).reshape(a.shape)), key
+  assert got['transition_bias'] == pytest.approx(float(expect['transition_bias']))
+  assert got['crp_alpha'] == pytest.approx(float(expect['crp_alpha']))
+
+
+def test_torch_free_reader_matches_torch_load(tmp_path):
+  import pickle
+  import torch
+  params = weights.init_params(7, 9, 2, sigma2=0.2, transition_bias=0.4, seed=8)
+  path = str(tmp_path / 'm.uisrnn')
+  weights.save_checkpoint(params, path)
+  raw = torch.load(path, weights_only=False)
+  via_torch = weights.params_from_state(raw['rnn_state_dict'], raw['rnn_init_hidden'], raw['sigma2'],
+                                        raw['transition_bias'], raw['crp_alpha'],
+                                        raw['transition_bias_denominator'])
+  _same_params(via_torch, weights.load_checkpoint(path))
+  # views: transposed, offset into a shared storage, 0-d, other dtypes
+  base = torch.arange(24, dtype=torch.float32).reshape(4, 6)
+  obj = {'t': base.t(), 'window': base[1:3, 2:5], 'scalar': torch.tensor(3.5),
+         'long': torch.arange(5), 'half': torch.ones(3, dtype=torch.float16), 'list': [base[0], 'text', 7]}
+  torch.save(obj, str(tmp_path / 'views.pt'))
+  got = weights.read_torch_zip(str(tmp_path / 'views.pt'))
+  assert np.array_equal(got['t'], base.t().numpy()) and got['t'].flags['C_CONTIGUOUS']
+  assert np.array_equal(got['window'], base[1:3, 2:5].numpy())
+  assert float(got['scalar']) == 3.5 and got['long'].dtype == np.int64 and got['half'].dtype == np.float16
+  assert np.array_equal(got['list'][0], base[0].numpy()) and got['list'][1:] == ['text', 7]
+  # nothing outside a checkpoint's vocabulary is ever resolved, let alone called
+
+  class Evil:
+    def __reduce__(self):
+      return (os.system, ('true',))
+  torch.save({'x': Evil()}, str(tmp_path / 'evil.pt'))
+  with pytest.raises(pickle.UnpicklingError):
+    weights.read_torch_zip(str(tmp_path / 'evil.pt'))
+  with pytest.raises(ValueError):
+    weights.read_torch_zip(__file__)
+
+
 def test_synthetic_generators_are_deterministic():
   a, ida = synth.make_utterance(7, 50, 32)
   b, idb = synth.make_utterance(7, 50, 32)

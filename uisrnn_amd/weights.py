@@ -14,7 +14,8 @@ host keeps a dict:
   transition_bias, crp_alpha                             python floats
   transition_bias_denominator                            float (carried for save())
 
-PyTorch is used only to read / write the reference's checkpoint format.
+Checkpoints in the reference's torch.save format are READ without PyTorch
+(read_torch_zip); writing one (save_checkpoint) still uses torch.save.
 """
 
 import numpy as np
@@ -128,17 +129,126 @@ def state_dict_from_params(params):
   return out
 
 
+# ---------------------------------------------------------------------------
+# Reading the reference's checkpoint WITHOUT PyTorch.
+#
+# torch.save (zip format, torch >= 1.6) writes <name>/data.pkl -- a protocol-2
+# pickle in which every tensor is torch._utils._rebuild_tensor_v2(storage,
+# offset, size, stride, ...) and every storage a persistent id
+# ('storage', torch.<T>Storage, key, device, numel) -- plus one raw
+# little-endian file <name>/data/<key> per storage.  The numpy members of the
+# reference's dict (rnn_init_hidden, sigma2) are ordinary numpy pickles.
+# The unpickler below resolves exactly the globals such a file needs and
+# nothing else, so loading a checkpoint cannot run arbitrary code.
+
+_STORAGE_DTYPES = {
+    'FloatStorage': np.float32, 'DoubleStorage': np.float64,
+    'HalfStorage': np.float16, 'LongStorage': np.int64,
+    'IntStorage': np.int32, 'ShortStorage': np.int16,
+    'CharStorage': np.int8, 'ByteStorage': np.uint8, 'BoolStorage': np.bool_,
+}
+
+
+class _StorageType:
+  def __init__(self, name):
+    self.dtype = np.dtype(_STORAGE_DTYPES[name])
+
+
+def _rebuild_tensor_v2(storage, storage_offset, size, stride, *unused):
+  size, stride = tuple(size), tuple(stride)
+  if not size:
+    return storage[storage_offset].copy()
+  view = np.lib.stride_tricks.as_strided(
+      storage[storage_offset:], shape=size,
+      strides=tuple(s * storage.itemsize for s in stride))
+  return np.array(view, order='C')  # own, contiguous copy
+
+
+def _rebuild_parameter(data, requires_grad, backward_hooks, *unused):
+  return data
+
+
+def read_torch_zip(filepath):
+  """The object stored by torch.save(obj, filepath), tensors as numpy arrays.
+
+  Pure Python (zipfile + a restricted pickle.Unpickler); raises ValueError for
+  files that are not torch zip archives and pickle.UnpicklingError for pickles
+  that reference anything outside a checkpoint's vocabulary.
+  """
+  import collections  # pylint: disable=import-outside-toplevel
+  import pickle       # pylint: disable=import-outside-toplevel
+  import zipfile      # pylint: disable=import-outside-toplevel
+  if not zipfile.is_zipfile(filepath):
+    raise ValueError('{} is not a torch zip checkpoint'.format(filepath))
+  with zipfile.ZipFile(filepath) as archive:
+    names = archive.namelist()
+    pkl = [n for n in names if n.endswith('/data.pkl') or n == 'data.pkl']
+    if len(pkl) != 1:
+      raise ValueError('{}: no data.pkl inside'.format(filepath))
+    prefix = pkl[0][:-len('data.pkl')]
+    byteorder = 'little'
+    if prefix + 'byteorder' in names:
+      byteorder = archive.read(prefix + 'byteorder').decode().strip()
+    storages = {}
+
+    def persistent_load(pid):
+      if not (isinstance(pid, tuple) and pid and pid[0] == 'storage'):
+        raise pickle.UnpicklingError('unexpected persistent id')
+      storage_type, key, numel = pid[1], pid[2], pid[4]
+      if key not in storages:
+        raw = archive.read('{}data/{}'.format(prefix, key))
+        dtype = storage_type.dtype.newbyteorder(
+            '<' if byteorder == 'little' else '>')
+        arr = np.frombuffer(raw, dtype=dtype, count=int(numel))
+        storages[key] = arr.astype(storage_type.dtype, copy=False)
+      return storages[key]
+
+    import numpy.core.multiarray as _np_multiarray  # noqa: alias of numpy._core
+    allowed = {
+        ('collections', 'OrderedDict'): collections.OrderedDict,
+        ('torch._utils', '_rebuild_tensor_v2'): _rebuild_tensor_v2,
+        ('torch._utils', '_rebuild_parameter'): _rebuild_parameter,
+        ('numpy', 'ndarray'): np.ndarray,
+        ('numpy', 'dtype'): np.dtype,
+        ('numpy.core.multiarray', '_reconstruct'): _np_multiarray._reconstruct,
+        ('numpy._core.multiarray', '_reconstruct'): _np_multiarray._reconstruct,
+        ('numpy.core.multiarray', 'scalar'): _np_multiarray.scalar,
+        ('numpy._core.multiarray', 'scalar'): _np_multiarray.scalar,
+        ('_codecs', 'encode'): __import__('_codecs').encode,
+    }
+
+    class _Unpickler(pickle.Unpickler):
+      def find_class(self, module, name):
+        if module == 'torch' and name in _STORAGE_DTYPES:
+          return _StorageType(name)
+        try:
+          return allowed[(module, name)]
+        except KeyError:
+          raise pickle.UnpicklingError(
+              'checkpoint refers to {}.{}, which a uis-rnn checkpoint does '
+              'not need'.format(module, name)) from None
+
+    import io  # pylint: disable=import-outside-toplevel
+    unpickler = _Unpickler(io.BytesIO(archive.read(pkl[0])))
+    unpickler.persistent_load = persistent_load
+    return unpickler.load()
+
+
 def load_checkpoint(filepath):
   """Read a checkpoint written by the reference's UISRNN.save().
 
   Format (uisrnn/uisrnn.py:141-147): torch.save of a dict with keys
   rnn_state_dict, rnn_init_hidden (numpy), transition_bias,
-  transition_bias_denominator, crp_alpha, sigma2 (numpy).  The numpy members
-  need weights_only=False on torch >= 2.6 (the reference's own load() at
-  uisrnn/uisrnn.py:155 fails there).
+  transition_bias_denominator, crp_alpha, sigma2 (numpy).  Read without
+  PyTorch (read_torch_zip); only the pre-1.6 non-zip format still goes through
+  torch.load (weights_only=False: the numpy members make the reference's own
+  load() at uisrnn/uisrnn.py:155 fail on torch >= 2.6).
   """
-  import torch  # pylint: disable=import-outside-toplevel
-  var_dict = torch.load(filepath, map_location='cpu', weights_only=False)
+  try:
+    var_dict = read_torch_zip(filepath)
+  except ValueError:
+    import torch  # pylint: disable=import-outside-toplevel
+    var_dict = torch.load(filepath, map_location='cpu', weights_only=False)
   return params_from_state(
       var_dict['rnn_state_dict'], var_dict['rnn_init_hidden'],
       var_dict['sigma2'], var_dict['transition_bias'], var_dict['crp_alpha'],
