@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UIS_ABI_VERSION 1
+#define UIS_ABI_VERSION 2
 
 typedef enum uis_status {
   UIS_OK = 0,
@@ -208,6 +208,30 @@ int32_t uis_model_constants(uis_handle* h, float* m0_out, float* h1_out);
  * pointers).  Unit-level entry point for parity tests; the decode does not call it.
  */
 int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in, float* mean_out, float* h_out);
+
+/*
+ * Online decoding (the caller side of the path: UIS-RNN is an online model; the reference
+ * only offers offline predict(), uisrnn/uisrnn.py:479-590, with the test_iteration replay).
+ * A session keeps the beam, the cluster states and the back-pointers of n_utt utterances on
+ * the device.  Semantics = predict_single with test_iteration 1 and look_ahead 1: whatever the
+ * chunking, the labels and scores equal those of one uis_decode over the whole utterances
+ * (bit for bit).  One session per handle; uis_decode is refused while it is open.
+ *
+ *   uis_stream_begin  opts->test_iteration and look_ahead must be 1; max_frames = the most frames
+ *                     any utterance will receive in this session (4 * beam_size bytes each)
+ *   uis_stream_push   frames: host float32, the new frames of utterance 0, then 1, ...;
+ *                     counts[u] >= 0 = how many of them belong to utterance u (0 is fine)
+ *   uis_stream_labels labels_out: host int32, for every utterance all frames received so far
+ *                     (packed in utterance order) under the currently best hypothesis -- earlier
+ *                     labels may still change with later frames, as in any beam search;
+ *                     scores_out [n_utt] / overflow_out [n_utt] or NULL.  Returns
+ *                     UIS_ERR_CLUSTER_CAP (labels still written) if a cap was hit.
+ *   uis_stream_end    frees the session
+ */
+int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_decode_opts* opts, int64_t max_frames);
+int32_t uis_stream_push(uis_handle* h, const float* frames, const int32_t* counts);
+int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* scores_out, int32_t* overflow_out);
+int32_t uis_stream_end(uis_handle* h);
 
 const char* uis_last_error(void);
 

@@ -1,0 +1,178 @@
+"""Online decoding (uis_stream_*): any chunking == one offline decode, bit for bit.
+
+The reference has no streaming entry point; the contract tested here is the one stated in
+include/uisrnn_hip.h: a session that has received an utterance's frames in whatever pieces
+holds exactly the beam of predict_single(test_iteration=1) over those frames
+(uisrnn/uisrnn.py:479-562) -- labels, best score, the whole final beam.  The offline side is
+checked against the CPU oracle as well.
+"""
+
+import numpy as np
+import pytest
+
+from uisrnn_amd import _capi
+from uisrnn_amd import synth
+from uisrnn_amd import weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+  return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _stream(dec, seqs, beam, schedule, max_frames, max_clusters=0, check_every_push=None):
+  """schedule: list of per-push lists of frame counts (one per utterance)."""
+  dec.stream_begin(len(seqs), beam, max_frames, max_clusters=max_clusters)
+  try:
+    pos = [0] * len(seqs)
+    for counts in schedule:
+      chunks = []
+      for u, n in enumerate(counts):
+        chunks.append(seqs[u][pos[u]:pos[u] + n] if n else None)
+        pos[u] += n
+      dec.stream_push(chunks)
+      if check_every_push is not None:
+        check_every_push(dec, pos)
+    assert pos == [len(s) for s in seqs], 'schedule does not cover the utterances'
+    labels, scores, overflow, status = dec.stream_labels()
+    info = np.empty((len(seqs), beam), dtype=np.float32)
+    dec._check(dec._lib.uis_last_decode_info(dec._handle, None, info.ctypes.data_as(_capi._fp)), 'info')
+    return labels, scores, overflow, status, info
+  finally:
+    dec.stream_end()
+
+
+def _offline(dec, seqs, beam, max_clusters=0):
+  lens = [len(s) for s in seqs]
+  offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+  frames = np.concatenate(seqs).astype(np.float32)
+  out = dec.decode(frames, offsets, beam, 1, 1, max_clusters=max_clusters, want_beam_scores=True)
+  return out, offsets
+
+
+def _random_schedule(rng, lens, max_chunk):
+  left = list(lens)
+  schedule = []
+  while any(left):
+    counts = []
+    for u, n in enumerate(left):
+      take = int(min(n, rng.integers(0, max_chunk + 1)))   # 0 = this utterance is silent in this push
+      counts.append(take)
+      left[u] -= take
+    if any(counts):
+      schedule.append(counts)
+  return schedule
+
+
+@pytest.mark.parametrize('max_chunk', [1, 7, 40])
+def test_any_chunking_equals_offline_decode(max_chunk, oracle_lib):
+  params = synth.tracker_params(256, 512, 1, seed=21)
+  lens = [60, 33, 1, 90, 17, 45, 72, 8, 64]
+  seqs, _ = synth.make_utterances(12_000, len(lens), lens, 256)
+  dec = _capi.Decoder(params)
+  off, offsets = _offline(dec, seqs, 10)
+  ref = oracle_lib.decode(params, seqs, 10, 1, 1, n_threads=8)
+  rng = np.random.default_rng(max_chunk)
+  labels, scores, overflow, status, beam = _stream(dec, seqs, 10, _random_schedule(rng, lens, max_chunk), 100)
+  assert status == 0 and not overflow.any()
+  for u in range(len(seqs)):
+    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
+    assert np.array_equal(labels[u], ref['labels'][u]), u
+  assert np.array_equal(_bits(scores), _bits(off['scores']))
+  assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
+  assert np.array_equal(_bits(beam), _bits(ref['beam_scores']))
+  # the handle is usable for ordinary decodes again
+  again, _ = _offline(dec, seqs, 10)
+  assert np.array_equal(again['labels'], off['labels'])
+
+
+def test_prefix_labels_after_every_push(oracle_lib):
+  """After every push the session equals an offline decode of the prefixes received so far."""
+  params = synth.tracker_params(256, 512, 1, seed=22)
+  lens = [24, 10, 31]
+  seqs, _ = synth.make_utterances(12_100, 3, lens, 256)
+  dec = _capi.Decoder(params)
+  checker = _capi.Decoder(params)
+
+  def check(d, pos):
+    labels, scores, _, status = d.stream_labels()
+    assert status == 0
+    prefixes = [seqs[u][:pos[u]] for u in range(3)]
+    keep = [u for u in range(3) if pos[u] > 0]
+    if not keep:
+      return
+    off, offsets = _offline(checker, [prefixes[u] for u in keep], 6)
+    for k, u in enumerate(keep):
+      assert np.array_equal(labels[u], off['labels'][offsets[k]:offsets[k + 1]]), (u, pos)
+      assert _bits(scores[u]) == _bits(off['scores'][k])
+    for u in range(3):
+      if pos[u] == 0:
+        assert len(labels[u]) == 0 and scores[u] == 0.0
+
+  schedule = [[5, 0, 2], [0, 0, 9], [7, 10, 0], [12, 0, 20]]
+  _stream(dec, seqs, 6, schedule, 40, check_every_push=check)
+
+
+def test_odd_model_shapes_general_select_and_depth(oracle_lib):
+  """Padded dims, depth 2 (k_dense_upper_in), a beam too wide for the fast select kernel."""
+  rng = np.random.default_rng(3)
+  params = weights.init_params(20, 24, 2, sigma2=0.08, transition_bias=0.2, seed=4)
+  params['rnn_init_hidden'] = (0.2 * rng.standard_normal((2, 24))).astype(np.float32)
+  cents = rng.standard_normal((3, 20))
+  seqs = []
+  for n in (15, 4, 22):
+    ids = np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]
+    seqs.append((cents[ids] * 0.4 + 0.1 * rng.standard_normal((n, 20))).astype(np.float64))
+  for beam in (5, 40):
+    ref = oracle_lib.decode(params, seqs, beam, 1, 1, n_threads=4)
+    cap = max(int(ref['max_clusters'].max()), 2)
+    dec = _capi.Decoder(params)
+    labels, scores, overflow, status, beam_scores = _stream(
+        dec, seqs, beam, _random_schedule(rng, [15, 4, 22], 6), 30, max_clusters=cap)
+    assert status == 0
+    for u in range(3):
+      assert np.array_equal(labels[u], ref['labels'][u]), (beam, u)
+    assert np.array_equal(_bits(beam_scores), _bits(ref['beam_scores']))
+
+
+def test_session_errors():
+  params = synth.tracker_params(256, 512, 1, seed=23)
+  dec = _capi.Decoder(params)
+  seqs, _ = synth.make_utterances(12_200, 2, 5, 256)
+  assert dec._lib.uis_stream_labels(dec._handle, None, None, None) == _capi.UIS_ERR_INVALID_ARG  # nothing open
+  dec.stream_begin(2, 4, 8)
+  with pytest.raises(_capi.HipLibraryError):          # one session per handle
+    dec.stream_begin(2, 4, 8)
+  with pytest.raises(_capi.HipLibraryError):          # offline decode refused meanwhile
+    _offline(dec, seqs, 4)
+  dec.stream_push([seqs[0], seqs[1]])
+  with pytest.raises(_capi.HipLibraryError):          # 5 + 5 > max_frames 8
+    dec.stream_push([seqs[0], None])
+  labels, _, _, _ = dec.stream_labels()                # the failed push changed nothing
+  assert [len(x) for x in labels] == [5, 5]
+  dec.stream_end()
+  dec.stream_end()                                     # idempotent
+  opts = _capi.make_opts(4, 1, 2, 0, 0, 0)             # test_iteration 2 is not online
+  assert dec._lib.uis_stream_begin(dec._handle, 2, opts, 8) == _capi.UIS_ERR_UNSUPPORTED
+
+
+def test_python_online_session_matches_predict():
+  import uisrnn_amd
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(synth.tracker_params(256, 512, 1, seed=24))
+  seqs, _ = synth.make_utterances(12_300, 3, [50, 20, 35], 256)
+  inference_args.test_iteration = 1
+  offline = model.predict(seqs, inference_args)
+  with model.online(3, inference_args, max_frames=64) as session:
+    session.push([seqs[0][:10], None, seqs[2][:35]])
+    partial = session.labels()
+    assert [len(x) for x in partial] == [10, 0, 35] and partial[2] == offline[2]
+    session.push([seqs[0][10:], seqs[1], None])
+    assert session.labels() == offline
+    with pytest.raises(TypeError):
+      session.push([seqs[0].astype(np.float32), None, None])   # the reference's float64 rule
+  inference_args.look_ahead = 2
+  with pytest.raises(ValueError):
+    model.online(3, inference_args, max_frames=64)

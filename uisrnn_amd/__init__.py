@@ -12,3 +12,4 @@ parse_arguments = arguments.parse_arguments
 compute_sequence_match_accuracy = evals.compute_sequence_match_accuracy
 UISRNN = _uisrnn.UISRNN
 parallel_predict = _uisrnn.parallel_predict
+OnlineSession = _uisrnn.OnlineSession  # extension: streaming decode

@@ -222,6 +222,14 @@ def load_library(path=None):
   lib.uis_model_constants.argtypes = [ctypes.c_void_p, _fp, _fp]
   lib.uis_rnn_step.restype = i32
   lib.uis_rnn_step.argtypes = [ctypes.c_void_p, _fp, _fp, _fp, _fp]
+  lib.uis_stream_begin.restype = i32
+  lib.uis_stream_begin.argtypes = [ctypes.c_void_p, i32, ctypes.POINTER(DecodeOpts), ctypes.c_int64]
+  lib.uis_stream_push.restype = i32
+  lib.uis_stream_push.argtypes = [ctypes.c_void_p, _fp, i32p]
+  lib.uis_stream_labels.restype = i32
+  lib.uis_stream_labels.argtypes = [ctypes.c_void_p, i32p, _fp, i32p]
+  lib.uis_stream_end.restype = i32
+  lib.uis_stream_end.argtypes = [ctypes.c_void_p]
   lib.uis_last_error.restype = ctypes.c_char_p
   lib.uis_last_error.argtypes = []
   _lib = lib
@@ -231,7 +239,8 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = (
     'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
     'uis_decode', 'uis_decode_device', 'uis_last_decode_info',
-    'uis_model_constants', 'uis_rnn_step', 'uis_last_error')
+    'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',
+    'uis_stream_labels', 'uis_stream_end', 'uis_last_error')
 
 
 def last_error(lib):
@@ -340,6 +349,53 @@ class Decoder:
     if want_beam_scores:
       out['beam_scores'] = beam_scores
     return out
+
+  # ---- online decoding (uis_stream_*)
+  def stream_begin(self, n_utt, beam_size, max_frames, max_clusters=0, flags=0):
+    """Open a streaming session for n_utt utterances (test_iteration 1, look_ahead 1)."""
+    opts = make_opts(beam_size, 1, 1, max_clusters, flags, 0)
+    rc = self._lib.uis_stream_begin(self._handle, int(n_utt), ctypes.byref(opts), int(max_frames))
+    self._check(rc, 'uis_stream_begin')
+    self._stream_n = int(n_utt)
+    self._stream_have = np.zeros(int(n_utt), dtype=np.int64)
+
+  def stream_push(self, chunks):
+    """chunks: one [n_u, D] array (or None / empty) per utterance: its new frames."""
+    if len(chunks) != self._stream_n:
+      raise ValueError('one chunk (or None) per utterance')
+    dim = self.observation_dim
+    parts, counts = [], np.zeros(self._stream_n, dtype=np.int32)
+    for u, chunk in enumerate(chunks):
+      if chunk is None or len(chunk) == 0:
+        continue
+      arr = np.ascontiguousarray(chunk, dtype=np.float32)
+      if arr.ndim != 2 or arr.shape[1] != dim:
+        raise ValueError('chunk does not match observation_dim')
+      parts.append(arr)
+      counts[u] = arr.shape[0]
+    frames = np.concatenate(parts) if parts else np.zeros((0, dim), dtype=np.float32)
+    rc = self._lib.uis_stream_push(
+        self._handle, frames.ctypes.data_as(_fp) if len(frames) else None,
+        counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    self._check(rc, 'uis_stream_push')
+    self._stream_have += counts
+
+  def stream_labels(self):
+    """Best-hypothesis labels of everything received so far: (list of int32 arrays, scores, overflow, status)."""
+    total = int(self._stream_have.sum())
+    labels = np.empty(max(total, 1), dtype=np.int32)
+    scores = np.empty(self._stream_n, dtype=np.float32)
+    overflow = np.zeros(self._stream_n, dtype=np.int32)
+    rc = self._lib.uis_stream_labels(
+        self._handle, labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), scores.ctypes.data_as(_fp),
+        overflow.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    rc = self._check(rc, 'uis_stream_labels')
+    bounds = np.concatenate([[0], np.cumsum(self._stream_have)]).astype(np.int64)
+    per_utt = [labels[bounds[u]:bounds[u + 1]].copy() for u in range(self._stream_n)]
+    return per_utt, scores, overflow, rc
+
+  def stream_end(self):
+    self._check(self._lib.uis_stream_end(self._handle), 'uis_stream_end')
 
   def decode_device(self, d_frames_ptr, offsets, beam_size, look_ahead,
                     test_iteration, d_labels_ptr, d_scores_ptr, max_clusters=0,

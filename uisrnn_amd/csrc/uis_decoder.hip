@@ -91,6 +91,21 @@ struct uis_handle {
   // the one-launch decode relies on observed, not promised, placement (workgroup b on XCD b % 8,
   // all 256 workgroups resident); when its own checks fail once, this handle stops using it
   bool inlaunch_failed = false, resident_off = false;
+  // streaming session (uis_stream_*): owns its device memory
+  struct Stream {
+    bool active = false;
+    int U = 0, B = 0, Kmax = 0, S = 0;
+    int64_t cap = 0;                  // frames per utterance the session can hold
+    std::vector<int32_t> have;        // frames received per utterance
+    std::vector<void*> allocs;
+    DevBuf chunk_x, chunk_pad, chunk_gi0, chunk_mse0, labels, scores;
+    DecodeState st{};
+    int32_t* d_avail = nullptr;
+    int64_t* d_foff = nullptr;
+    int64_t* d_lab_off = nullptr;
+    float* d_beam_scores = nullptr;
+    int64_t steps_run = 0;
+  } stream_state;
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
@@ -306,6 +321,7 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
 int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
   if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
+  if (h->stream_state.active) return fail(UIS_ERR_INVALID_ARG, "a streaming session is open on this handle (uis_stream_end first)");
   const DevModel& m = h->m;
   const int B = opts->beam_size, L = opts->look_ahead, tau = opts->test_iteration;
   int Kmax = opts->max_clusters > 0 ? opts->max_clusters : 16;
@@ -747,10 +763,19 @@ UIS_EXPORT int32_t uis_device_count(void) {
 
 UIS_EXPORT const char* uis_last_error(void) { return g_err.c_str(); }
 
+static void stream_free_on_destroy(uis_handle* h) {
+  for (void* p : h->stream_state.allocs) (void)hipFree(p);
+  h->stream_state.allocs.clear();
+  DevBuf* bufs[] = {&h->stream_state.chunk_x, &h->stream_state.chunk_pad, &h->stream_state.chunk_gi0,
+                    &h->stream_state.chunk_mse0, &h->stream_state.labels, &h->stream_state.scores};
+  for (DevBuf* b : bufs) b->release();
+}
+
 UIS_EXPORT void uis_destroy(uis_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  stream_free_on_destroy(h);
   for (void* p : h->model_allocs) (void)hipFree(p);
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
@@ -909,5 +934,213 @@ UIS_EXPORT int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, fl
   if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
   if (overflow_out && h->last_U) memcpy(overflow_out, h->last_overflow.data(), (size_t)h->last_U * 4);
   if (beam_scores_out && h->last_U) memcpy(beam_scores_out, h->last_beam_scores.data(), (size_t)h->last_U * h->last_B * 4);
+  return UIS_OK;
+}
+
+
+// ------------------------------------------------------------------ streaming
+//
+// Online decoding (the caller side of the path -- UIS-RNN is an online model, the
+// reference only offers offline predict()).  A session keeps the beam, the cluster-state pool
+// and the back-pointers of n_utt utterances on the device; uis_stream_push() appends frames (any
+// number per utterance, also none) and advances every utterance by the frames it received;
+// uis_stream_labels() reads the best hypothesis' labels for everything received so far.
+// Semantics = predict_single with test_iteration 1 (uisrnn.py:479-562): pushing an utterance
+// in any chunking gives bit for bit the labels / scores of one uis_decode over the whole of it
+// (tests/test_gpu_stream.py).  look_ahead 1.  Runs on the launch-per-step kernels.
+
+namespace {
+
+void stream_free(uis_handle* h) {
+  uis_handle::Stream& ss = h->stream_state;
+  for (void* p : ss.allocs) (void)hipFree(p);
+  ss.allocs.clear();
+  DevBuf* bufs[] = {&ss.chunk_x, &ss.chunk_pad, &ss.chunk_gi0, &ss.chunk_mse0, &ss.labels, &ss.scores};
+  for (DevBuf* b : bufs) b->release();
+  ss.active = false;
+  ss.have.clear();
+}
+
+template <typename T>
+int stream_alloc(uis_handle* h, T** out, size_t count, bool zero = false) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(UIS_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+  h->stream_state.allocs.push_back(p);
+  if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
+  *out = static_cast<T*>(p);
+  return UIS_OK;
+}
+
+}  // namespace
+
+UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_decode_opts* opts, int64_t max_frames) {
+  if (!h || !opts || n_utt < 1 || max_frames < 1) return fail(UIS_ERR_INVALID_ARG, "null handle/opts, n_utt < 1 or max_frames < 1");
+  uis_handle::Stream& ss = h->stream_state;
+  if (ss.active) return fail(UIS_ERR_INVALID_ARG, "a streaming session is already open on this handle");
+  const DevModel& m = h->m;
+  const int B = opts->beam_size;
+  const int Kmax = opts->max_clusters > 0 ? opts->max_clusters : 16;
+  if (B < 1 || B > 256) return fail(UIS_ERR_UNSUPPORTED, "beam_size must be in [1, 256]");
+  if (opts->look_ahead != 1) return fail(UIS_ERR_UNSUPPORTED, "streaming needs look_ahead 1");
+  if (opts->test_iteration != 1) return fail(UIS_ERR_UNSUPPORTED, "streaming is online decoding: test_iteration must be 1");
+  if (Kmax > 4096) return fail(UIS_ERR_UNSUPPORTED, "max_clusters must be <= 4096");
+  if (max_frames > 0x7fffff00LL) return fail(UIS_ERR_UNSUPPORTED, "max_frames too large");
+  const int U = n_utt, S = B * Kmax + B;
+  const SelectLds lds = select_lds_layout(m.Dp, B, Kmax, S);
+  if (lds.total > 160 * 1024) return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+  const double bytes = (double)U * S * (m.Dp + (double)m.depth * m.Hp) * 4.0 + (double)U * max_frames * B * 4.0;
+  if (bytes > 200e9) return fail(UIS_ERR_OOM, "streaming state would need " + std::to_string((long long)(bytes / 1e9)) + " GB");
+  HIPCHK(hipSetDevice(h->device));
+  ss = uis_handle::Stream{};
+  ss.U = U; ss.B = B; ss.Kmax = Kmax; ss.S = S; ss.cap = max_frames;
+  ss.have.assign(U, 0);
+  DecodeState& st = ss.st;
+  st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = 1; st.tau = 1; st.flags = opts->flags;
+  st.max_rows = U * B;
+  const long rows_cap = (long)U * B + 48;
+  int rc = UIS_OK;
+  int64_t* d_off = nullptr; double *d_logblk = nullptr, *d_logden = nullptr;
+#define SALLOC(ptr, count, zero) if ((rc = stream_alloc(h, &(ptr), (size_t)(count), zero))) { stream_free(h); return rc; }
+  SALLOC(d_off, U + 1, false);
+  SALLOC(st.utt_step, U, false);
+  SALLOC(st.overflow, U, false);
+  SALLOC(ss.d_avail, U, true);
+  SALLOC(ss.d_foff, U, true);
+  SALLOC(ss.d_lab_off, U, true);
+  SALLOC(d_logblk, max_frames + 2, false);
+  SALLOC(d_logden, max_frames + 2, false);
+  SALLOC(st.pool_mean, (size_t)U * S * m.Dp, false);
+  SALLOC(st.pool_hid, ((size_t)U * S + 1) * m.depth * m.Hp, false);
+  SALLOC(st.pool_cnt, (size_t)U * S, false);
+  SALLOC(st.beam_n, 2 * (size_t)U, false);
+  SALLOC(st.beam_K, 2 * (size_t)U * B, false);
+  SALLOC(st.beam_last, 2 * (size_t)U * B, false);
+  SALLOC(st.beam_sum, 2 * (size_t)U * B, false);
+  SALLOC(st.beam_score, 2 * (size_t)U * B, false);
+  SALLOC(st.beam_slot, 2 * (size_t)U * B * Kmax, false);
+  SALLOC(st.beam_blk, 2 * (size_t)U * B * Kmax, false);
+  SALLOC(st.bp, (size_t)U * max_frames * B, false);
+  SALLOC(st.rows, rows_cap, true);
+  SALLOC(st.nrows, 2, true);
+  SALLOC(st.gi_up, m.depth > 1 ? (size_t)rows_cap * m.G : 16, false);
+  SALLOC(st.a1, (size_t)rows_cap * m.Hp, true);
+  SALLOC(st.counters, 96, true);
+  SALLOC(st.cl_abort, 16, true);
+  SALLOC(ss.d_beam_scores, (size_t)U * B, false);
+#undef SALLOC
+  std::vector<int64_t> off(U + 1);
+  for (int u = 0; u <= U; ++u) off[u] = (int64_t)u * max_frames;  // capacity offsets: they address the back-pointers
+  std::vector<double> logblk(max_frames + 2), logden(max_frames + 2);
+  for (int64_t n = 0; n < max_frames + 2; ++n) {
+    logblk[n] = n > 0 ? std::log((double)n) : 0.0;
+    logden[n] = std::log((double)n + h->alpha);
+  }
+  HIPCHK(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d_logblk, logblk.data(), logblk.size() * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d_logden, logden.data(), logden.size() * 8, hipMemcpyHostToDevice, h->stream));
+  st.off = d_off; st.logblk = d_logblk; st.logden = d_logden;
+  st.avail = ss.d_avail; st.foff = ss.d_foff; st.lab_off = ss.d_lab_off;
+  hipLaunchKernelGGL(k_init_state, dim3((U + 255) / 256), dim3(256), 0, h->stream, st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+  ss.active = true;
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int32_t* counts) {
+  if (!h || !counts) return fail(UIS_ERR_INVALID_ARG, "null handle/counts");
+  uis_handle::Stream& ss = h->stream_state;
+  if (!ss.active) return fail(UIS_ERR_INVALID_ARG, "no streaming session (uis_stream_begin first)");
+  const DevModel& m = h->m;
+  const int U = ss.U;
+  int64_t F = 0, max_new = 0;
+  std::vector<int64_t> foff(U);
+  std::vector<int32_t> avail(U);
+  for (int u = 0; u < U; ++u) {
+    if (counts[u] < 0) return fail(UIS_ERR_INVALID_ARG, "negative frame count");
+    if ((int64_t)ss.have[u] + counts[u] > ss.cap) return fail(UIS_ERR_INVALID_ARG, "utterance exceeds the session's max_frames");
+    foff[u] = F - ss.have[u];  // row of step s's frame in this chunk = foff + s
+    F += counts[u];
+    max_new = std::max<int64_t>(max_new, counts[u]);
+    avail[u] = ss.have[u] + counts[u];
+  }
+  if (F == 0) return UIS_OK;
+  if (!frames) return fail(UIS_ERR_INVALID_ARG, "frames is null");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ss.chunk_x.ensure((size_t)F * m.D * 4))) return rc;
+  if ((rc = ss.chunk_gi0.ensure((size_t)F * m.G * 4))) return rc;
+  if ((rc = ss.chunk_mse0.ensure((size_t)F * 4))) return rc;
+  HIPCHK(hipMemcpyAsync(ss.chunk_x.p, frames, (size_t)F * m.D * 4, hipMemcpyHostToDevice, h->stream));
+  const float* d_x = ss.chunk_x.as<float>();
+  if (m.D != m.Dp) {
+    if ((rc = ss.chunk_pad.ensure((size_t)F * m.Dp * 4))) return rc;
+    const long total = (long)F * m.Dp;
+    hipLaunchKernelGGL(k_pad_frames, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d_x,
+                       ss.chunk_pad.as<float>(), (long)F, m.D, m.Dp);
+    HIPCHK(hipGetLastError());
+    d_x = ss.chunk_pad.as<float>();
+  }
+  Launcher lch{h, h->stream, false};
+  LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
+  LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
+         ss.chunk_mse0.as<float>(), (long)F);
+  HIPCHK(hipMemcpyAsync(ss.d_foff, foff.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(ss.d_avail, avail.data(), (size_t)U * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
+  DecodeState st = ss.st;
+  st.x = d_x; st.gi0 = ss.chunk_gi0.as<float>(); st.mse0 = ss.chunk_mse0.as<float>();
+  const SelectLds lds = select_lds_layout(m.Dp, ss.B, ss.Kmax, ss.S);
+  if ((rc = enqueue_steps(h, lch, st, lds.total, (int)max_new))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));  // foff / avail / the caller's frames may be reused
+  for (int u = 0; u < U; ++u) ss.have[u] = avail[u];
+  ss.steps_run += max_new;
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* scores_out, int32_t* overflow_out) {
+  if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
+  uis_handle::Stream& ss = h->stream_state;
+  if (!ss.active) return fail(UIS_ERR_INVALID_ARG, "no streaming session (uis_stream_begin first)");
+  const int U = ss.U;
+  std::vector<int64_t> lab_off(U);
+  int64_t F = 0;
+  for (int u = 0; u < U; ++u) { lab_off[u] = F; F += ss.have[u]; }
+  if (F > 0 && !labels_out) return fail(UIS_ERR_INVALID_ARG, "labels_out is null");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = ss.labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
+  if ((rc = ss.scores.ensure((size_t)U * 4))) return rc;
+  HIPCHK(hipMemcpyAsync(ss.d_lab_off, lab_off.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_backtrace, dim3((U + 63) / 64), dim3(64), 0, h->stream, ss.st, ss.labels.as<int32_t>(),
+                     ss.scores.as<float>(), ss.d_beam_scores);
+  HIPCHK(hipGetLastError());
+  if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, ss.labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+  if (scores_out) HIPCHK(hipMemcpyAsync(scores_out, ss.scores.p, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
+  h->last_U = U; h->last_B = ss.B;
+  h->last_overflow.assign(U, 0);
+  h->last_beam_scores.assign((size_t)U * ss.B, INFINITY);
+  HIPCHK(hipMemcpyAsync(h->last_overflow.data(), ss.st.overflow, (size_t)U * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), ss.d_beam_scores, (size_t)U * ss.B * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  int n_over = 0;
+  for (int u = 0; u < U; ++u) {
+    if (overflow_out) overflow_out[u] = h->last_overflow[u];
+    n_over += h->last_overflow[u] != 0;
+  }
+  if (n_over)
+    return fail(UIS_ERR_CLUSTER_CAP, std::to_string(n_over) + " utterance(s) needed more than max_clusters=" +
+                                         std::to_string(ss.Kmax) + " clusters per hypothesis");
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_stream_end(uis_handle* h) {
+  if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
+  if (!h->stream_state.active) return UIS_OK;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  stream_free(h);
   return UIS_OK;
 }

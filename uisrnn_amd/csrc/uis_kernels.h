@@ -98,6 +98,14 @@ struct DecodeState {
   int rx_stride;
   int32_t* rx_nrows;
   uint32_t* rx_bar;
+  // streaming (uis_stream_*): utterances are NOT in lock-step.  avail[u] = frames received so far
+  // (= decode steps that may run; test_iteration is 1), foff[u] + step = row of step `step`'s
+  // frame in the current chunk's x / gi0 / mse0, lab_off[u] = where the utterance's labels go.
+  // `off` then holds capacity offsets (u * max_frames): it only addresses the back-pointers.
+  // All three are null in an ordinary decode.
+  const int32_t* avail;
+  const int64_t* foff;
+  const int64_t* lab_off;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

@@ -918,7 +918,10 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   unsigned long long t_prev_ = __builtin_readcyclecounter();
 #endif
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
-  const int nxt = par ^ 1;
+  // streaming: every utterance has its own step count, so the parity of ITS tables is its own
+  // step's; `par` stays the parity of the launch (row counter)
+  const int tpar = st.avail ? (st.utt_step[u] & 1) : par;
+  const int nxt = tpar ^ 1;
 
   const SelectLds L = select_lds_layout(m.Dp, B, Kmax, S);
   float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
@@ -942,15 +945,15 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   int* sfree = reinterpret_cast<int*>(smem_raw + L.off_free);
   int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite [2] nlead [3] nfree
 
-  const size_t bcur = ((size_t)par * U + u) * B;
+  const size_t bcur = ((size_t)tpar * U + u) * B;
   const size_t bnxt = ((size_t)nxt * U + u) * B;
 
   // ---- round trip 1 (entries of the tables beyond K_b / nb are garbage and never used)
   const int step = st.utt_step[u];
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
-  const int nb = st.beam_n[(size_t)par * U + u];
+  const int nb = st.beam_n[(size_t)tpar * U + u];
   // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
-  if (u == 0 && tid == 0) st.nrows[nxt] = 0;
+  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
   if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
   if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
@@ -965,9 +968,9 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   for (int sl = tid; sl < S; sl += 256) slive[sl] = 0;
   if (tid < 16) smisc[tid] = 0;
   const long N = off1 - off0;
-  const long T = (long)st.tau * N;
+  const long T = st.avail ? (long)st.avail[u] : (long)st.tau * N;
   if (step >= T) return;  // utterance finished (uniform over the workgroup)
-  const long frame = off0 + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
+  const long frame = st.foff ? (long)st.foff[u] + step : off0 + (step % N);  // np.tile(seq, (tau, 1)), uisrnn.py:524
   __syncthreads();
   TSTAMP(0);
   for (int e = tid; e < nb * Kmax; e += 256) {
@@ -1280,10 +1283,12 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   unsigned long long t_prev_ = wall_clock64();
 #endif
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
-  const int nxt = par ^ 1;
+  // streaming (never KEEP): the parity of an utterance's tables is its own step's
+  const int tpar = (!KEEP && st.avail) ? (st.utt_step[u] & 1) : par;
+  const int nxt = tpar ^ 1;
   const FastLds L = fast_lds_layout(m.Dp, B, Kmax, S);
   float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
-  unsigned char* const set_cur = smem_raw + (KEEP ? par * L.set_stride : 0);
+  unsigned char* const set_cur = smem_raw + (KEEP ? tpar * L.set_stride : 0);
   unsigned char* const set_nxt = smem_raw + (KEEP ? nxt * L.set_stride : 0);
   int* sslot = reinterpret_cast<int*>(set_cur + L.off_slot);
   int* sblk = reinterpret_cast<int*>(set_cur + L.off_blk);
@@ -1309,7 +1314,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   float* swscore = reinterpret_cast<float*>(smem_raw + L.off_wscore);
   int* smisc = reinterpret_cast<int*>(smem_raw + L.off_misc);  // [0] nlive [1] nfinite
 
-  const size_t bcur = ((size_t)par * U + u) * B;
+  const size_t bcur = ((size_t)tpar * U + u) * B;
   const size_t bnxt = ((size_t)nxt * U + u) * B;
 
   // ---- round trip 1: every load is issued before the first result is stored to LDS (written
@@ -1322,7 +1327,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const bool has_e = tid < B * Kmax, has_b = tid < B;
   if (fresh) {
     if (!KEEP) { step = st.utt_step[u]; off0 = (long)st.off[u]; off1 = (long)st.off[u + 1]; }
-    nb = st.beam_n[(size_t)par * U + u];
+    nb = st.beam_n[(size_t)tpar * U + u];
     const int r_slot = has_e ? st.beam_slot[bcur * Kmax + tid] : 0;
     const int r_blk = has_e ? st.beam_blk[bcur * Kmax + tid] : 0;
     myK = has_b ? st.beam_K[bcur + tid] : 0;
@@ -1346,9 +1351,9 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   for (int sl = tid; sl < S; sl += NT) slive[sl] = 0;
   if (tid < 16) smisc[tid] = 0;
   const long N = off1 - off0;
-  const long T = (long)st.tau * N;
+  const long T = (!KEEP && st.avail) ? (long)st.avail[u] : (long)st.tau * N;
   if (step >= T) return;
-  const long frame = off0 + (step % N);
+  const long frame = (!KEEP && st.foff) ? (long)st.foff[u] + step : off0 + (step % N);
   // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
   if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
     const int v = lane < nb ? myK + 1 : 0;
@@ -2517,8 +2522,9 @@ __global__ void k_backtrace(DecodeState st, int32_t* __restrict__ labels, float*
                             float* __restrict__ beam_scores) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= st.U) return;
-  const long N = (long)(st.off[u + 1] - st.off[u]);
-  const long T = (long)st.tau * N;
+  // streaming: the frames received so far (test_iteration 1); labels go where the caller packs them
+  const long N = st.avail ? (long)st.avail[u] : (long)(st.off[u + 1] - st.off[u]);
+  const long T = st.avail ? N : (long)st.tau * N;
   const int par = (int)(T & 1);  // parity holding the final beam
   const int nb = N > 0 ? st.beam_n[(size_t)par * st.U + u] : 0;
   const size_t e = ((size_t)par * st.U + u) * st.B;
@@ -2526,7 +2532,7 @@ __global__ void k_backtrace(DecodeState st, int32_t* __restrict__ labels, float*
     for (int b = 0; b < st.B; ++b) beam_scores[(size_t)u * st.B + b] = b < nb ? st.beam_score[e + b] : INFINITY;
   if (scores) scores[u] = nb > 0 ? st.beam_score[e] : (N > 0 ? INFINITY : 0.0f);
   if (N == 0) return;
-  int32_t* out = labels + st.off[u];
+  int32_t* out = labels + (st.lab_off ? st.lab_off[u] : st.off[u]);
   if (nb == 0) { for (long i = 0; i < N; ++i) out[i] = -1; return; }
   const uint32_t* bp = st.bp + (size_t)st.tau * st.off[u] * st.B;
   int r = 0;

@@ -206,6 +206,14 @@ class UISRNN:
     self._check_sequence(test_sequence)
     return self._decode_batch([test_sequence], args)[0]
 
+  def online(self, num_utterances, args, max_frames):
+    """An OnlineSession (streaming decode; extension, see the class)."""
+    if args.look_ahead != 1:
+      raise ValueError('online decoding needs look_ahead 1')
+    if self.transition_bias is None:
+      raise TypeError('transition_bias is None: the model was never fit or loaded')
+    return OnlineSession(self, num_utterances, args, max_frames)
+
   def predict(self, test_sequences, args):
     """Predict labels for one sequence or a list of them (uisrnn.py:564-590).
 
@@ -225,6 +233,56 @@ class UISRNN:
         return []
       return self._decode_batch(test_sequences, args)
     raise TypeError('test_sequences should be either a list or numpy array.')
+
+
+class OnlineSession:
+  """Online (streaming) diarization of a fixed set of utterances.
+
+  Not part of the reference's API -- google/uis-rnn only decodes offline, replaying the
+  utterance `test_iteration` times (uisrnn/arguments.py:186-193) -- but the model is an
+  online one.  A session keeps the beam on the GPU; frames are pushed as they arrive and
+  `labels()` returns the currently best hypothesis for everything received.  Equivalent,
+  bit for bit, to `predict` with test_iteration=1, look_ahead=1 on the frames received so
+  far, whatever the chunking.
+
+    with model.online(num_utterances=2, args=inference_args, max_frames=10000) as session:
+      session.push([chunk_a, None])        # [n, D] float arrays; None = nothing new
+      session.push([chunk_a2, chunk_b])
+      labels = session.labels()            # list of lists of ints, one per utterance
+  """
+
+  def __init__(self, model, num_utterances, args, max_frames):
+    self._model = model
+    self._decoder = _capi.Decoder(model.params, model.device_index)  # own handle: one session per handle
+    cap = int(getattr(args, 'max_clusters', 0) or _DEFAULT_MAX_CLUSTERS)
+    self._decoder.stream_begin(num_utterances, args.beam_size, max_frames, max_clusters=cap)
+    self._open = True
+
+  def push(self, chunks):
+    for chunk in chunks:
+      if chunk is not None and len(chunk):
+        self._model._check_sequence(np.asarray(chunk))
+    self._decoder.stream_push(chunks)
+
+  def labels(self):
+    per_utt, _, overflow, _ = self._decoder.stream_labels()
+    if overflow.any():
+      raise RuntimeError('utterance(s) {} need more than max_clusters clusters per hypothesis; '
+                         'open the session with a larger args.max_clusters'.format(
+                             np.flatnonzero(overflow).tolist()))
+    return [x.tolist() for x in per_utt]
+
+  def close(self):
+    if self._open:
+      self._decoder.stream_end()
+      self._decoder.close()
+      self._open = False
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
 
 
 def parallel_predict(model, test_sequences, args, num_processes=4, devices=None):
