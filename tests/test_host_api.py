@@ -120,10 +120,23 @@ def test_library_exports_every_declared_symbol():
   lib = _capi.load_library()
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.uis_abi_version() == 2
+  assert lib.uis_abi_version() == _capi.UIS_ABI_VERSION == 2
   version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', open(
       os.path.join(ROOT, 'include', 'uis_numerics.h')).read()).group(1))
   assert lib.uis_numerics_version() == version
+
+
+def test_driver_build_entry_point():
+  """__graft_entry__.build() is what the driver runs as its "does it build" check."""
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import __graft_entry__
+  __graft_entry__.build()
+  # the header, the library and the Python constants agree on the ABI version
+  header = open(os.path.join(os.path.dirname(__graft_entry__.__file__), 'include', 'uisrnn_hip.h')).read()
+  assert int(re.search(r'#define UIS_ABI_VERSION (\d+)', header).group(1)) == _capi.UIS_ABI_VERSION
+  flags = dict(re.findall(r'#define (UIS_FLAG_\w+)\s+(0x[0-9a-fA-F]+)u', header))
+  for name, value in flags.items():
+    assert getattr(_capi, name) == int(value, 16), name
 
 
 def test_struct_layouts_match_header():
