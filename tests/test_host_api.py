@@ -139,6 +139,18 @@ def test_driver_build_entry_point():
     assert getattr(_capi, name) == int(value, 16), name
 
 
+def test_initial_cluster_cap_keeps_wide_beams_on_the_fast_path():
+  import argparse
+  from uisrnn_amd import uisrnn as host
+  def cap(beam, look=1, explicit=0):
+    return host._initial_cluster_cap(argparse.Namespace(beam_size=beam, look_ahead=look, max_clusters=explicit))
+  assert cap(10) == 16 and cap(15) == 16          # 15 * 17 = 255 candidates: fits as it is
+  assert cap(20) == 11 and 20 * (cap(20) + 1) <= 256
+  assert cap(28) == 8 and cap(29) == 16           # below 8 clusters it is not worth it
+  assert cap(20, look=2) == 16                    # look_ahead >= 2 has its own kernel
+  assert cap(20, explicit=32) == 32               # the caller's word wins
+
+
 def test_struct_layouts_match_header():
   """ctypes mirrors of the header structs (LP64): sizes and a few offsets."""
   assert ctypes.sizeof(_capi.ModelDesc) == 16 + 10 * 8 + 16

@@ -17,6 +17,24 @@ from uisrnn_amd import _capi
 from uisrnn_amd import weights
 
 _DEFAULT_MAX_CLUSTERS = 16
+
+
+def _initial_cluster_cap(args):
+  """Device table size (clusters per hypothesis) of the first decode attempt.
+
+  The fast select kernel and the one-launch decode need beam_size * (cap + 1) <= 256
+  candidates (include/uisrnn_hip.h).  With the default cap 16 a beam wider than 15 would
+  leave that path; real diarization rarely opens more than a handful of clusters, so a wide
+  beam starts with the largest cap that still fits (never below 8) and the overflow retry
+  below doubles it when an utterance does need more.
+  """
+  explicit = int(getattr(args, 'max_clusters', 0) or 0)
+  if explicit:
+    return explicit
+  fits = 256 // max(int(args.beam_size), 1) - 1
+  if int(args.look_ahead) == 1 and 8 <= fits < _DEFAULT_MAX_CLUSTERS:
+    return fits
+  return _DEFAULT_MAX_CLUSTERS
 _MAX_CLUSTERS_LIMIT = 1024
 
 
@@ -150,7 +168,7 @@ class UISRNN:
       frames[start:start + seq.shape[0]] = seq
     results = [None] * n_utt
     pending = list(range(n_utt))
-    cap = int(getattr(args, 'max_clusters', 0) or _DEFAULT_MAX_CLUSTERS)
+    cap = _initial_cluster_cap(args)
     stats = None
     while pending:
       sub_lens = lens[pending]
@@ -254,7 +272,7 @@ class OnlineSession:
   def __init__(self, model, num_utterances, args, max_frames):
     self._model = model
     self._decoder = _capi.Decoder(model.params, model.device_index)  # own handle: one session per handle
-    cap = int(getattr(args, 'max_clusters', 0) or _DEFAULT_MAX_CLUSTERS)
+    cap = _initial_cluster_cap(args)
     self._decoder.stream_begin(num_utterances, args.beam_size, max_frames, max_clusters=cap)
     self._open = True
 
