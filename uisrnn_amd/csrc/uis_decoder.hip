@@ -644,7 +644,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
         if ((rc = enqueue_steps(h, gl, gp.st, lds.total, 2))) return rc;
     }
     if (L == 1)
-      LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
+      LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3(gp.U), dim3(64), (size_t)64 * B, gp.st, d_labels,
              d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
     else
       LAUNCH(UIS_K_BACKTRACE, k_backtrace_window, dim3((gp.U + 63) / 64), dim3(64), 0, gp.st, d_labels,
@@ -1114,7 +1114,7 @@ UIS_EXPORT int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* 
   if ((rc = ss.labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
   if ((rc = ss.scores.ensure((size_t)U * 4))) return rc;
   HIPCHK(hipMemcpyAsync(ss.d_lab_off, lab_off.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_backtrace, dim3((U + 63) / 64), dim3(64), 0, h->stream, ss.st, ss.labels.as<int32_t>(),
+  hipLaunchKernelGGL(k_backtrace, dim3(U), dim3(64), (size_t)64 * ss.B, h->stream, ss.st, ss.labels.as<int32_t>(),
                      ss.scores.as<float>(), ss.d_beam_scores);
   HIPCHK(hipGetLastError());
   if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, ss.labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
