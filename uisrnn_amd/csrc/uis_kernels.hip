@@ -1268,10 +1268,17 @@ struct RowSink {
 // `par ^ 1` -- so the only global state a select reads back is the cluster means; the caller
 // passes the step number and the utterance's frame range.
 // DPT: the padded observation_dim when the caller knows it at compile time (0 = read m.Dp).
-template <int NT, bool RES, bool KEEP, int DPT = 0>
+// PARTS (KEEP only; 3 = everything): 1 = the PREPARATION of a step -- live slots, their list, the
+// candidate table: all of it depends on this workgroup's LDS tables only, so the resident decode
+// runs it while it waits for the other workgroups' linear_mean2 results; 2 = the rest.
+// `published` is called by wave 0 as soon as the step's rnn rows are written (before the table
+// updates nobody else reads): the resident decode arrives at its barrier there.
+struct SelectNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NT, bool RES, bool KEEP, int DPT = 0, int PARTS = 3, typename Pub = SelectNoHook>
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
                                                  unsigned char* smem_raw, RowSink sink, int step_in = 0,
-                                                 long off0_in = 0, long off1_in = 0) {
+                                                 long off0_in = 0, long off1_in = 0, Pub published = Pub()) {
+  static_assert(PARTS == 3 || KEEP, "the split needs the beam in LDS");
   int tid_ = threadIdx.x;
   // inside the resident decode's step loop: keep the compiler from hoisting every tid-derived
   // address out of the loop (they would have to live -- spilled -- across the dense stages)
@@ -1325,71 +1332,81 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   int step = step_in, nb = 0, myK = 0;
   long off0 = off0_in, off1 = off1_in;
   const bool has_e = tid < B * Kmax, has_b = tid < B;
-  if (fresh) {
-    if (!KEEP) { step = st.utt_step[u]; off0 = (long)st.off[u]; off1 = (long)st.off[u + 1]; }
-    nb = st.beam_n[(size_t)tpar * U + u];
-    const int r_slot = has_e ? st.beam_slot[bcur * Kmax + tid] : 0;
-    const int r_blk = has_e ? st.beam_blk[bcur * Kmax + tid] : 0;
-    myK = has_b ? st.beam_K[bcur + tid] : 0;
-    const int r_last = has_b ? st.beam_last[bcur + tid] : 0;
-    const int r_sum = has_b ? st.beam_sum[bcur + tid] : 0;
-    const float r_score = has_b ? st.beam_score[bcur + tid] : 0.0f;
-    float r_w[4];
+  if (PARTS & 1) {
+    if (fresh) {
+      if (!KEEP) { step = st.utt_step[u]; off0 = (long)st.off[u]; off1 = (long)st.off[u + 1]; }
+      nb = st.beam_n[(size_t)tpar * U + u];
+      const int r_slot = has_e ? st.beam_slot[bcur * Kmax + tid] : 0;
+      const int r_blk = has_e ? st.beam_blk[bcur * Kmax + tid] : 0;
+      myK = has_b ? st.beam_K[bcur + tid] : 0;
+      const int r_last = has_b ? st.beam_last[bcur + tid] : 0;
+      const int r_sum = has_b ? st.beam_sum[bcur + tid] : 0;
+      const float r_score = has_b ? st.beam_score[bcur + tid] : 0.0f;
+      float r_w[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r_w[k] = tid + k * NT < m.Dp ? m.wgt[tid + k * NT] : 0.0f;
+      for (int k = 0; k < 4; ++k) r_w[k] = tid + k * NT < m.Dp ? m.wgt[tid + k * NT] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (tid + k * NT < m.Dp) swgt[tid + k * NT] = r_w[k];
-    for (int i = tid + 4 * NT; i < m.Dp; i += NT) swgt[i] = m.wgt[i];  // observation_dim > 4 * NT
-    if (has_e) { sslot[tid] = r_slot; sblk[tid] = r_blk; }
-    if (has_b) { sK[tid] = myK; slast[tid] = r_last; ssum[tid] = r_sum; sscore[tid] = r_score; }
-    if (KEEP) for (int sl = tid; sl < S; sl += NT) spcnt[sl] = 0;
+      for (int k = 0; k < 4; ++k)
+        if (tid + k * NT < m.Dp) swgt[tid + k * NT] = r_w[k];
+      for (int i = tid + 4 * NT; i < m.Dp; i += NT) swgt[i] = m.wgt[i];  // observation_dim > 4 * NT
+      if (has_e) { sslot[tid] = r_slot; sblk[tid] = r_blk; }
+      if (has_b) { sK[tid] = myK; slast[tid] = r_last; ssum[tid] = r_sum; sscore[tid] = r_score; }
+      if (KEEP) {
+        for (int sl = tid; sl < S; sl += NT) spcnt[sl] = 0;
+        if (tid == 0) *reinterpret_cast<int*>(set_cur + L.off_nb) = nb;
+      }
+    } else {
+      nb = *reinterpret_cast<const int*>(set_cur + L.off_nb);
+      myK = has_b ? sK[tid] : 0;
+    }
+    for (int sl = tid; sl < S; sl += NT) slive[sl] = 0;
+    if (tid < 16) smisc[tid] = 0;
   } else {
     nb = *reinterpret_cast<const int*>(set_cur + L.off_nb);
-    myK = has_b ? sK[tid] : 0;
   }
-  for (int sl = tid; sl < S; sl += NT) slive[sl] = 0;
-  if (tid < 16) smisc[tid] = 0;
   const long N = off1 - off0;
   const long T = (!KEEP && st.avail) ? (long)st.avail[u] : (long)st.tau * N;
   if (step >= T) return;
   const long frame = (!KEEP && st.foff) ? (long)st.foff[u] + step : off0 + (step % N);
-  // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
-  if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
-    const int v = lane < nb ? myK + 1 : 0;
-    int excl = 0, total = 0;
-    for (int j2 = 0; j2 < nb; ++j2) {
-      const int kj = __builtin_amdgcn_readlane(v, j2);
-      if (lane > j2) excl += kj;
-      total += kj;
+  if (PARTS & 1) {
+    // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
+    if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
+      const int v = lane < nb ? myK + 1 : 0;
+      int excl = 0, total = 0;
+      for (int j2 = 0; j2 < nb; ++j2) {
+        const int kj = __builtin_amdgcn_readlane(v, j2);
+        if (lane > j2) excl += kj;
+        total += kj;
+      }
+      if (lane < nb) sbase[lane] = excl;
+      if (lane == 0) sbase[nb] = total;
     }
-    if (lane < nb) sbase[lane] = excl;
-    if (lane == 0) sbase[nb] = total;
+    __syncthreads();  // (1) tables staged
+    TSTAMP(0);
+    for (int e = tid; e < nb * Kmax; e += NT) {
+      const int b = e / Kmax, c = e - b * Kmax;
+      if (c < sK[b]) slive[sslot[e]] = 1;
+    }
+    // candidate i = sbase[b] + c  ->  (b, c): one LDS word per candidate instead of a search
+    // over the prefix sums wherever a candidate index has to be decoded
+    if (tid < nb * (Kmax + 1)) {  // <= 256 <= NT (select_fast_ok)
+      const int b = tid / (Kmax + 1), c = tid - b * (Kmax + 1);
+      if (c <= sK[b]) scand[sbase[b] + c] = ((unsigned)b << 16) | (unsigned)c;
+    }
+    __syncthreads();  // (2) live flags
+    for (int base = 0; base < S; base += NT) {  // compaction: ballot per wave, one LDS atomic per wave
+      const int sl = base + tid;
+      const bool lv = sl < S && slive[sl] != 0;
+      const unsigned long long mask = __ballot(lv);
+      int wbase = 0;
+      if (lane == 0 && mask) wbase = atomicAdd(&smisc[0], __popcll(mask));
+      wbase = __shfl(wbase, 0, 64);
+      if (lv) slivelist[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = sl;
+    }
+    __syncthreads();  // (3) live list
+    TSTAMP(1);
   }
-  __syncthreads();  // (1) tables staged
-  TSTAMP(0);
-  for (int e = tid; e < nb * Kmax; e += NT) {
-    const int b = e / Kmax, c = e - b * Kmax;
-    if (c < sK[b]) slive[sslot[e]] = 1;
-  }
-  // candidate i = sbase[b] + c  ->  (b, c): one LDS word per candidate instead of a search
-  // over the prefix sums wherever a candidate index has to be decoded
-  if (tid < nb * (Kmax + 1)) {  // <= 256 <= NT (select_fast_ok)
-    const int b = tid / (Kmax + 1), c = tid - b * (Kmax + 1);
-    if (c <= sK[b]) scand[sbase[b] + c] = ((unsigned)b << 16) | (unsigned)c;
-  }
-  __syncthreads();  // (2) live flags
-  for (int base = 0; base < S; base += NT) {  // compaction: ballot per wave, one LDS atomic per wave
-    const int sl = base + tid;
-    const bool lv = sl < S && slive[sl] != 0;
-    const unsigned long long mask = __ballot(lv);
-    int wbase = 0;
-    if (lane == 0 && mask) wbase = atomicAdd(&smisc[0], __popcll(mask));
-    wbase = __shfl(wbase, 0, 64);
-    if (lv) slivelist[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = sl;
-  }
-  __syncthreads();  // (3) live list
-  TSTAMP(1);
+  if (PARTS == 1) return;
   const int nlive = smisc[0];
   const int C = sbase[nb];
 
@@ -1624,6 +1641,17 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     if (isw && !is_lead) dst = dl;
   }
   TSTAMP(5);
+  if (KEEP) {
+    // resident decode: the rows first -- they are all the other workgroups wait for
+    row_base = __shfl(row_base, 0, 64);
+    if (is_lead) {
+      const int nprev = src >= 0 ? scnt[src] : 0;
+      spcnt[dst] = nprev + 1;
+      RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
+      sink.rows[row_base + ord] = rr;
+    }
+    published();
+  }
   // the one changed entry of each winner's tables (the rest is being copied by waves 1-3)
   if (isw && wc < Kmax) {
     const bool is_new = wc == Kb;
@@ -1656,13 +1684,14 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(Kmaxseen, off, 64); Kmaxseen = o > Kmaxseen ? o : Kmaxseen; }
   TSTAMP(6);
-  row_base = __shfl(row_base, 0, 64);
-  if (is_lead) {
-    const int nprev = src >= 0 ? scnt[src] : 0;
-    if (KEEP) spcnt[dst] = nprev + 1;
-    else st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
-    RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
-    sink.rows[row_base + ord] = rr;
+  if (!KEEP) {
+    row_base = __shfl(row_base, 0, 64);
+    if (is_lead) {
+      const int nprev = src >= 0 ? scnt[src] : 0;
+      st.pool_cnt[(size_t)u * S + dst] = nprev + 1;
+      RnnRow rr; rr.utt = u; rr.src = src; rr.dst = dst; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
+      sink.rows[row_base + ord] = rr;
+    }
   }
   if (lane == 0) {
     st.beam_n[(size_t)nxt * U + u] = keep;
@@ -1707,6 +1736,26 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
 #define UIS_RES_RC 3           // row tiles per pass
 #define UIS_RES_HEAD_TILES 24  // row tiles whose descriptors are staged in LDS at a time (even)
 
+// The barrier in two halves, so that work that needs nobody else's data can sit between them.
+//   xcd_arrive     every wave drains its stores, thread 0 signals (s_ctl[2] = "already arrived")
+//   xcd_wait       thread 0 arrives now if nobody did, then polls; ends with the workgroup barrier
+__device__ __forceinline__ void xcd_arrive(const DecodeState& st, int cluster, int* s_ctl) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    (void)__hip_atomic_fetch_add(st.rx_bar + cluster * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s_ctl[2] = 1;
+  }
+}
+// wave 0 only, from inside a select whose other waves have no global stores in flight
+__device__ __forceinline__ void xcd_arrive_wave0(const DecodeState& st, int cluster, int* s_ctl) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {
+    (void)__hip_atomic_fetch_add(st.rx_bar + cluster * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s_ctl[2] = 1;
+  }
+}
+
 __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, uint32_t target, int* s_abort) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
   __syncthreads();
@@ -1716,7 +1765,8 @@ __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, 
     // write-through); the poll is an sc1 load: it skips this CU's L1 and is served by that L2
     // (the arrival's return value is not used -- no round trip before the first poll, which queues
     // behind it at the same L2 channel)
-    (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!s_abort[2]) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    s_abort[2] = 0;
     unsigned spins = 0;
     int bad = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -1891,6 +1941,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ctl[0] = 0;
     s_ctl[1] = 0;
+    s_ctl[2] = 0;  // "this workgroup has already arrived at the barrier it is about to wait at"
 #if defined(UIS_RESIDENT_TIMING) || defined(UIS_RESIDENT_PROBE)
     for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k] = 0;
 #endif
@@ -1939,6 +1990,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
   const bool keep_beam = U <= 256;
+  const bool did_select = cluster + 8 * rank < U;  // keep_beam: this workgroup owns an utterance
   long my_off0 = 0, my_off1 = 0;
   if (keep_beam && cluster + 8 * rank < U) { my_off0 = (long)st.off[cluster + 8 * rank]; my_off1 = (long)st.off[cluster + 8 * rank + 1]; }
 #if defined(UIS_RESIDENT_TIMING)
@@ -1972,7 +2024,14 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     }
 #endif
     if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
-      if (cluster + 8 * rank < U) select_fast_body<512, true, true, DP>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
+      if (did_select) {
+        if (s == 0) {  // (later steps: prepared while waiting for the previous step's last barrier)
+          select_fast_body<512, true, true, DP, 1>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
+          __syncthreads();
+        }
+        select_fast_body<512, true, true, DP, 2>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1,
+                                                 [&]() { xcd_arrive_wave0(st, cluster, s_ctl); });
+      }
       __syncthreads();
     } else {
       for (int i = rank; cluster + 8 * i < U; i += 32) {
@@ -2135,6 +2194,11 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(6);
+    if (keep_beam && did_select && s + 1 < nsteps) {
+      // arrive, prepare the next step's select out of this workgroup's own LDS tables, then wait
+      xcd_arrive(st, cluster, s_ctl);
+      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+    }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
