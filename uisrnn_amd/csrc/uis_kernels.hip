@@ -1268,17 +1268,18 @@ struct RowSink {
 // `par ^ 1` -- so the only global state a select reads back is the cluster means; the caller
 // passes the step number and the utterance's frame range.
 // DPT: the padded observation_dim when the caller knows it at compile time (0 = read m.Dp).
-// PARTS (KEEP only; 3 = everything): 1 = the PREPARATION of a step -- live slots, their list, the
-// candidate table: all of it depends on this workgroup's LDS tables only, so the resident decode
-// runs it while it waits for the other workgroups' linear_mean2 results; 2 = the rest.
+// PARTS (bit mask, KEEP only; 7 = everything): 1 and 4 = the two halves of the PREPARATION of a
+// step -- live slots and the candidate table, then the list of live slots: all of it depends on
+// this workgroup's LDS tables only, so the resident decode runs the halves while it waits at
+// the previous step's barriers; 2 = the rest.
 // `published` is called by wave 0 as soon as the step's rnn rows are written (before the table
 // updates nobody else reads): the resident decode arrives at its barrier there.
 struct SelectNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int NT, bool RES, bool KEEP, int DPT = 0, int PARTS = 3, typename Pub = SelectNoHook>
+template <int NT, bool RES, bool KEEP, int DPT = 0, int PARTS = 7, typename Pub = SelectNoHook>
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
                                                  unsigned char* smem_raw, RowSink sink, int step_in = 0,
                                                  long off0_in = 0, long off1_in = 0, Pub published = Pub()) {
-  static_assert(PARTS == 3 || KEEP, "the split needs the beam in LDS");
+  static_assert(PARTS == 7 || KEEP, "the split needs the beam in LDS");
   int tid_ = threadIdx.x;
   // inside the resident decode's step loop: keep the compiler from hoisting every tid-derived
   // address out of the loop (they would have to live -- spilled -- across the dense stages)
@@ -1394,6 +1395,8 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
       if (c <= sK[b]) scand[sbase[b] + c] = ((unsigned)b << 16) | (unsigned)c;
     }
     __syncthreads();  // (2) live flags
+  }
+  if (PARTS & 4) {
     for (int base = 0; base < S; base += NT) {  // compaction: ballot per wave, one LDS atomic per wave
       const int sl = base + tid;
       const bool lv = sl < S && slive[sl] != 0;
@@ -1406,7 +1409,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     __syncthreads();  // (3) live list
     TSTAMP(1);
   }
-  if (PARTS == 1) return;
+  if (!(PARTS & 2)) return;
   const int nlive = smisc[0];
   const int C = sbase[nb];
 
@@ -2026,7 +2029,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
       if (did_select) {
         if (s == 0) {  // (later steps: prepared while waiting for the previous step's last barrier)
-          select_fast_body<512, true, true, DP, 1>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
+          select_fast_body<512, true, true, DP, 5>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
           __syncthreads();
         }
         select_fast_body<512, true, true, DP, 2>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1,
@@ -2117,6 +2120,13 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(2);
+    const bool prep_next = keep_beam && did_select && s + 1 < nsteps;
+    if (prep_next) {
+      // arrive, do the first half of the next step's select preparation (this workgroup's own LDS
+      // tables: nobody else's data), then wait
+      xcd_arrive(st, cluster, s_ctl);
+      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+    }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(3);
 
@@ -2142,6 +2152,10 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       __syncthreads();
     }
     RSTAMP(4);
+    if (prep_next) {  // ... and the second half inside the next barrier
+      xcd_arrive(st, cluster, s_ctl);
+      select_fast_body<512, true, true, DP, 4>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+    }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
 
@@ -2194,11 +2208,6 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(6);
-    if (keep_beam && did_select && s + 1 < nsteps) {
-      // arrive, prepare the next step's select out of this workgroup's own LDS tables, then wait
-      xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
-    }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
