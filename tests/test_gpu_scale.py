@@ -136,3 +136,18 @@ def test_handles_release_their_memory():
   torch.cuda.synchronize()
   free1, _ = torch.cuda.mem_get_info()
   assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)
+
+
+def test_one_launch_decode_repeats_bit_for_bit():
+  """The in-launch hand-offs of k_decode_resident are timing dependent in principle: the same
+  batch, decoded 40 times back to back (tools/stress_resident.py runs hundreds), must give the
+  launch-per-step path's bits every time."""
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  lengths = [120 + (37 * u) % 200 for u in range(64)]
+  seqs, _ = synth.make_utterances(30_000, 64, lengths, 256)
+  dec = _capi.Decoder(params)
+  ref, _ = _decode(dec, seqs, 10, 1, 2, flags=_capi.UIS_FLAG_STEPWISE)
+  for _ in range(40):
+    out, _ = _decode(dec, seqs, 10, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
+    assert np.array_equal(out['labels'], ref['labels'])
+    assert np.array_equal(out['beam_scores'].view(np.uint32), ref['beam_scores'].view(np.uint32))
