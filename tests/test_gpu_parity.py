@@ -278,6 +278,32 @@ def test_cluster_cap_is_reported(oracle_lib):
   assert np.array_equal(out['labels'][offsets[1]:offsets[2]], ref['labels'][1])
 
 
+def test_cluster_cap_on_the_one_launch_decode(oracle_lib):
+  """Hidden size 512 (the one-launch decode): a hypothesis that outgrows max_clusters is flagged
+  per utterance exactly like on the launch-per-step path, and the doubled retry of the Python
+  host gives the oracle's labels."""
+  import uisrnn_amd
+  from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel
+  params = weights.init_params(256, 512, 1, sigma2=0.5, transition_bias=0.5, crp_alpha=50.0, seed=15)
+  rng = np.random.default_rng(16)
+  seqs = [rng.standard_normal((30, 256)), rng.standard_normal((2, 256)), rng.standard_normal((25, 256))]
+  ref = oracle_lib.decode(params, seqs, 8, 1, 2, n_threads=3)
+  assert ref['max_clusters'][0] > 8 and ref['max_clusters'][1] <= 8
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  for flags in (_capi.UIS_FLAG_RESIDENT, _capi.UIS_FLAG_STEPWISE):
+    out = dec.decode(frames, offsets, 8, 1, 2, max_clusters=8, flags=flags)
+    assert out['status'] == _capi.UIS_ERR_CLUSTER_CAP
+    assert out['overflow'].tolist() == [1, 0, 1]
+    assert np.array_equal(out['labels'][offsets[1]:offsets[2]], ref['labels'][1])
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  inference_args.beam_size = 8
+  inference_args.max_clusters = 8
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  assert model.predict(seqs, inference_args) == [x.tolist() for x in ref['labels']]
+
+
 def test_python_surface_and_demo_flow(tmp_path, oracle_lib):
   """uisrnn_amd.UISRNN.predict / parallel_predict / save+load, as the reference's demo uses them."""
   import subprocess
