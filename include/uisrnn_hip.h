@@ -101,8 +101,9 @@ typedef struct uis_decode_opts {
                                     subset, in-launch XCD barriers between the stages of a
                                     step) and fail with UIS_ERR_UNSUPPORTED where it does not
                                     apply.  It is the DEFAULT wherever it applies: look_ahead 1,
-                                    rnn_depth 1, rnn_hidden_size 512, observation_dim 256/512,
-                                    beam_size * (max_clusters + 1) <= 256, one stream, 256 CUs  */
+                                    rnn_depth 1, rnn_hidden_size 256 or 512 and observation_dim
+                                    128, 256 or 512 (after padding to 16), beam_size *
+                                    (max_clusters + 1) <= 256, one stream, a 256-CU device      */
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */

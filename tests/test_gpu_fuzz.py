@@ -52,6 +52,10 @@ SHAPES = [
     (250, 500, 1, 6, 1, 2, [9, 14, 5, 1, 20, 3, 8, 11, 2]),  # pads to 256 / 512: the one-launch decode, padded lanes
     (512, 512, 1, 5, 1, 1, [7, 12, 30]),      # one-launch decode, observation_dim 512
     (400, 505, 1, 4, 1, 3, [6]),              # one-launch decode, one utterance, tau 3
+    (250, 250, 1, 6, 1, 2, [9, 14, 5, 1, 20, 3, 8, 11, 2, 30]),  # one-launch decode, hidden 256: two ranks per feature tile
+    (120, 256, 1, 5, 1, 2, [12, 7, 40, 3]),   # one-launch decode, hidden 256, observation_dim 128: four ranks per mean tile
+    (128, 500, 1, 4, 1, 1, [25, 6]),          # one-launch decode, hidden 512, observation_dim 128
+    (512, 256, 1, 4, 1, 2, [10, 18]),         # one-launch decode, hidden 256 < observation_dim 512
 ]
 
 

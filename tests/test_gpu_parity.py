@@ -226,6 +226,10 @@ def test_resident_decode_is_bit_identical(oracle_lib):
   wide = synth.tracker_params(512, 512, 1, seed=7)      # observation_dim 512: one linear_mean2 tile per rank
   seqs5, _ = synth.make_utterances(8950, 20, 25, 512)
   _compare(wide, seqs5, 8, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)   # up to 26 clusters per hypothesis
+  small = synth.tracker_params(256, 256, 1, seed=8)     # hidden 256: two ranks share a GRU / linear_mean1 tile
+  many256, _ = synth.make_utterances(8960, 300, 11, 256)
+  _compare(small, many256, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)
+  _compare(small, seqs, 10, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)
   with pytest.raises(_capi.HipLibraryError):  # hidden size 24: not supported, must be refused
     case = golden_util.load_case('d20_h24_depth3')
     d2 = _capi.Decoder(case['params'])

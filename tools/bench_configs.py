@@ -36,6 +36,11 @@ if 'small' in which:
   run('8 utt x 500 frames, launch-per-step path', 256, 512, 8, 500, 10, 1, 2, 16, flags=STEP)
   run('256 utt x 200 frames, beam 10', 256, 512, 256, 200, 10, 1, 2, 16)
   run('256 utt x 200 frames, launch-per-step path', 256, 512, 256, 200, 10, 1, 2, 16, flags=STEP)
+if 'h256' in which:
+  run('hidden 256, D 256: 64 utt x 500 frames, beam 10', 256, 256, 64, 500, 10, 1, 2, 16)
+  run('hidden 256, D 256, launch-per-step path', 256, 256, 64, 500, 10, 1, 2, 16, flags=STEP)
+  run('hidden 256, D 128: 64 utt x 500 frames, beam 10', 128, 256, 64, 500, 10, 1, 2, 16)
+  run('hidden 256, D 128, launch-per-step path', 128, 256, 64, 500, 10, 1, 2, 16, flags=STEP)
 if 'c3' in which:
   run('configs[2]: beam 50, look_ahead 2, 16 utt x 200 frames', 256, 512, 16, 200, 50, 2, 2, 12)
 if 'c5' in which:

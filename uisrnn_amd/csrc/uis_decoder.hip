@@ -454,17 +454,18 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if ((opts->flags & UIS_FLAG_DATAFLOW) && !dataflow)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DATAFLOW needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
   // the whole decode in one launch with register-resident weights (k_decode_resident)
-  const bool resident_ok = L == 1 && m.depth == 1 && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) && G == 1 &&
+  const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 256 || m.Hp == 512) &&
+                           (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
                            select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && h->n_cu == 256 &&
                            ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
-                           resident_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024;
+                           resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
   // the default wherever it applies; UIS_FLAG_STEPWISE (or any of the per-step experiments) keeps
   // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
   const bool resident = resident_ok && !use_graph && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                         !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW));
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
-    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 512 (padded), "
-                                     "observation_dim 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 256 or 512 (padded), "
+                                     "observation_dim 128, 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
                                      "stream, a 256-CU device and no per-step path flag");
   const int tile_cap = (int)((rows_cap + 15) / 16) + 1;
   const size_t ctl_words = (size_t)8 * 16 + 8 + 8 + 2 * tile_cap + 2 * 8 * 32;
@@ -610,16 +611,20 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     if (resident) {
       // h1 into the extra slot, then ONE launch for every step of every utterance
       HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
-      const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Dp, B, Kmax, S), 96 * 1024);  // one workgroup per CU
-      if (m.Dp == 256) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<256>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(UIS_K_GRU, k_decode_resident<256>, dim3(256), dim3(512), shmem, m, gp.st);
-      } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<512>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        LAUNCH(UIS_K_GRU, k_decode_resident<512>, dim3(256), dim3(512), shmem, m, gp.st);
-      }
+      const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S), 96 * 1024);  // one workgroup per CU
+#define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
+  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
+    LAUNCH(UIS_K_GRU, (k_decode_resident<HPV, DPV>), dim3(256), dim3(512), shmem, m, gp.st);                        \
+  }
+      UIS_RESIDENT_CASE(512, 256)
+      UIS_RESIDENT_CASE(512, 512)
+      UIS_RESIDENT_CASE(512, 128)
+      UIS_RESIDENT_CASE(256, 256)
+      UIS_RESIDENT_CASE(256, 128)
+      UIS_RESIDENT_CASE(256, 512)
+#undef UIS_RESIDENT_CASE
     } else if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
       GraphCache& gc = h->gcache[g];
       const bool same = gc.exec && gc.lds == (size_t)lds.total && memcmp(&gc.st, &gp.st, sizeof(DecodeState)) == 0;

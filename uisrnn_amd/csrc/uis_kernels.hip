@@ -1900,9 +1900,9 @@ __device__ __forceinline__ void resident_tile(const f32x4 (&wr)[NG][PER], const 
 // LDS of k_decode_resident: select area | split-K partial tiles | control words | the rank's
 // linear_mean1 / linear_mean2 weight tiles | this step's row descriptors of the cluster (16-byte
 // head + 8-byte frame per row)
-__host__ __device__ inline size_t resident_lds_bytes(int Dp, int B, int Kmax, int S) {
+__host__ __device__ inline size_t resident_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
   return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4 + 64 +
-         (size_t)2 * 32 * 64 * 16 + (size_t)UIS_RES_HEAD_TILES * 16 * 24;
+         (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)UIS_RES_HEAD_TILES * 16 * 24;
 }
 
 // Diagnostic build (-DUIS_RESIDENT_TIMING): thread 0 of workgroup 0 (runs a select) and of
@@ -1919,12 +1919,15 @@ __host__ __device__ inline size_t resident_lds_bytes(int Dp, int B, int Kmax, in
 #define FSTAMP(k) do {} while (0)
 #endif
 
-template <int DP>
+template <int HP, int DP>
 __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState st) {
-  constexpr int HP = 512, NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
+  constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
+  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
   constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
   constexpr int EPT = (RC + 1) / 2;
-  static_assert(SH2 == 1 || SH2 == 2, "observation_dim 256 or 512 (padded)");
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32 && PER * UIS_KSPLIT == NKB,
+                "hidden size 256 / 512, observation_dim 128 / 256 / 512 (padded)");
+  static_assert(UIS_RES_HEAD_TILES % SH1 == 0 && UIS_RES_HEAD_TILES % SH2 == 0, "chunks start at a rank's first tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
@@ -1963,15 +1966,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const int nsteps = s_ctl[1];
 
   // ---- this thread's share of the weights, for the whole decode
-  // (W_hh: 48 registers per thread; the two mean-head tiles: 2 x 32 KB of LDS)
+  // (hidden size 512: W_hh = 48 registers per thread, the two mean-head tiles 2 x 32 KB of LDS)
   f32x4 wg[3][PER];
+  const int ft1 = rank / SH1, tpar1 = rank % SH1;  // ranks sharing a feature tile take alternate row tiles
   const int ft2 = rank / SH2, tpar2 = rank % SH2;
 #pragma unroll
   for (int kb = 0; kb < PER; ++kb) {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-      wg[g][kb] = reinterpret_cast<const f32x4*>(m.whh[0])[((size_t)(g * 32 + rank) * NKB + w * PER + kb) * 64 + lane];
-    s_w1[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)rank * NKB + w * PER + kb) * 64 + lane];
+      wg[g][kb] = reinterpret_cast<const f32x4*>(m.whh[0])[((size_t)(g * NFT1 + ft1) * NKB + w * PER + kb) * 64 + lane];
+    s_w1[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)ft1 * NKB + w * PER + kb) * 64 + lane];
     s_w2[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w2)[((size_t)ft2 * NKB + w * PER + kb) * 64 + lane];
   }
 
@@ -2070,15 +2074,17 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     for (int c0 = 0; c0 < nrt; c0 += UIS_RES_HEAD_TILES) {
       if (!single) stage_heads(c0);
       const int c1 = nrt < c0 + UIS_RES_HEAD_TILES ? nrt : c0 + UIS_RES_HEAD_TILES;
-      for (int i0 = c0; i0 < c1; i0 += RC) {
+      // of the chunk this rank takes the row tiles c0 + tpar1, c0 + tpar1 + SH1, ...: index i
+      const int my1 = c1 - c0 > tpar1 ? (c1 - c0 - tpar1 + SH1 - 1) / SH1 : 0;
+      for (int i0 = 0; i0 < my1; i0 += RC) {
         uint32_t boff[RC];
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
-          const int tile = i0 + r < c1 ? i0 + r : i0;
+          const int tile = c0 + tpar1 + SH1 * (i0 + r < my1 ? i0 + r : i0);
           const RowHead rh = lds_row_head(s_head, 16 * (tile - c0) + (t & 15));
           boff[r] = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
         }
-        const int j = rank * 16 + (t & 15);
+        const int j = ft1 * 16 + (t & 15);
         RowHead re[EPT];
         float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
         bool ework[EPT];
@@ -2086,8 +2092,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #pragma unroll
           for (int k = 0; k < EPT; ++k) {
             const int r = (t >> 8) + 2 * k;
-            const int lrow = 16 * (i0 + r) + ((t & 255) >> 4);
-            ework[k] = r < RC && i0 + r < c1 && lrow < nrows;
+            const int lrow = 16 * (c0 + tpar1 + SH1 * (i0 + r)) + ((t & 255) >> 4);
+            ework[k] = r < RC && i0 + r < my1 && lrow < nrows;
             gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
             re[k] = RowHead{0, 0, 0, 0};
             if (ework[k]) {
@@ -2100,7 +2106,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           }
         };
         FSTAMP(0);
-        resident_tile<3, PER, RC, 64>(wg, m.bhh[0] + rank * 16, HP, rs_hid, boff, c1 - i0 < RC ? c1 - i0 : RC, spart,
+        resident_tile<3, PER, RC, 64>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
                                       epilogue_operands);
         FSTAMP(1);
 #pragma unroll
@@ -2112,7 +2118,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
           const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
           st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
-          hst[((tile0 + i0 + r) * 32 + rank) * 256 + e] = out;  // the copy linear_mean1 streams
+          hst[((tile0 + c0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;  // the copy linear_mean1 streams
         }
         FSTAMP(2);
         __syncthreads();  // spart (and, chunked, the descriptors) are reused
@@ -2131,22 +2137,23 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(3);
 
     // ---- linear_mean1 + relu -> a1 (needs no descriptors: row tile in, row tile out)
-    for (int i0 = 0; i0 < nrt; i0 += RC) {
+    const int my1h = nrt > tpar1 ? (nrt - tpar1 + SH1 - 1) / SH1 : 0;  // this rank's row tiles tpar1, tpar1 + SH1, ...
+    for (int i0 = 0; i0 < my1h; i0 += RC) {
       uint32_t boff[RC];
 #pragma unroll
       for (int r = 0; r < RC; ++r) {
-        const int tile = i0 + r < nrt ? i0 + r : i0;
-        boff[r] = (uint32_t)((((tile0 + tile) * 32) * 256 + (t & 15) * 16) * 4);
+        const int tile = tpar1 + SH1 * (i0 + r < my1h ? i0 + r : i0);
+        boff[r] = (uint32_t)((((tile0 + tile) * NFT1) * 256 + (t & 15) * 16) * 4);
       }
       f32x4 w1r[1][PER];
 #pragma unroll
       for (int kb = 0; kb < PER; ++kb) w1r[0][kb] = s_w1[(w * PER + kb) * 64 + lane];
-      resident_tile<1, PER, RC, 1024>(w1r, m.b1 + rank * 16, 0, rs_hst, boff, nrt - i0 < RC ? nrt - i0 : RC, spart, []() {});
+      resident_tile<1, PER, RC, 1024>(w1r, m.b1 + ft1 * 16, 0, rs_hst, boff, my1h - i0 < RC ? my1h - i0 : RC, spart, []() {});
       for (int e = t; e < RC * 256; e += 512) {
-        const int r = e >> 8, lrow = 16 * (i0 + r) + ((e & 255) >> 4);
-        if (lrow < nrows) {
+        const int r = e >> 8, tile = tpar1 + SH1 * (i0 + r), lrow = 16 * tile + ((e & 255) >> 4);
+        if (i0 + r < my1h && lrow < nrows) {
           const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
-          st.a1[((tile0 + i0 + r) * 32 + rank) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
+          st.a1[((tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
         }
       }
       __syncthreads();
@@ -2170,7 +2177,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
           const int tile = c0 + tpar2 + SH2 * (i0 + r < my_tiles ? i0 + r : i0);
-          boff[r] = (uint32_t)((((tile0 + tile) * 32) * 256 + (t & 15) * 16) * 4);
+          boff[r] = (uint32_t)((((tile0 + tile) * NFT1) * 256 + (t & 15) * 16) * 4);
         }
         const int f = ft2 * 16 + (t & 15);
         RowHead re[EPT];
