@@ -242,6 +242,32 @@ def test_reference_checkpoint_is_read_without_torch(monkeypatch):
   assert got['crp_alpha'] == pytest.approx(float(expect['crp_alpha']))
 
 
+def test_checkpoint_is_written_without_torch(tmp_path, monkeypatch):
+  """save() produces the reference's torch.save file with torch unimportable; torch.load (the
+  reference's reader) then returns real tensors with the same bits."""
+  params = weights.init_params(12, 10, 2, sigma2=0.3, transition_bias=0.15, crp_alpha=2.0, seed=5)
+  params['rnn_init_hidden'] = np.random.default_rng(6).standard_normal((2, 10)).astype(np.float32)
+  path = str(tmp_path / 'written.uisrnn')
+  with monkeypatch.context() as mp:
+    mp.setitem(sys.modules, 'torch', None)
+    weights.save_checkpoint(params, path)
+    _same_params(weights.load_checkpoint(path), {**params, 'transition_bias_denominator': 0.0})
+  import torch
+  raw = torch.load(path, weights_only=False)
+  assert list(raw) == ['rnn_state_dict', 'rnn_init_hidden', 'transition_bias',
+                       'transition_bias_denominator', 'crp_alpha', 'sigma2']
+  state = weights.state_dict_from_params(params)
+  assert list(raw['rnn_state_dict']) == list(state)
+  for key, val in state.items():
+    got = raw['rnn_state_dict'][key]
+    assert isinstance(got, torch.Tensor) and got.dtype == torch.float32 and got.is_contiguous()
+    assert np.array_equal(got.numpy(), val), key
+  assert raw['rnn_init_hidden'].shape == (2, 1, 10) and raw['crp_alpha'] == 2.0
+  # torch can also take it through its own nn.Module machinery, like the reference's load()
+  gru = torch.nn.GRU(12, 10, 2)
+  gru.load_state_dict({k[len('gru.'):]: v for k, v in raw['rnn_state_dict'].items() if k.startswith('gru.')})
+
+
 def test_torch_free_reader_matches_torch_load(tmp_path):
   import pickle
   import torch

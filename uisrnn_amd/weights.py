@@ -14,8 +14,8 @@ host keeps a dict:
   transition_bias, crp_alpha                             python floats
   transition_bias_denominator                            float (carried for save())
 
-Checkpoints in the reference's torch.save format are READ without PyTorch
-(read_torch_zip); writing one (save_checkpoint) still uses torch.save.
+Checkpoints in the reference's torch.save format are read (read_torch_zip) and
+written (write_torch_zip) without PyTorch.
 """
 
 import numpy as np
@@ -255,14 +255,99 @@ def load_checkpoint(filepath):
       var_dict.get('transition_bias_denominator', 0.0))
 
 
+# ---------------------------------------------------------------------------
+# Writing that format WITHOUT PyTorch.  The pickle is produced by the pure-Python
+# pickler with two stand-ins: _TorchGlobal (written as a bare GLOBAL opcode --
+# the module is never imported here) and _Tensor (reduces to
+# torch._utils._rebuild_tensor_v2 over a storage persistent id, exactly what
+# torch.save emits for a contiguous CPU float tensor).
+
+
+class _TorchGlobal:
+  def __init__(self, module, name):
+    self.module, self.name = module, name
+
+  def __call__(self, *args):  # (the pickler only checks that a reduce function is callable)
+    raise TypeError('{}.{} is a name in a pickle, not a function'.format(self.module, self.name))
+
+
+class _Storage:
+  def __init__(self, key, array):
+    self.key, self.array = key, array
+
+
+class _Tensor:
+  def __init__(self, storage, shape):
+    self.storage, self.shape = storage, tuple(int(n) for n in shape)
+
+  def __reduce__(self):
+    stride, acc = [], 1
+    for n in reversed(self.shape):
+      stride.append(acc)
+      acc *= n
+    import collections  # pylint: disable=import-outside-toplevel
+    return (_TorchGlobal('torch._utils', '_rebuild_tensor_v2'),
+            (self.storage, 0, self.shape, tuple(reversed(stride)), False,
+             collections.OrderedDict()))
+
+
+def write_torch_zip(obj, filepath, tensor_keys=('rnn_state_dict',)):
+  """torch.save(obj, filepath) for a dict whose `tensor_keys` members are dicts
+  of float32 numpy arrays (written as torch tensors); everything else --
+  numpy arrays, floats, None -- is pickled as it is.  No PyTorch involved; the
+  result loads with torch.load(..., weights_only=False) and read_torch_zip."""
+  import collections  # pylint: disable=import-outside-toplevel
+  import io           # pylint: disable=import-outside-toplevel
+  import pickle       # pylint: disable=import-outside-toplevel
+  import zipfile      # pylint: disable=import-outside-toplevel
+  storages = []
+  out = {}
+  for key, val in obj.items():
+    if key in tensor_keys:
+      tensors = collections.OrderedDict()
+      for name, arr in val.items():
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        storage = _Storage(str(len(storages)), arr)
+        storages.append(storage)
+        tensors[name] = _Tensor(storage, arr.shape)
+      out[key] = tensors
+    else:
+      out[key] = val
+
+  class _Pickler(pickle._Pickler):  # pylint: disable=protected-access
+    dispatch = dict(pickle._Pickler.dispatch)  # pylint: disable=protected-access
+
+    def persistent_id(self, item):
+      if isinstance(item, _Storage):
+        return ('storage', _TorchGlobal('torch', 'FloatStorage'), item.key, 'cpu',
+                int(item.array.size))
+      return None
+
+    def _save_torch_global(self, item):
+      self.write(pickle.GLOBAL + item.module.encode() + b'\n' + item.name.encode() + b'\n')
+      self.memoize(item)
+
+    dispatch[_TorchGlobal] = _save_torch_global
+
+  buf = io.BytesIO()
+  _Pickler(buf, protocol=2).dump(out)
+  name = 'archive'
+  with zipfile.ZipFile(filepath, 'w', compression=zipfile.ZIP_STORED) as archive:
+    archive.writestr(name + '/data.pkl', buf.getvalue())
+    archive.writestr(name + '/byteorder', 'little')
+    for storage in storages:
+      archive.writestr('{}/data/{}'.format(name, storage.key),
+                       storage.array.astype('<f4', copy=False).tobytes())
+    archive.writestr(name + '/version', '3\n')
+
+
 def save_checkpoint(params, filepath):
-  """Write the reference's checkpoint format (uisrnn/uisrnn.py:141-147)."""
-  import torch  # pylint: disable=import-outside-toplevel
-  state = {k: torch.from_numpy(np.array(v, dtype=np.float32))
-           for k, v in state_dict_from_params(params).items()}
+  """Write the reference's checkpoint format (uisrnn/uisrnn.py:141-147), without
+  PyTorch: a file the reference's own UISRNN.load() reads (where its torch.load
+  accepts numpy members, i.e. torch < 2.6 or weights_only=False)."""
   depth, hid = params['rnn_depth'], params['rnn_hidden_size']
-  torch.save({
-      'rnn_state_dict': state,
+  write_torch_zip({
+      'rnn_state_dict': state_dict_from_params(params),
       'rnn_init_hidden': np.asarray(
           params['rnn_init_hidden'], dtype=np.float32).reshape(depth, 1, hid),
       'transition_bias': params['transition_bias'],
