@@ -67,9 +67,11 @@ def main():
   # the reference predicts one utterance at a time; a list is one GPU batch here
   predicted = model.predict(test_sequences, inference_args)
   accuracies = []
+  test_record = []
   for truth, labels in zip(test_cluster_ids, predicted):
     accuracy = uisrnn.compute_sequence_match_accuracy(truth, labels)
     accuracies.append(accuracy)
+    test_record.append((accuracy, len(truth)))  # demo.py:61-64
     print('Ground truth labels: {} ...'.format(truth[:8]))
     print('Predicted labels:    {} ...'.format(labels[:8]))
     print('accuracy {:.4f}  ({} frames)'.format(accuracy, len(labels)))
@@ -82,6 +84,8 @@ def main():
   print('Performance: averaged accuracy {:.6f}, accuracy numbers for all testing '
         'sequences: {}'.format(float(np.mean(accuracies)),
                                ' '.join('{:.4f}'.format(a) for a in accuracies)))
+  # the reference's closing summary (demo.py:68-70; also appended to layer_*_result.txt)
+  print(uisrnn.output_result(model_args, uisrnn.parse_arguments(rest)[1], test_record))
   stats = model.last_stats or {}
   print('Decode: {:.2f} ms on device, {} rnn rows'.format(
       stats.get('decode_ms', 0.0), stats.get('rnn_rows', 0)))

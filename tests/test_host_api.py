@@ -151,6 +151,23 @@ def test_initial_cluster_cap_keeps_wide_beams_on_the_fast_path():
   assert cap(20, explicit=32) == 32               # the caller's word wins
 
 
+def test_output_result_known_answer(tmp_path, monkeypatch):
+  """uisrnn.output_result (uisrnn/utils.py:253-285): the expected text below is what the
+  reference prints for these arguments (recorded from the reference in the dev container)."""
+  monkeypatch.chdir(tmp_path)
+  model_args, training_args, _ = uisrnn_amd.parse_arguments([])
+  text = uisrnn_amd.output_result(model_args, training_args, [(0.93, 120), (1.0, 64), (0.5, 7)])
+  expected = (
+      'Config:\n  sigma_alpha: 1.0\n  sigma_beta: 1.0\n  crp_alpha: 1.0\n  learning rate: 0.001\n'
+      '  regularization: 1e-05\n  batch size: 10\n\nPerformance:\n  averaged accuracy: 0.810000\n'
+      '  accuracy numbers for all testing sequences:\n    0.930000\n    1.000000\n    0.500000\n'
+      + '=' * 80 + '\n')
+  assert text == expected
+  assert (tmp_path / 'layer_512_1_0.2_result.txt').read_text() == expected
+  uisrnn_amd.output_result(model_args, training_args, [(1.0, 3)])       # appends, like the reference
+  assert (tmp_path / 'layer_512_1_0.2_result.txt').read_text().count('Config:') == 2
+
+
 def test_struct_layouts_match_header():
   """ctypes mirrors of the header structs (LP64): sizes and a few offsets."""
   assert ctypes.sizeof(_capi.ModelDesc) == 16 + 10 * 8 + 16
