@@ -351,9 +351,10 @@ def test_python_surface_and_demo_flow(tmp_path, oracle_lib):
   assert out.returncode != 0  # missing file is an error, not a silent fallback
   root = __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))
   out = subprocess.run([_sys.executable, __import__('os').path.join(root, 'demo.py')],
-                       capture_output=True, text=True, cwd=root)
+                       capture_output=True, text=True, cwd=str(tmp_path))  # (output_result appends a file to the cwd)
   assert out.returncode == 0, out.stderr[-2000:]
   assert 'averaged accuracy' in out.stdout
+  assert (tmp_path / 'layer_512_1_0.2_result.txt').exists()
   acc = float(out.stdout.split('averaged accuracy')[1].split(',')[0])
   assert acc > 0.97
 
