@@ -220,7 +220,9 @@ def main():
       algo_bytes = int(4 * 3 * hid * hid + rows_algo * 4 * (hid + 3 * hid + hid))
     achieved = flop_per_launch / (avg_us * 1e-6) / 1e12
     roofline = {
-        'bound': 'mfma', 'kernel': kernel, 'achieved': round(achieved, 3),
+        'bound': 'mfma', 'kernel': kernel,
+        'decode_path': 'one launch (k_decode_resident)' if resident else 'launch per step',
+        'achieved': round(achieved, 3),
         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         'traffic': committed_traffic(kernel),
