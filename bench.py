@@ -231,6 +231,9 @@ def main():
         'rows_per_step_algorithmic': round(rows_algo, 1),
         'rows_per_step_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
         'path_frac_fp32': round(value / world * flop_per_frame / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+        # SURVEY.md 8(d) asks for both fractions; HBM is not the binding one (arithmetic intensity ~300 FLOP/B)
+        'path_frac_hbm': round(value / world * tau * (4 * dim * (1 + beam * 4 + 2 * beam) + 8 * hid * beam + 8 * beam)
+                               / (PEAK_HBM_GBS * 1e9), 4),
         'kernel_ms_profile_pass': {k: round(v, 3) for k, v in prof['kernel_ms'].items()},
     }
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
