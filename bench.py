@@ -1,31 +1,44 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X UIS-RNN decode path (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
 
 One "step" = one pass of the hot path (uisrnn.UISRNN.predict over a list,
-uisrnn/uisrnn.py:564-590) over one batch of synthetic utterances:
-BASELINE.json configs[1] -- 64 utterances x 500 frames x 256-dim, beam_size=10,
-look_ahead=1, test_iteration=2, <= 4 speakers -- per GPU (weak scaling:
-utterances are independent, every rank decodes its own 64; the only
-collective is the final all_gather of the int32 labels over RCCL).
+uisrnn/uisrnn.py:564-590) over one batch of synthetic utterances.  --config picks
+the BASELINE.json `configs[i]` workload (per GPU):
 
-The frame stream and the label buffer live in HBM before the timed region
-starts (torch is used for device memory and torch.distributed only).
+  1 (default)  64 utterances x 500 frames x 256-dim, beam 10, look_ahead 1   <- the metric's config
+  2            beam 50, look_ahead 2, 64 utterances x 1000 frames (wide-beam stress)
+  3            the per-GPU share of configs[3]: 1024 utterances x 1000 frames, beam 10
+  4            observation_dim 512, rnn_hidden_size 512, beam 20, 64 x 500 frames
+
+Multi-GPU (the reference's analogue is parallel_predict,
+uisrnn/uisrnn.py:593-623): utterances are independent, so every rank decodes its own
+utterances (weak scaling) and the only collective is the final all_gather of the int32
+labels (RCCL over xGMI).  `--gpus N` with N > 1 and no WORLD_SIZE in the environment
+re-executes itself under `python -m torch.distributed.run --nproc-per-node N`; under
+torchrun (the driver's launch) it reads RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to
+run when fewer than N HIP devices are visible.
+
+The frame stream and the label buffer live in HBM before the timed region starts
+(torch is used for device memory and torch.distributed only).  `value` is that
+HBM-resident rate; `value_host_buffers` is the same pass through uis_decode from
+pinned host memory (H2D of the frames and D2H of the labels inside the clock,
+SURVEY.md 8d).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     -- the dominant kernel timed with HIP events on the decode stream
-                  (UIS_FLAG_PROFILE pass): k_decode_resident, the one-launch beam
-                  search, where it applies (this workload); k_dense_gru, the
-                  hidden-side GRU GEMM, on the launch-per-step path (--flags 128)
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm)
-                  timed on this box's host cores on a bounded sample; the GPU
-                  labels are checked against it.
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on
+                  this box's host cores on a bounded sample (the GPU labels are checked
+                  against it), next to the reference's own measured rates
+                  (tests/golden/reference_cpu_rate.json, recorded in the dev container:
+                  google/uis-rnn cannot travel to the GPU box).
 """
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -37,11 +50,49 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
-CONFIG = dict(workload='configs[1]: 64 utt x 500 frames x 256-dim, beam 10, '
-                       'look_ahead 1, test_iteration 2, <=4 speakers',
-              utterances_per_gpu=64, frames=500, observation_dim=256,
-              rnn_hidden_size=512, rnn_depth=1, beam_size=10, look_ahead=1,
-              test_iteration=2, model='closed-form tracker (uisrnn_amd.synth)')
+CONFIGS = {
+    1: dict(workload='configs[1]: 64 utt x 500 frames x 256-dim, beam 10, look_ahead 1, '
+                     'test_iteration 2, <=4 speakers',
+            utterances_per_gpu=64, frames=500, observation_dim=256, rnn_hidden_size=512,
+            rnn_depth=1, beam_size=10, look_ahead=1, test_iteration=2, max_clusters=16),
+    2: dict(workload='configs[2]: beam 50, look_ahead 2, 64 utt x 1000 frames x 256-dim, '
+                     'test_iteration 2',
+            utterances_per_gpu=64, frames=1000, observation_dim=256, rnn_hidden_size=512,
+            rnn_depth=1, beam_size=50, look_ahead=2, test_iteration=2, max_clusters=12),
+    3: dict(workload='configs[3] per-GPU share: 1024 utt x 1000 frames x 256-dim, beam 10, '
+                     'look_ahead 1, test_iteration 2',
+            utterances_per_gpu=1024, frames=1000, observation_dim=256, rnn_hidden_size=512,
+            rnn_depth=1, beam_size=10, look_ahead=1, test_iteration=2, max_clusters=16),
+    4: dict(workload='configs[4]: observation_dim 512, rnn_hidden_size 512, beam 20, '
+                     '64 utt x 500 frames, look_ahead 1, test_iteration 2',
+            utterances_per_gpu=64, frames=500, observation_dim=512, rnn_hidden_size=512,
+            rnn_depth=1, beam_size=20, look_ahead=1, test_iteration=2, max_clusters=11),
+}
+TRAINED_D256 = os.path.join(ROOT, 'tests', 'golden', 'trained_d256.uisrnn')
+
+
+def flops_per_frame(cfg, clusters=4):
+  """algorithmic FLOPs per input frame (test_iteration decode steps each)."""
+  dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
+  beam, look, tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
+  p = 3 * hid * dim + 3 * hid * hid + hid * hid + dim * hid
+  if look == 1:
+    per_step = 2.0 * p * beam + 3.0 * dim * beam * (clusters + 1)
+  else:
+    # per window of `look` frames: the first look-1 sub-steps evaluate CoreRNN for every
+    # prefix, the last one for the winners only (SURVEY.md 8d, config #3)
+    prefixes, total = beam, 0.0
+    for _ in range(look - 1):
+      prefixes *= clusters + 1
+      total += 2.0 * p * prefixes
+    per_step = (total + 2.0 * p * beam) / look
+  return tau * per_step
+
+
+def bytes_per_step(cfg, clusters=4):
+  """minimum state traffic per decode step and utterance."""
+  dim, hid, beam = cfg['observation_dim'], cfg['rnn_hidden_size'], cfg['beam_size']
+  return 4 * dim * (1 + beam * clusters + 2 * beam) + 8 * cfg['rnn_depth'] * hid * beam + 8 * beam
 
 
 def committed_traffic(kernel):
@@ -63,61 +114,147 @@ def committed_traffic(kernel):
     return None
 
 
-def reference_rate_note():
-  """The reference's own predict() rate, recorded when the fixtures were generated.
-
-  google/uis-rnn cannot run on the GPU box (it is not shipped there); its wall time per
-  utterance was stored in tests/golden/tracker_d256.npz by make_golden.py (dev container,
-  8 vCPU Xeon, one torch thread, same model family and beam as this benchmark).
-  """
+def reference_rates():
+  """The reference's own measured predict() rates (dev container), or None."""
   try:
-    data = np.load(os.path.join(ROOT, 'tests', 'golden', 'tracker_d256.npz'))
-    frames = sum(len(data['run0_labels_{}'.format(u)]) for u in range(int(data['n_utt'])))
-    secs = float(np.sum(data['run0_secs']))
-    return ('google/uis-rnn predict(): {:.1f} frames/s ({} frames in {:.0f} s, beam 10, D=256, '
-            'H=512, 1 thread, dev container; tests/golden/tracker_d256.npz)'.format(
-                frames / secs, frames, secs))
-  except Exception:  # pylint: disable=broad-except
+    with open(os.path.join(ROOT, 'tests', 'golden', 'reference_cpu_rate.json')) as f:
+      rec = json.load(f)
+    return {'whole_box_frames_per_s': round(rec['whole_box_frames_per_s'], 2),
+            'one_process_one_thread_frames_per_s': round(rec['one_process_one_thread_frames_per_s'], 2),
+            'cores': rec['cores'], 'box': rec['box'], 'workload': rec['workload'],
+            'source': 'tests/golden/reference_cpu_rate.json (google/uis-rnn run by '
+                      'tests/golden/make_trained.py wholebox)'}
+  except (OSError, KeyError, ValueError):
     return None
 
 
-def parse():
+def parse(argv=None):
   ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=10)
-  ap.add_argument('--warmup', type=int, default=2)
-  ap.add_argument('--utterances', type=int, default=CONFIG['utterances_per_gpu'])
-  ap.add_argument('--frames', type=int, default=CONFIG['frames'])
-  ap.add_argument('--beam_size', type=int, default=CONFIG['beam_size'])
+  ap.add_argument('--gpus', type=int, default=None)
+  ap.add_argument('--steps', type=int, default=None)
+  ap.add_argument('--warmup', type=int, default=None)
+  ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS))
+  ap.add_argument('--utterances', type=int, default=None, help='utterances per GPU')
+  ap.add_argument('--frames', type=int, default=None)
+  ap.add_argument('--beam_size', type=int, default=None)
+  ap.add_argument('--model', default='auto', choices=['auto', 'trained', 'tracker'],
+                  help='trained = tests/golden/trained_d256.uisrnn (the reference\'s fit, '
+                       'SURVEY.md 8d; D=256 configs only); tracker = closed-form weights '
+                       '(uisrnn_amd.synth); auto = trained where it applies')
   ap.add_argument('--no_cpu_baseline', action='store_true')
+  ap.add_argument('--no_host_buffers', action='store_true',
+                  help='skip the PCIe-inclusive pass (value_host_buffers)')
   ap.add_argument('--cpu_sample', type=int, default=0,
                   help='utterances in the CPU-baseline sample (0 = auto)')
   ap.add_argument('--flags', type=int, default=0, help='UIS_FLAG_* for the timed run')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
-                  help='collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to '
-                       'exercise the multi-rank path on a box with fewer GPUs than ranks)')
+                  help='collective backend for N > 1 (nccl = RCCL over xGMI)')
   ap.add_argument('--force_dist', action='store_true',
                   help='initialise the process group and run the gather even with one rank '
                        '(exercises the RCCL calls on a single-GPU box)')
   ap.add_argument('--streams', type=int, default=0,
                   help='utterance groups decoded concurrently (0 = library default)')
-  return ap.parse_args()
+  return ap.parse_args(argv)
 
 
-def main():
-  args = parse()
+def free_port():
+  with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def respawn_under_torchrun(n_gpus, argv):
+  """--gpus N without a launcher: one rank per GPU through torch.distributed.run."""
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+         '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+  os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  os.execv(sys.executable, cmd)
+
+
+def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None):
+  """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both
+  sides; returns the MAX over ranks of the elapsed seconds.
+
+  step_fn(): one pass of the hot path (incl. the final label gather when dist is set);
+  sync_fn(): wait for this rank's device.  `dist` is torch.distributed or None.
+  """
+  import torch  # pylint: disable=import-outside-toplevel
+  for _ in range(warmup):
+    step_fn()
+  sync_fn()
+  if dist is not None:
+    dist.barrier()
+  sync_fn()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step_fn()
+  sync_fn()
+  if dist is not None:
+    dist.barrier()
+  elapsed = time.perf_counter() - t0
+  if dist is not None:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+  return elapsed
+
+
+def load_model(cfg, which):
+  """(params, description): the trained checkpoint where it applies, else closed-form weights."""
+  from uisrnn_amd import synth, weights  # pylint: disable=import-outside-toplevel
+  dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
+  can_train = dim == 256 and hid == 512 and os.path.exists(TRAINED_D256)
+  if which == 'trained' and not can_train:
+    raise SystemExit('--model trained needs tests/golden/trained_d256.uisrnn and a D=256/H=512 config')
+  if which in ('auto', 'trained') and can_train:
+    return (weights.load_checkpoint(TRAINED_D256),
+            'tests/golden/trained_d256.uisrnn: trained by the reference\'s fit(), 300 iterations '
+            '(tests/golden/make_trained.py)')
+  return (synth.tracker_params(dim, hid, cfg['rnn_depth'], seed=0),
+          'closed-form tracker (uisrnn_amd.synth)')
+
+
+def main(argv=None):
+  args = parse(argv)
+  env_world = os.environ.get('WORLD_SIZE')
+  if env_world is None and args.gpus is not None and args.gpus > 1:
+    import torch  # pylint: disable=import-outside-toplevel
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+      raise SystemExit('bench.py --gpus {}: only {} HIP device(s) visible; one rank per GPU is '
+                       'required (no folding of ranks onto one device)'.format(args.gpus, n_dev))
+    respawn_under_torchrun(args.gpus, sys.argv[1:] if argv is None else argv)
+  world = int(env_world or '1')
+  if args.gpus is not None and args.gpus != world:
+    raise SystemExit('bench.py --gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
   import torch  # device memory + torch.distributed only
   from uisrnn_amd import _capi, synth
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  cfg = dict(CONFIGS[args.config])
+  if args.utterances is not None:
+    cfg['utterances_per_gpu'] = args.utterances
+  if args.frames is not None:
+    cfg['frames'] = args.frames
+  if args.beam_size is not None:
+    cfg['beam_size'] = args.beam_size
+  if args.utterances is not None or args.frames is not None or args.beam_size is not None:
+    cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}]'.format(
+        cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'])
+  big = cfg['utterances_per_gpu'] * cfg['frames'] > 200_000 or cfg['look_ahead'] > 1
+  steps = args.steps if args.steps is not None else (3 if big else 10)
+  warmup = args.warmup if args.warmup is not None else (1 if big else 2)
+
   n_dev = torch.cuda.device_count()
   if n_dev < 1:
     raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
-  # one GPU per rank; if the launcher narrowed visibility to one device per process the
-  # modulo maps every rank to its only device
-  dev_index = local_rank % n_dev
+  if local_rank >= n_dev:
+    raise RuntimeError('rank {} (local rank {}) has no GPU of its own: {} HIP device(s) visible, '
+                       'one rank per GPU is required'.format(rank, local_rank, n_dev))
+  dev_index = local_rank
   torch.cuda.set_device(dev_index)
   use_dist = world > 1 or args.force_dist
   if use_dist:
@@ -133,9 +270,11 @@ def main():
     dist = None
   dev = torch.device('cuda', dev_index)
 
-  dim, hid = CONFIG['observation_dim'], CONFIG['rnn_hidden_size']
-  n_utt, n_frames = args.utterances, args.frames
-  params = synth.tracker_params(dim, hid, CONFIG['rnn_depth'], seed=0)
+  dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
+  n_utt, n_frames = cfg['utterances_per_gpu'], cfg['frames']
+  beam, look, tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
+  params, model_note = load_model(cfg, args.model)
+  cfg['model'] = model_note
   seqs, _ = synth.make_utterances(10_000 + rank * n_utt, n_utt, n_frames, dim)
   frames = np.concatenate(seqs, axis=0).astype(np.float32)
   offsets = np.arange(n_utt + 1, dtype=np.int64) * n_frames
@@ -148,77 +287,94 @@ def main():
   gather_dev = dev if args.backend == 'nccl' else torch.device('cpu')
   gathered = (torch.empty(world * total_frames, dtype=torch.int32, device=gather_dev)
               if use_dist else None)
-  beam, look, tau = args.beam_size, CONFIG['look_ahead'], CONFIG['test_iteration']
+  state = {'last': None, 'cap': cfg['max_clusters']}
 
-  def one_step(flags):
-    out = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
-                                d_labels.data_ptr(), d_scores.data_ptr(),
-                                max_clusters=16, flags=flags,
-                                n_streams=args.streams)
-    if out['status'] != 0:
-      raise RuntimeError('decode hit the cluster cap in the benchmark workload')
+  def decode_once(flags):
+    while True:
+      out = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
+                                  d_labels.data_ptr(), d_scores.data_ptr(),
+                                  max_clusters=state['cap'], flags=flags,
+                                  n_streams=args.streams)
+      if out['status'] == 0:
+        return out
+      # a surviving hypothesis needed more clusters than the tables hold: the Python host's
+      # policy (uisrnn_amd/uisrnn.py) is to decode again with twice the room; only warm-up
+      # passes may do that -- a timed pass that retried would be counted as failed
+      if state.get('timing'):
+        raise RuntimeError('decode hit the cluster cap inside the timed region')
+      state['cap'] *= 2
+
+  def one_step():
+    state['last'] = decode_once(args.flags)
     if use_dist:  # the final gather: the only collective of the path (RCCL over xGMI)
       dist.all_gather_into_tensor(
           gathered, d_labels if args.backend == 'nccl' else d_labels.cpu())
-    return out
 
-  for _ in range(args.warmup):
-    one_step(args.flags)
-  if use_dist:
-    dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  last = None
-  for _ in range(args.steps):
-    last = one_step(args.flags)
-  torch.cuda.synchronize()
-  if use_dist:
-    dist.barrier()
-  elapsed = time.perf_counter() - t0
-  if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-  ms_per_step = 1e3 * elapsed / max(args.steps, 1)
-  value = world * total_frames * args.steps / elapsed
-  stats = last['stats'] if last else {}
+  decode_once(args.flags)  # settles the cluster cap before anything is timed
+  state['timing'] = True
+  elapsed = timed_region(one_step, torch.cuda.synchronize, steps, warmup, dist, gather_dev)
+  ms_per_step = 1e3 * elapsed / max(steps, 1)
+  value = world * total_frames * steps / elapsed
+  stats = state['last']['stats'] if state['last'] else {}
 
   result = None
   if rank == 0:
+    # ---- PCIe-inclusive rate: pinned host frames in, labels out, same passes
+    host_rate = None
+    if not args.no_host_buffers:
+      pin_frames = torch.from_numpy(frames).pin_memory()
+      pin_labels = torch.empty(total_frames, dtype=torch.int32).pin_memory()
+      pin_scores = torch.empty(n_utt, dtype=torch.float32).pin_memory()
+      def host_step():
+        rc = decoder.decode_host(pin_frames.data_ptr(), offsets, beam, look, tau,
+                                 pin_labels.data_ptr(), pin_scores.data_ptr(),
+                                 max_clusters=state['cap'], flags=args.flags)
+        if rc['status'] != 0:
+          raise RuntimeError('host-buffer decode hit the cluster cap')
+      el = timed_region(host_step, torch.cuda.synchronize, max(steps // 2, 1), 1)
+      host_rate = total_frames * max(steps // 2, 1) / el
+      if not np.array_equal(pin_labels.numpy(), d_labels.cpu().numpy()):
+        raise RuntimeError('host-buffer decode and device-buffer decode disagree')
+
     # ---- roofline of the dominant kernel: HIP events around every launch
     prof = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
                                  d_labels.data_ptr(), d_scores.data_ptr(),
-                                 max_clusters=16,
+                                 max_clusters=state['cap'],
                                  flags=args.flags | _capi.UIS_FLAG_PROFILE)['stats']
     n_steps = prof['n_steps']
-    gru_ms = prof['kernel_ms']['gru']
-    gru_launches = max(prof['kernel_launches']['gru'], 1)
     resident = prof['kernel_launches']['select'] == 0 and prof['kernel_launches']['gru'] == 1
-    # start/stop events of hipExtLaunchKernelGGL = the dispatch's own begin/end timestamps
-    # (cross-check: rocprofv3 --kernel-trace average in profiles/)
-    avg_us = 1e3 * gru_ms / gru_launches
     rows_algo = prof['rnn_rows_nodedup'] / max(n_steps, 1)
-    flop_per_frame = tau * (2.0 * (3 * hid * dim + 3 * hid * hid + hid * hid + dim * hid) * beam
-                            + 3.0 * dim * beam * 5)
+    rows_exec = prof['rnn_rows'] / max(n_steps, 1)
+    fpf = flops_per_frame(cfg)
+    ceiling = PEAK_F32_MFMA_TFLOPS * 1e12 / fpf
+    bps = bytes_per_step(cfg)
     if resident:
       # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
       # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
       # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
       kernel = 'k_decode_resident'
-      flop_per_launch = 2.0 * (3 * hid * hid + hid * hid + dim * hid) * prof['rnn_rows_nodedup']
-      # SURVEY.md 8(d), per decode step and utterance: x_t, the candidates' means, the winners'
-      # h / mean in and out, back-pointers = 4D(1 + B*K + 2B) + 8*H*B + 8B with K = 4 clusters;
-      # the weights once.  (Served by the XCD's L2 for the most part: `traffic` is what reached HBM.)
-      algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) +
-                       n_utt * n_steps * (4 * dim * (1 + beam * 4 + 2 * beam) + 8 * hid * beam + 8 * beam))
+      kclass = 'gru'
+      per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
+      flop_per_launch = per_row * prof['rnn_rows_nodedup']
+      flop_exec = per_row * prof['rnn_rows']
+      algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) + n_utt * n_steps * bps)
     else:
-      # one launch = one step's hidden-side GRU matvecs (3H x H MACs per surviving hypothesis)
-      kernel = 'k_dense_gru'
-      flop_per_launch = 2.0 * 3 * hid * hid * rows_algo
-      # W_hh once + per row: h in, gi0 in (3H), h' out
-      algo_bytes = int(4 * 3 * hid * hid + rows_algo * 4 * (hid + 3 * hid + hid))
-    achieved = flop_per_launch / (avg_us * 1e-6) / 1e12
+      # the class that takes the most device time; for the GRU GEMM one launch = one step's
+      # hidden-side matvecs (3H x H MACs per surviving hypothesis / prefix)
+      kclass = max(('gru', 'head1', 'head2', 'select', 'expand', 'upper_in'),
+                   key=lambda k: prof['kernel_ms'][k])
+      kernel = {'gru': 'k_dense_gru', 'head1': 'k_dense_head1', 'head2': 'k_dense_head2',
+                'select': 'k_select_fast', 'expand': 'k_window', 'upper_in': 'k_dense_upper_in'}[kclass]
+      launches_gru = max(prof['kernel_launches']['gru'], 1)
+      rows_per_launch = prof['rnn_rows_nodedup'] / launches_gru
+      per_row = {'gru': 2.0 * 3 * hid * hid, 'head1': 2.0 * hid * hid, 'head2': 2.0 * dim * hid}.get(kclass, 0.0)
+      flop_per_launch = per_row * rows_per_launch
+      flop_exec = per_row * prof['rnn_rows'] / launches_gru
+      algo_bytes = int(4 * 3 * hid * hid + rows_per_launch * 4 * (hid + 3 * hid + hid))
+    k_launches = max(prof['kernel_launches'][kclass], 1)
+    avg_us = 1e3 * prof['kernel_ms'][kclass] / k_launches
+    achieved = flop_per_launch / (avg_us * 1e-6) / 1e12 if flop_per_launch else 0.0
+    executed = flop_exec / (avg_us * 1e-6) / 1e12 if flop_exec else 0.0
     roofline = {
         'bound': 'mfma', 'kernel': kernel,
         'decode_path': 'one launch (k_decode_resident)' if resident else 'launch per step',
@@ -226,14 +382,17 @@ def main():
         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         'traffic': committed_traffic(kernel),
-        'avg_launch_us': round(avg_us, 3), 'launches': gru_launches,
+        'avg_launch_us': round(avg_us, 3), 'launches': k_launches,
         'algorithmic_bytes_per_launch': algo_bytes,
+        # `achieved` counts the algorithmic rows (one CoreRNN step per surviving hypothesis,
+        # SURVEY.md 8d); row de-duplication (8 f1) executes fewer -- what the MFMA pipes ran:
+        'executed': {'tflops': round(executed, 3), 'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4)},
         'rows_per_step_algorithmic': round(rows_algo, 1),
-        'rows_per_step_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
-        'path_frac_fp32': round(value / world * flop_per_frame / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-        # SURVEY.md 8(d) asks for both fractions; HBM is not the binding one (arithmetic intensity ~300 FLOP/B)
-        'path_frac_hbm': round(value / world * tau * (4 * dim * (1 + beam * 4 + 2 * beam) + 8 * hid * beam + 8 * beam)
-                               / (PEAK_HBM_GBS * 1e9), 4),
+        'rows_per_step_executed': round(rows_exec, 1),
+        'ceiling_frames_per_s_fp32': round(ceiling, 0),
+        'path_frac_fp32': round(value / world / ceiling, 4),
+        # SURVEY.md 8(d) asks for both fractions; HBM is not the binding one (~300 FLOP/B)
+        'path_frac_hbm': round(value / world * tau * bps / (PEAK_HBM_GBS * 1e9), 4),
         'kernel_ms_profile_pass': {k: round(v, 3) for k, v in prof['kernel_ms'].items()},
     }
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
@@ -243,27 +402,40 @@ def main():
       cores = os.cpu_count() or 1
       threads = min(cores, 64)
       sample = args.cpu_sample or min(n_utt, max(threads, 1))
+      if look > 1:
+        sample = min(sample, 8)
+      sample_frames = n_frames if look == 1 else min(n_frames, 100)
+      sample_seqs = [s[:sample_frames] for s in seqs[:sample]]
       t0 = time.perf_counter()
-      ref = oracle.decode(params, seqs[:sample], beam, look, tau, n_threads=threads)
+      ref = oracle.decode(params, sample_seqs, beam, look, tau, n_threads=threads)
       cpu_s = time.perf_counter() - t0
-      got = d_labels.cpu().numpy()
-      parity = all(
-          np.array_equal(got[u * n_frames:(u + 1) * n_frames], ref['labels'][u])
-          for u in range(sample))
-      cpu = {'value': round(sample * n_frames / cpu_s, 2), 'unit': 'frames/s',
+      if sample_frames == n_frames:
+        got = d_labels.cpu().numpy()
+        parity = all(
+            np.array_equal(got[u * n_frames:(u + 1) * n_frames], ref['labels'][u])
+            for u in range(sample))
+      else:  # truncated utterances: decode exactly those on the GPU for the comparison
+        chk = decoder.decode(np.concatenate(sample_seqs).astype(np.float32),
+                             np.arange(sample + 1, dtype=np.int64) * sample_frames,
+                             beam, look, tau, max_clusters=state['cap'])
+        parity = all(
+            np.array_equal(chk['labels'][u * sample_frames:(u + 1) * sample_frames], ref['labels'][u])
+            for u in range(sample))
+      cpu = {'value': round(sample * sample_frames / cpu_s, 2), 'unit': 'frames/s',
              'cores': threads, 'kind': 'port',
-             'reference_python': reference_rate_note(),
-             'sample': '{} of the {} utterances, {} threads, {:.1f}s; GPU labels '
-                       'identical: {}'.format(sample, n_utt, threads, cpu_s, parity)}
+             'reference': reference_rates(),
+             'sample': '{} of the {} utterances ({} frames each), {} threads, {:.1f}s; GPU labels '
+                       'identical: {}'.format(sample, n_utt, sample_frames, threads, cpu_s, parity)}
     result = {
         'metric': 'diarization frames/sec (whole node), beam=10, 256-dim',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup,
+        'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic', 'config': dict(CONFIG, utterances_per_gpu=n_utt,
-                                            frames=n_frames, beam_size=beam,
-                                            parallelism='utterance-sharded x{}'.format(world)),
+        'data': 'synthetic',
+        'config': dict(cfg, parallelism='utterance-sharded x{}'.format(world),
+                       max_clusters=state['cap']),
+        'value_host_buffers': round(host_rate, 1) if host_rate else None,
         'decode_ms_device': round(stats.get('decode_ms', 0.0), 3),
         'n_streams': stats.get('n_streams', 0),
         'roofline': roofline, 'cpu_baseline': cpu,

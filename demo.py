@@ -65,12 +65,11 @@ def main():
         model_args.observation_dim, model_args.rnn_hidden_size, model_args.rnn_depth))
 
   # the reference predicts one utterance at a time; a list is one GPU batch here
-  predicted = model.predict(test_sequences, inference_args)
-  accuracies = []
+  # and the accuracy step (demo.py:61-64) runs on the labels while they are still in HBM
+  predicted, accuracies = model.predict_and_evaluate(test_sequences, test_cluster_ids, inference_args)
   test_record = []
-  for truth, labels in zip(test_cluster_ids, predicted):
-    accuracy = uisrnn.compute_sequence_match_accuracy(truth, labels)
-    accuracies.append(accuracy)
+  for truth, labels, accuracy in zip(test_cluster_ids, predicted, accuracies):
+    assert accuracy == uisrnn.compute_sequence_match_accuracy(truth, labels)  # host cross-check
     test_record.append((accuracy, len(truth)))  # demo.py:61-64
     print('Ground truth labels: {} ...'.format(truth[:8]))
     print('Predicted labels:    {} ...'.format(labels[:8]))

@@ -20,13 +20,14 @@
 #ifndef UISRNN_HIP_H_
 #define UISRNN_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define UIS_ABI_VERSION 2
+#define UIS_ABI_VERSION 3
 
 typedef enum uis_status {
   UIS_OK = 0,
@@ -38,7 +39,9 @@ typedef enum uis_status {
   UIS_ERR_CLUSTER_CAP = -6,   /* a surviving hypothesis needed more than max_clusters
                                  clusters; labels_out of the flagged utterances are
                                  invalid -- retry with a larger cap (the Python host does) */
-  UIS_ERR_UNSUPPORTED = -7    /* option combination outside the built kernels' range */
+  UIS_ERR_UNSUPPORTED = -7    /* option combination outside the built kernels' range; also: a
+                                 look_ahead >= 2 window had more live assignment prefixes than
+                                 the level capacity (a larger max_clusters cannot help)      */
 } uis_status;
 
 /*
@@ -86,24 +89,17 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_GENERIC_SELECT 0x8u /* use the general score/prune kernel even where the
                                     wave-synchronous fast path applies (A/B switch;
                                     results are bit-identical either way)            */
-#define UIS_FLAG_FUSED      0x10u /* experimental: GRU, linear_mean1 and linear_mean2 in ONE
-                                    launch per step (k_rnn_fused: XCD-local workgroup clusters
-                                    with barriers) instead of three; bit-identical results,
-                                    currently slower; depth-1 models only  */
-#define UIS_FLAG_DATAFLOW   0x20u /* experimental: the workgroups of the GRU, linear_mean1 and
-                                    linear_mean2 kernels in ONE launch per step, consumer
-                                    tiles waiting on per-row-tile arrival counters instead of
-                                    kernel boundaries (k_rnn_dataflow); bit-identical results;
-                                    depth-1 models only                                      */
-#define UIS_FLAG_RESIDENT   0x40u /* REQUIRE the one-launch decode (k_decode_resident: 256
-                                    workgroups, one per CU, W_hh in registers and the mean-head
-                                    tiles in LDS for the whole decode, one XCD per utterance
-                                    subset, in-launch XCD barriers between the stages of a
-                                    step) and fail with UIS_ERR_UNSUPPORTED where it does not
-                                    apply.  It is the DEFAULT wherever it applies: look_ahead 1,
-                                    rnn_depth 1, rnn_hidden_size 256 or 512 and observation_dim
-                                    128, 256 or 512 (after padding to 16), beam_size *
-                                    (max_clusters + 1) <= 256, one stream, a 256-CU device      */
+#define UIS_FLAG_RESIDENT   0x40u /* REQUIRE the one-launch decode (k_decode_resident: one workgroup
+                                    per CU in clusters of 32 -- one cluster per XCD -- W_hh in
+                                    registers and the mean-head tiles in LDS for the whole decode,
+                                    one XCD per utterance subset, in-launch XCD barriers between
+                                    the stages of a step; launched cooperatively so that all
+                                    workgroups are co-resident) and fail with UIS_ERR_UNSUPPORTED
+                                    where it does not apply.  It is the DEFAULT wherever it
+                                    applies: look_ahead 1, rnn_depth 1, rnn_hidden_size 256 or 512
+                                    and observation_dim 128, 256 or 512 (after padding to 16),
+                                    beam_size * (max_clusters + 1) <= 256, one stream, a device
+                                    whose CU count is a multiple of 32                          */
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */
@@ -233,6 +229,35 @@ int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_decode_opts* op
 int32_t uis_stream_push(uis_handle* h, const float* frames, const int32_t* counts);
 int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* scores_out, int32_t* overflow_out);
 int32_t uis_stream_end(uis_handle* h);
+
+/*
+ * Sequence-match accuracy on the device -- the step after predict() in the reference's demo
+ * (demo.py:61-66; uisrnn/evals.py:40-73: confusion matrix + scipy linear_sum_assignment).
+ * For every utterance u (labels offsets[u] .. offsets[u+1] of both sequences) matched_out[u]
+ * = the number of positions that agree under the best one-to-one mapping between the two
+ * label sets; accuracy = matched_out[u] / length in float64 (evals.py:72), left to the caller.
+ * Labels are int32 in [0, 65536) (map other id types to integers first, as evals.py:58-61
+ * does), at most 64 distinct values per sequence -- otherwise UIS_ERR_UNSUPPORTED.  Empty
+ * utterances give 0 (the reference raises ValueError there; the Python mirror does too).
+ *   uis_eval_accuracy         both sequences on the host
+ *   uis_eval_accuracy_device  both in HBM on the handle's device
+ *   uis_eval_last_decode      sequence a = the labels of this handle's last successful
+ *                             uis_decode, still resident in HBM; truth: host, same packing
+ * offsets / matched_out are host pointers.
+ */
+int32_t uis_eval_accuracy(uis_handle* h, const int32_t* labels_a, const int32_t* labels_b,
+                          const int64_t* offsets, int32_t n_utt, int64_t* matched_out);
+int32_t uis_eval_accuracy_device(uis_handle* h, const int32_t* d_labels_a, const int32_t* d_labels_b,
+                                 const int64_t* offsets, int32_t n_utt, int64_t* matched_out);
+int32_t uis_eval_last_decode(uis_handle* h, const int32_t* truth, int32_t n_utt, int64_t* matched_out);
+
+/*
+ * Pinned (page-locked) host memory for the frames / labels handed to uis_decode: with it the
+ * H2D copy of the frame stream is asynchronous and overlaps the input projection of the chunks
+ * already on the device.  Pageable memory works too (staged by the runtime).
+ */
+int32_t uis_host_alloc(size_t bytes, void** out);
+void uis_host_free(void* p);
 
 const char* uis_last_error(void);
 

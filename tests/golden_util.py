@@ -16,7 +16,69 @@ SEEDED_CASES = {
 
 
 def case_names():
-  return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz'))
+  """Fixtures of make_golden.py (random / closed-form weights); trained_* are load_trained's."""
+  return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
+                if f.endswith('.npz') and not f.startswith('trained_'))
+
+
+TRAINED_CASES = {
+    # name -> (checkpoint written by the reference's save(), how the utterances are obtained)
+    'trained_single': 'trained_single.uisrnn',
+    'trained_toy4': 'trained_toy4.uisrnn',
+    'trained_d256_n100': 'trained_d256.uisrnn',
+    'trained_d256_n500': 'trained_d256.uisrnn',
+    'trained_d256_n1000': 'trained_d256.uisrnn',
+}
+
+
+def trained_names():
+  return sorted(n for n in TRAINED_CASES
+                if os.path.exists(os.path.join(GOLDEN_DIR, n + '.npz')))
+
+
+def load_trained(name):
+  """Fixtures of make_trained.py: a model the reference trained + its predict() outputs.
+
+  Returns dict(params, seqs, cfg=(beam, look_ahead, test_iteration), labels, best, beam,
+  truth (or None), alt={u: dict(labels, rescored, margin)}, margins).
+  """
+  from uisrnn_amd import synth, weights  # pylint: disable=import-outside-toplevel
+  data = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+  params = weights.load_checkpoint(os.path.join(GOLDEN_DIR, TRAINED_CASES[name]))
+  n_utt = int(data['n_utt'])
+  if 'seq_0' in data.files:
+    seqs = [data['seq_{}'.format(u)] for u in range(n_utt)]
+  else:  # D=256 utterances are regenerated from their seeds (uisrnn_amd.synth)
+    seqs = [synth.make_utterance(int(data['utt_seed']) + u, int(data['n_frames']), 256)[0]
+            for u in range(n_utt)]
+  alt = {}
+  for u in range(n_utt):
+    if 'alt_labels_{}'.format(u) in data.files:
+      alt[u] = {'labels': data['alt_labels_{}'.format(u)],
+                'rescored': float(data['alt_rescored_{}'.format(u)]),
+                'margin': float(data['alt_margin_{}'.format(u)])}
+  cfg = tuple(int(v) for v in data['cfg'])
+  return {'params': params, 'seqs': seqs, 'cfg': cfg,
+          'labels': [data['labels_{}'.format(u)] for u in range(n_utt)],
+          'best': data['best'], 'beam': data['beam'], 'secs': data['secs'],
+          'truth': data['truth_0'] if 'truth_0' in data.files else None,
+          'accuracy': data['accuracy'] if 'accuracy' in data.files else None,
+          'margins': [float(data['oracle_margin_{}'.format(u)]) for u in range(n_utt)],
+          'alt': alt}
+
+
+def accept_labels(case, u, got, got_score):
+  """SURVEY.md section 7 hard part 1: `got` must equal the reference's labels -- or the
+  recorded alternative that the REFERENCE re-scored to within 1e-4 relative of its own best and
+  whose decision margin was inside float32 rounding (a near-tie flipped by summation order)."""
+  if np.array_equal(got, case['labels'][u]):
+    return True
+  alt = case['alt'].get(u)
+  if alt is None or not np.array_equal(got, alt['labels']):
+    return False
+  best = float(case['best'][u])
+  return (abs(alt['rescored'] - best) <= 1e-4 * abs(best) and alt['margin'] <= 4 * 2.0 ** -23
+          and abs(float(got_score) - best) <= 1e-4 * abs(best))
 
 
 def _params_from_npz(data):

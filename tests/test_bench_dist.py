@@ -1,0 +1,80 @@
+"""bench.py's multi-rank plumbing on CPU: the timed region (barrier + sync on both sides, MAX
+over ranks), the final label gather and the self-spawn under torch.distributed.run -- world
+size 2 over gloo.  The decode itself needs a GPU; here a stand-in step function takes its place."""
+
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RANK_SCRIPT = textwrap.dedent('''
+    import json, os, sys, time
+    sys.path.insert(0, {root!r})
+    import torch, torch.distributed as dist
+    import bench
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    labels = torch.full((5,), rank, dtype=torch.int32)
+    gathered = torch.empty(world * 5, dtype=torch.int32)
+    calls = []
+    def step():
+      time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
+      dist.all_gather_into_tensor(gathered, labels)
+      calls.append(1)
+    elapsed = bench.timed_region(step, lambda: None, steps=3, warmup=2, dist=dist,
+                                 reduce_device=torch.device('cpu'))
+    assert len(calls) == 5
+    assert gathered.view(world, 5)[1].tolist() == [1] * 5
+    print(json.dumps({{'rank': rank, 'elapsed': elapsed}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_timed_region_world_2_gloo(tmp_path):
+  script = tmp_path / 'rank.py'
+  script.write_text(_RANK_SCRIPT.format(root=ROOT))
+  port = 29500 + os.getpid() % 400
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+       '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+      capture_output=True, text=True, timeout=300, cwd=ROOT)
+  assert out.returncode == 0, out.stderr[-3000:]
+  import json
+  recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+  assert sorted(r['rank'] for r in recs) == [0, 1]
+  # every rank reports the SAME number: the slowest rank's (3 steps x 40 ms)
+  assert abs(recs[0]['elapsed'] - recs[1]['elapsed']) < 1e-9
+  assert recs[0]['elapsed'] >= 0.11
+
+
+def test_gpus_flag_refuses_to_fold_ranks_onto_one_device():
+  """`bench.py --gpus 2` on a box with fewer than 2 GPUs must fail loudly, not run one rank."""
+  env = dict(os.environ)
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    env.pop(k, None)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+  import torch
+  if torch.cuda.device_count() < 2:
+    assert out.returncode != 0
+    assert 'HIP device(s) visible' in (out.stderr + out.stdout)
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+  env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+  assert out.returncode != 0 and 'WORLD_SIZE=2' in (out.stderr + out.stdout)
+
+
+def test_flop_model_matches_the_survey():
+  """62.9 MFLOP per input frame for configs[1], 167.8 for configs[4]."""
+  sys.path.insert(0, ROOT)
+  import bench
+  assert abs(bench.flops_per_frame(bench.CONFIGS[1]) / 1e6 - 62.9) < 0.2
+  assert abs(bench.flops_per_frame(bench.CONFIGS[4]) / 1e6 - 167.8) < 0.5
+  assert abs(bench.flops_per_frame(bench.CONFIGS[2]) / 1e6 - 944) < 10
+  assert bench.bytes_per_step(bench.CONFIGS[1]) == 103504

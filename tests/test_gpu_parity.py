@@ -18,8 +18,7 @@ from uisrnn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-_PATH_FLAGS = (_capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_FUSED |
-               _capi.UIS_FLAG_DATAFLOW | _capi.UIS_FLAG_GRAPH)
+_PATH_FLAGS = _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_GRAPH
 
 
 def _bits(a):
@@ -174,42 +173,6 @@ def test_generic_select_flag_is_bit_identical(oracle_lib):
   _compare(params, seqs, 70, 1, 1, oracle_lib, max_clusters=8)     # beyond it: general kernel
 
 
-def test_fused_rnn_step_is_bit_identical(oracle_lib):
-  """UIS_FLAG_FUSED: k_rnn_fused (one launch per step, XCD-local clusters with barriers) vs the oracle."""
-  params = synth.tracker_params(256, 512, 1, seed=6)
-  lengths = [64, 30, 77, 12, 50, 41, 1, 90, 23, 64, 35, 18]
-  seqs, _ = synth.make_utterances(8800, len(lengths), lengths, 256)
-  dec = _capi.Decoder(params)
-  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec)
-  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_FUSED)
-  _compare(params, seqs, 5, 2, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_FUSED)   # under look_ahead
-  prof = dec.decode(*oracle_lib.pack(seqs), 10, 1, 2,
-                    flags=_capi.UIS_FLAG_PROFILE | _capi.UIS_FLAG_FUSED)['stats']
-  assert prof['kernel_launches']['head1'] == 0 and prof['kernel_launches']['gru'] > 0
-  # more rows than one pass of three row tiles per cluster covers
-  many, _ = synth.make_utterances(8900, 80, 12, 256)
-  _compare(params, many, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_FUSED | _capi.UIS_FLAG_NO_DEDUP)
-  # depth-2 models are refused, not silently run unfused
-  case = golden_util.load_case('toy_d2_depth2')
-  d2 = _capi.Decoder(case['params'])
-  with pytest.raises(_capi.HipLibraryError):
-    d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_FUSED)
-
-
-def test_dataflow_rnn_step_is_bit_identical(oracle_lib):
-  """UIS_FLAG_DATAFLOW: GRU / head1 / head2 workgroups in one launch with per-row-tile counters."""
-  params = synth.tracker_params(256, 512, 1, seed=6)
-  lengths = [64, 30, 77, 12, 50, 41, 1, 90, 23, 64, 35, 18]
-  seqs, _ = synth.make_utterances(8800, len(lengths), lengths, 256)
-  dec = _capi.Decoder(params)
-  _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
-  _compare(params, seqs, 5, 2, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
-  many, _ = synth.make_utterances(8900, 80, 12, 256)
-  _compare(params, many, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_DATAFLOW | _capi.UIS_FLAG_NO_DEDUP)
-  for _ in range(3):  # hand-offs are timing dependent: repeat
-    _compare(params, seqs, 10, 1, 2, oracle_lib, decoder=dec, flags=_capi.UIS_FLAG_DATAFLOW)
-
-
 def test_resident_decode_is_bit_identical(oracle_lib):
   """UIS_FLAG_RESIDENT: the whole decode in one launch (k_decode_resident) vs the oracle."""
   params = synth.tracker_params(256, 512, 1, seed=6)
@@ -249,6 +212,96 @@ def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):
   with pytest.raises(_capi.HipLibraryError):          # demanded explicitly: the failure is reported
     _capi.Decoder(params).decode(*oracle_lib.pack(seqs), 10, 1, 2,
                                  flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_TEST_MISPLACED)
+
+
+def test_quirk7_zero_first_difference_on_the_device(oracle_lib):
+  """weighted_mse_loss returns inf when the FIRST squared difference is exactly 0
+  (uisrnn/loss_func.py:36,41: nnz counts the first column only).  Engineered on the decode
+  path: a frame whose component 0 equals m0[0] makes the fresh-cluster candidate's MSE inf
+  (k_mse0); a frame whose component 0 equals a live cluster's mean[0] does the same for that
+  cluster (the select's MSE).  Both decode paths must agree with the oracle bit for bit."""
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  dec = _capi.Decoder(params)
+  m0, _ = dec.constants()
+  seqs, _ = synth.make_utterances(9300, 2, [14, 9], 256)
+  seqs[0][0, 0] = np.float64(m0[0])    # the very first frame: its only candidate is non-finite
+  seqs[1][4, 0] = np.float64(m0[0])    # mid-utterance: the fresh cluster drops out of that step
+  out, ref = _compare(params, seqs, 10, 1, 1, oracle_lib, decoder=dec)
+  assert (ref['labels'][0] == -1).all()          # the beam emptied at step 0, like the reference's
+  assert (ref['labels'][1] >= 0).all()
+  assert np.isinf(oracle_lib.weighted_mse(params, m0, seqs[0][0].astype(np.float32)))
+  # a live cluster's mean: after one frame the cluster's mean is the network's output for it
+  x0 = seqs[1][0].astype(np.float32)
+  _, h1 = dec.constants()
+  mean1, _ = dec.rnn_step(x0, h1)
+  probe = [np.array(seqs[1][:3])]
+  probe[0][1, 0] = np.float64(mean1[0])          # frame 1 meets cluster 0's mean[0] exactly
+  _, ref2 = _compare(params, probe, 10, 1, 1, oracle_lib, decoder=dec)
+  assert ref2['labels'][0].tolist()[1] != 0      # staying in cluster 0 was non-finite: a new one opens
+
+
+def test_level_capacity_is_reported_not_retried(oracle_lib):
+  """look_ahead >= 2: when a window has more live prefixes than an intermediate level holds the
+  call fails with UIS_ERR_UNSUPPORTED and says so (doubling max_clusters could not help)."""
+  params, rng = _many_cluster_case()
+  seqs = [rng.standard_normal((14, 64))]
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  with pytest.raises(_capi.HipLibraryError, match='look-ahead window'):
+    dec.decode(frames, offsets, 200, 4, 1, max_clusters=30)   # 200 * 31 * 32 * 33 prefixes > 32768
+
+
+def test_decode_while_another_stream_keeps_cus_busy(oracle_lib):
+  """The one-launch decode spins on in-launch barriers.  It is launched cooperatively, so the
+  runtime either makes all its workgroups co-resident or refuses; with other kernels occupying
+  the device (here: torch matmuls on another stream, before, during and after) the results must
+  stay identical -- whether the launch waits, or the barrier guard triggers the fallback."""
+  import torch
+  params = synth.tracker_params(256, 512, 1, seed=11)
+  seqs, _ = synth.make_utterances(9400, 16, 40, 256)
+  ref = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=8)
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  side = torch.cuda.Stream()
+  a = torch.randn(4096, 4096, device='cuda')
+  for _ in range(4):
+    with torch.cuda.stream(side):
+      for _ in range(30):
+        a = torch.tanh(a @ a) * 0.01
+    out = dec.decode(frames, offsets, 10, 1, 2)
+    assert out['status'] == 0
+    for u in range(len(seqs)):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u])
+    assert np.array_equal(_bits(out['scores']), _bits(ref['scores']))
+  torch.cuda.synchronize()
+
+
+def test_host_buffer_decode_from_pinned_memory(oracle_lib):
+  """uis_decode from pinned host buffers (uis_host_alloc): chunked H2D overlapped with the input
+  projection gives the same labels as the pageable path."""
+  import ctypes
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  seqs, _ = synth.make_utterances(9450, 40, 300, 256)   # 12000 frames: several copy chunks
+  frames, offsets = oracle_lib.pack(seqs)
+  dec = _capi.Decoder(params)
+  want = dec.decode(frames, offsets, 10, 1, 2)
+  lib = _capi.load_library()
+  bufs = []
+  for nbytes in (frames.nbytes, 4 * len(frames), 4 * len(seqs)):
+    p = ctypes.c_void_p()
+    assert lib.uis_host_alloc(nbytes, ctypes.byref(p)) == 0
+    bufs.append(p)
+  try:
+    ctypes.memmove(bufs[0], frames.ctypes.data, frames.nbytes)
+    rc = dec.decode_host(bufs[0].value, offsets, 10, 1, 2, bufs[1].value, bufs[2].value)
+    assert rc['status'] == 0
+    got = np.ctypeslib.as_array(ctypes.cast(bufs[1], ctypes.POINTER(ctypes.c_int32)), (len(frames),))
+    assert np.array_equal(got, want['labels'])
+    sc = np.ctypeslib.as_array(ctypes.cast(bufs[2], ctypes.POINTER(ctypes.c_float)), (len(seqs),))
+    assert np.array_equal(_bits(sc), _bits(want['scores']))
+  finally:
+    for p in bufs:
+      lib.uis_host_free(p)
 
 
 def _many_cluster_case():

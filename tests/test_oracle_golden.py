@@ -125,3 +125,41 @@ def test_numerics_version_matches_header(oracle_lib):
                              'uis_numerics.h')).read()
   version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', header).group(1))
   assert oracle_lib.numerics_version() == version
+
+
+# ---- models the REFERENCE trained (tests/golden/make_trained.py): its own behavioural tests
+
+
+@pytest.mark.parametrize('name', golden_util.trained_names())
+def test_trained_fixtures_match_reference(name, oracle_lib):
+  """Checkpoints written by the reference's fit() + save(); labels and scores recorded from its
+  predict().  Where the oracle's labels differ, only the alternative the reference itself
+  re-scored (make_trained.rescore_with_reference) is accepted -- golden_util.accept_labels."""
+  case = golden_util.load_trained(name)
+  beam, look, tau = case['cfg']
+  out = oracle_lib.decode(case['params'], case['seqs'], beam, look, tau, n_threads=4)
+  for u in range(len(case['seqs'])):
+    assert golden_util.accept_labels(case, u, out['labels'][u], out['scores'][u]), (name, u)
+    if np.array_equal(out['labels'][u], case['labels'][u]):
+      np.testing.assert_allclose(out['scores'][u], case['best'][u], rtol=RTOL)
+      fin = np.isfinite(case['beam'][u])
+      np.testing.assert_allclose(out['beam_scores'][u][fin], case['beam'][u][fin], rtol=RTOL)
+
+
+def test_trained_single_label_is_all_zeros(oracle_lib):
+  """tests/uisrnn_test.py:26-70 of the reference: one training label -> predict gives [0]*10."""
+  case = golden_util.load_trained('trained_single')
+  for lab in case['labels']:
+    assert lab.tolist() == [0] * 10
+  out = oracle_lib.decode(case['params'], case['seqs'], *case['cfg'])
+  assert all(l.tolist() == [0] * 10 for l in out['labels'])
+
+
+def test_trained_toy4_accuracy_is_one(oracle_lib):
+  """tests/integration_test.py:116-118 of the reference: four clusters, depth 2, accuracy 1.0."""
+  from uisrnn_amd import evals
+  case = golden_util.load_trained('trained_toy4')
+  assert float(case['accuracy']) == 1.0
+  out = oracle_lib.decode(case['params'], case['seqs'], *case['cfg'])
+  acc = evals.compute_sequence_match_accuracy(out['labels'][0].tolist(), case['truth'].tolist())
+  assert acc == 1.0

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuisrnn_hip.so')
 
 UIS_OK = 0
-UIS_ABI_VERSION = 2   # include/uisrnn_hip.h
+UIS_ABI_VERSION = 3   # include/uisrnn_hip.h
 UIS_ERR_INVALID_ARG = -1
 UIS_ERR_DIM_MISMATCH = -2
 UIS_ERR_NO_DEVICE = -3
@@ -29,8 +29,6 @@ UIS_FLAG_NO_DEDUP = 0x1
 UIS_FLAG_GRAPH = 0x2
 UIS_FLAG_PROFILE = 0x4
 UIS_FLAG_GENERIC_SELECT = 0x8
-UIS_FLAG_FUSED = 0x10
-UIS_FLAG_DATAFLOW = 0x20
 UIS_FLAG_RESIDENT = 0x40
 UIS_FLAG_STEPWISE = 0x80
 UIS_FLAG_TEST_MISPLACED = 0x100
@@ -195,6 +193,13 @@ def load_library(path=None):
         '{} not found: build it with `python -m uisrnn_amd.build` (hipcc, '
         'gfx950). There is no CPU fallback for the decode path.'.format(path))
   lib = ctypes.CDLL(path)
+  lib.uis_abi_version.restype = ctypes.c_int32
+  lib.uis_abi_version.argtypes = []
+  if lib.uis_abi_version() != UIS_ABI_VERSION:
+    # a stale in-tree build: its structs would not match the ctypes mirrors below
+    raise HipLibraryError(
+        '{} was built for ABI {} but this package expects {}: rebuild with '
+        '`python -m uisrnn_amd.build --force`'.format(path, lib.uis_abi_version(), UIS_ABI_VERSION))
   i32 = ctypes.c_int32
   i32p = ctypes.POINTER(ctypes.c_int32)
   i64p = ctypes.POINTER(ctypes.c_int64)
@@ -231,6 +236,16 @@ def load_library(path=None):
   lib.uis_stream_labels.argtypes = [ctypes.c_void_p, i32p, _fp, i32p]
   lib.uis_stream_end.restype = i32
   lib.uis_stream_end.argtypes = [ctypes.c_void_p]
+  lib.uis_eval_accuracy.restype = i32
+  lib.uis_eval_accuracy.argtypes = [ctypes.c_void_p, i32p, i32p, i64p, i32, i64p]
+  lib.uis_eval_accuracy_device.restype = i32
+  lib.uis_eval_accuracy_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, i64p, i32, i64p]
+  lib.uis_eval_last_decode.restype = i32
+  lib.uis_eval_last_decode.argtypes = [ctypes.c_void_p, i32p, i32, i64p]
+  lib.uis_host_alloc.restype = i32
+  lib.uis_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+  lib.uis_host_free.restype = None
+  lib.uis_host_free.argtypes = [ctypes.c_void_p]
   lib.uis_last_error.restype = ctypes.c_char_p
   lib.uis_last_error.argtypes = []
   _lib = lib
@@ -241,7 +256,8 @@ EXPORTED_SYMBOLS = (
     'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
     'uis_decode', 'uis_decode_device', 'uis_last_decode_info',
     'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',
-    'uis_stream_labels', 'uis_stream_end', 'uis_last_error')
+    'uis_stream_labels', 'uis_stream_end', 'uis_eval_accuracy', 'uis_eval_accuracy_device',
+    'uis_eval_last_decode', 'uis_host_alloc', 'uis_host_free', 'uis_last_error')
 
 
 def last_error(lib):
@@ -397,6 +413,63 @@ class Decoder:
 
   def stream_end(self):
     self._check(self._lib.uis_stream_end(self._handle), 'uis_stream_end')
+
+  def decode_host(self, frames_ptr, offsets, beam_size, look_ahead, test_iteration,
+                  labels_ptr, scores_ptr, max_clusters=0, flags=0):
+    """uis_decode on raw HOST pointers (e.g. pinned buffers from uis_host_alloc or torch)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_utt = offsets.shape[0] - 1
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags, 0)
+    stats = Stats()
+    rc = self._lib.uis_decode(
+        self._handle, ctypes.cast(ctypes.c_void_p(int(frames_ptr)), _fp),
+        offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        ctypes.byref(opts),
+        ctypes.cast(ctypes.c_void_p(int(labels_ptr)), ctypes.POINTER(ctypes.c_int32)),
+        ctypes.cast(ctypes.c_void_p(int(scores_ptr)), _fp) if scores_ptr else None,
+        ctypes.byref(stats))
+    rc = self._check(rc, 'uis_decode')
+    return {'stats': stats.as_dict(), 'status': rc}
+
+  # ---- evaluation on the device (uis_eval_*)
+  @staticmethod
+  def _eval_args(offsets):
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_utt = offsets.shape[0] - 1
+    matched = np.zeros(max(n_utt, 1), dtype=np.int64)
+    return offsets, n_utt, matched
+
+  def eval_matched(self, labels_a, labels_b, offsets):
+    """Matched positions per utterance under the best label mapping (host int32 arrays in)."""
+    labels_a = np.ascontiguousarray(labels_a, dtype=np.int32)
+    labels_b = np.ascontiguousarray(labels_b, dtype=np.int32)
+    offsets, n_utt, matched = self._eval_args(offsets)
+    if labels_a.shape != labels_b.shape or labels_a.shape[0] != int(offsets[-1]):
+      raise ValueError('both label arrays must hold offsets[-1] entries')
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    self._check(self._lib.uis_eval_accuracy(
+        self._handle, labels_a.ctypes.data_as(i32p), labels_b.ctypes.data_as(i32p),
+        offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        matched.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), 'uis_eval_accuracy')
+    return matched[:n_utt]
+
+  def eval_matched_device(self, d_labels_a_ptr, d_labels_b_ptr, offsets):
+    """Same with both label sequences resident in HBM (raw device pointers)."""
+    offsets, n_utt, matched = self._eval_args(offsets)
+    self._check(self._lib.uis_eval_accuracy_device(
+        self._handle, ctypes.c_void_p(int(d_labels_a_ptr)), ctypes.c_void_p(int(d_labels_b_ptr)),
+        offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        matched.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), 'uis_eval_accuracy_device')
+    return matched[:n_utt]
+
+  def eval_last_decode(self, truth, n_utt):
+    """Matched positions of the last decode()'s labels (still in HBM) against `truth`."""
+    truth = np.ascontiguousarray(truth, dtype=np.int32)
+    matched = np.zeros(max(int(n_utt), 1), dtype=np.int64)
+    self._check(self._lib.uis_eval_last_decode(
+        self._handle, truth.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(n_utt),
+        matched.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), 'uis_eval_last_decode')
+    return matched[:int(n_utt)]
 
   def decode_device(self, d_frames_ptr, offsets, beam_size, look_ahead,
                     test_iteration, d_labels_ptr, d_scores_ptr, max_clusters=0,

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "uis_kernels.hip"
+#include "uis_eval.hip"
 #include "uisrnn_hip.h"
 
 #define UIS_EXPORT extern "C" __attribute__((visibility("default")))
@@ -64,8 +65,10 @@ struct DevBuf {
 
 #define UIS_WIDE_TILE_ROWS 2048   // row capacity (about twice the rows actually run, after dedup) above which the 2x2 tiles win
 #define UIS_MAX_GROUPS 8
+#define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
+#define UIS_H2D_CHUNKS 4     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection
 
 struct GraphCache {
   hipGraphExec_t exec = nullptr;
@@ -83,7 +86,8 @@ struct ProfileEvents {
 
 struct uis_handle {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  std::vector<hipEvent_t> h2d_done;
   DevModel m{};
   std::vector<void*> model_allocs;
   double alpha = 1.0;
@@ -120,6 +124,8 @@ struct uis_handle {
   std::vector<GraphCache> gcache;
   // info of the last decode
   int last_U = 0, last_B = 0;
+  std::vector<int64_t> io_offsets;  // offsets of the last uis_decode (its labels are still in io_labels)
+  DevBuf ev_a, ev_b, ev_off, ev_out;  // uis_eval_* staging
   std::vector<int32_t> last_overflow;
   std::vector<float> last_beam_scores;
 };
@@ -205,6 +211,35 @@ struct Launcher {
     HIPCHK(hipGetLastError());
     return UIS_OK;
   }
+  // The one-launch decode spins on in-launch barriers: every workgroup of the grid must be
+  // resident at once.  hipLaunchCooperativeKernel guarantees that (or refuses the launch); the
+  // occupancy query is checked as well so that the refusal has a readable reason.  With
+  // `profile`, events recorded around the launch on the same (otherwise idle) stream.
+  int run_cooperative(int cls, void (*kernel)(DevModel, DecodeState), int n_cu, dim3 grid, dim3 block, size_t shmem,
+                      DevModel m, DecodeState st) {
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), (int)block.x, shmem));
+    if ((long)per_cu * n_cu < (long)grid.x) {
+      h->inlaunch_failed = true;
+      return fail(UIS_ERR_HIP, "one-launch decode: " + std::to_string(grid.x) + " workgroups cannot be co-resident (" +
+                                   std::to_string(per_cu) + " per CU x " + std::to_string(n_cu) + " CUs)");
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    if (profile) {
+      int rc = events(&a, &b, cls);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(a, stream));
+    }
+    void* argv[2] = {&m, &st};
+    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, (unsigned)shmem, stream);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      h->inlaunch_failed = true;  // the caller falls back to the launch-per-step path
+      return fail(UIS_ERR_HIP, std::string("hipLaunchCooperativeKernel(k_decode_resident): ") + hipGetErrorString(e));
+    }
+    if (profile) HIPCHK(hipEventRecord(b, stream));
+    return UIS_OK;
+  }
 };
 
 #define LAUNCH(...)                       \
@@ -217,15 +252,6 @@ struct Launcher {
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
   const int mr = (int)max_rows;
-  if (st.tile_ctr) {  // UIS_FLAG_DATAFLOW: the three kernels' workgroups in one launch
-    const int blocks = 2 * step_grid_blocks(mr, m.Hp / 16, 1, 1) + step_grid_blocks(mr, m.Dp / 16, 1, 1);
-    LAUNCH(UIS_K_GRU, k_rnn_dataflow, dim3(blocks), dim3(512), 0, m, st, par);
-    return UIS_OK;
-  }
-  if (st.cl_counter) {  // UIS_FLAG_FUSED: one launch for GRU + mean head
-    LAUNCH(UIS_K_GRU, k_rnn_fused, dim3(256), dim3(512), 0, m, st, par);
-    return UIS_OK;
-  }
   const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
   for (int l = 0; l < m.depth; ++l) {
     if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
@@ -319,7 +345,8 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
 }
 
 int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
-                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
+                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats,
+                const float* h_frames = nullptr) {
   if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
   if (h->stream_state.active) return fail(UIS_ERR_INVALID_ARG, "a streaming session is open on this handle (uis_stream_end first)");
   const DevModel& m = h->m;
@@ -434,9 +461,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
   ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
   ENSURE(bp, L == 1 ? (size_t)std::max<int64_t>(tau * F, 1) * B * 4 : 16);
-  // k_decode_resident: one row region per XCD, a multiple of 16 rows
-  const int rx_stride = (int)(((((long)U + 7) / 8) * B + 15) / 16 * 16);
-  const long rows_cap = std::max(max_rows + 48L * G, 8L * rx_stride);  // every group's last row tile may run past its rows
+  // k_decode_resident: the CUs form ncl clusters of 32 (one per XCD: 8 on a whole MI355X, 1 in
+  // CPX mode); one row region per cluster, a multiple of 16 rows
+  const int ncl = (h->n_cu >= 32 && h->n_cu % 32 == 0 && h->n_cu / 32 <= UIS_MAX_CLUSTERS) ? h->n_cu / 32 : 0;
+  const int nclq = std::max(ncl, 1);
+  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * B + 15) / 16 * 16);
+  const long rows_cap = std::max(max_rows + 48L * G, (long)nclq * rx_stride);  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
   // depth 1: k_decode_resident's h' staging buffer
@@ -444,31 +474,23 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 96 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
-  // opt-in one-launch rnn step: depth-1 models whose exchanged buffers fit 31-bit byte offsets
-  const bool fused = (opts->flags & UIS_FLAG_FUSED) && m.depth == 1 && G == 1 &&
-                     (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
-  if ((opts->flags & UIS_FLAG_FUSED) && !fused)
-    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_FUSED needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
-  const bool dataflow = (opts->flags & UIS_FLAG_DATAFLOW) && m.depth == 1 && G == 1 &&
-                        (double)U * S * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9;
-  if ((opts->flags & UIS_FLAG_DATAFLOW) && !dataflow)
-    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DATAFLOW needs rnn_depth 1, one stream and < 2 GB of cluster-state / row buffers");
   // the whole decode in one launch with register-resident weights (k_decode_resident)
   const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 256 || m.Hp == 512) &&
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
-                           select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && h->n_cu == 256 &&
+                           select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && ncl >= 1 &&
                            ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                            resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
   // the default wherever it applies; UIS_FLAG_STEPWISE (or any of the per-step experiments) keeps
   // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
   const bool resident = resident_ok && !use_graph && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
-                        !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW));
+                        !(opts->flags & UIS_FLAG_STEPWISE);
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 256 or 512 (padded), "
                                      "observation_dim 128, 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
-                                     "stream, a 256-CU device and no per-step path flag");
-  const int tile_cap = (int)((rows_cap + 15) / 16) + 1;
-  const size_t ctl_words = (size_t)8 * 16 + 8 + 8 + 2 * tile_cap + 2 * 8 * 32;
+                                     "stream, a device whose CU count is a multiple of 32 and no per-step path flag");
+  // control words: [0, 16) XCC id per cluster, [16] abort, [32, 32 + 32 ncl) row counters,
+  // then 32 ncl barrier counters (one 128-byte line per cluster each)
+  const size_t ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
   ENSURE(cluster_ctl, ctl_words * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
@@ -521,19 +543,42 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
   HIPCHK(hipMemsetAsync(h->cluster_ctl.p, 0, ctl_words * 4, h->stream));
-  const float* d_x = d_frames;
-  if (m.D != m.Dp && F > 0) {
-    const long total = (long)F * m.Dp;
-    hipLaunchKernelGGL(k_pad_frames, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d_frames,
-                       h->xpad.as<float>(), (long)F, m.D, m.Dp);
-    HIPCHK(hipGetLastError());
-    d_x = h->xpad.as<float>();
-  }
-  if (F > 0) {
-    LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, h->gi0.as<float>(),
-           (long)F);
-    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-           h->mse0.as<float>(), (long)F);
+  // once per decode: pad (only when D is not a multiple of 16), gi0 = W_ih0 x + b_ih0, mse0.
+  // Host frames (uis_decode) arrive in chunks on the copy stream; chunk i's kernels overlap the
+  // H2D of chunk i+1 (true overlap needs pinned host memory, uis_host_alloc).
+  const float* d_x = (m.D != m.Dp && F > 0) ? h->xpad.as<float>() : d_frames;
+  auto pre_chunk = [&](int64_t f0, int64_t f1) -> int {
+    const long n = (long)(f1 - f0);
+    if (m.D != m.Dp) {
+      const long total = n * m.Dp;
+      hipLaunchKernelGGL(k_pad_frames, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                         d_frames + (size_t)f0 * m.D, h->xpad.as<float>() + (size_t)f0 * m.Dp, n, m.D, m.Dp);
+      HIPCHK(hipGetLastError());
+    }
+    LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
+           h->gi0.as<float>() + (size_t)f0 * m.G, n);
+    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m,
+           d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n);
+    return UIS_OK;
+  };
+  if (F > 0 && h_frames) {
+    const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / 4096));
+    while ((int)h->h2d_done.size() < n_chunks) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->h2d_done.push_back(e);
+    }
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
+    for (int c = 0; c < n_chunks; ++c) {
+      const int64_t f0 = F * c / n_chunks, f1 = F * (c + 1) / n_chunks;
+      HIPCHK(hipMemcpyAsync(const_cast<float*>(d_frames) + (size_t)f0 * m.D, h_frames + (size_t)f0 * m.D,
+                            (size_t)(f1 - f0) * m.D * 4, hipMemcpyHostToDevice, h->copy_stream));
+      HIPCHK(hipEventRecord(h->h2d_done[c], h->copy_stream));
+      HIPCHK(hipStreamWaitEvent(h->stream, h->h2d_done[c], 0));
+      if ((rc = pre_chunk(f0, f1))) return rc;
+    }
+  } else if (F > 0) {
+    if ((rc = pre_chunk(0, F))) return rc;
   }
   HIPCHK(hipEventRecord(h->ev_pre, h->stream));
 
@@ -567,20 +612,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.gi_up = h->gi_up.as<float>() + (m.depth > 1 ? (u0 * rows_per_utt + 48 * (size_t)g) * m.G : 0);
     st.a1 = h->a1.as<float>() + (u0 * rows_per_utt + 48 * (size_t)g) * m.Hp;
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
-    if (fused) {
-      st.cl_counter = h->cluster_ctl.as<uint32_t>();
-      st.cl_xcc = st.cl_counter + 8 * 16;
-    }
-    st.cl_abort = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 8;
-    if (dataflow) {
-      st.tile_ctr = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 16;
-      st.tile_cap = tile_cap;
-    }
+    st.cl_abort = h->cluster_ctl.as<uint32_t>() + 16;
     if (resident) {
-      st.cl_xcc = h->cluster_ctl.as<uint32_t>() + 8 * 16;
+      st.ncl = ncl;
+      st.cl_xcc = h->cluster_ctl.as<uint32_t>();
       st.rx_stride = rx_stride;
-      st.rx_nrows = h->cluster_ctl.as<int32_t>() + 8 * 16 + 16 + 2 * tile_cap;
-      st.rx_bar = h->cluster_ctl.as<uint32_t>() + 8 * 16 + 16 + 2 * tile_cap + 8 * 32;
+      st.rx_nrows = h->cluster_ctl.as<int32_t>() + 32;
+      st.rx_bar = h->cluster_ctl.as<uint32_t>() + 32 + UIS_MAX_CLUSTERS * 32;
     }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;
@@ -616,7 +654,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
-    LAUNCH(UIS_K_GRU, (k_decode_resident<HPV, DPV>), dim3(256), dim3(512), shmem, m, gp.st);                        \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV>, h->n_cu, dim3(32 * ncl), dim3(512),     \
+                                 shmem, m, gp.st)))                                                                  \
+      return rc;                                                                                                     \
   }
       UIS_RESIDENT_CASE(512, 256)
       UIS_RESIDENT_CASE(512, 512)
@@ -665,7 +705,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->last_beam_scores.data(), h->beam_scores_out.p, (size_t)U * B * 4, hipMemcpyDeviceToHost,
                         h->stream));
   uint32_t abort_word = 0;
-  HIPCHK(hipMemcpyAsync(&abort_word, h->cluster_ctl.as<uint32_t>() + 8 * 16 + 8, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&abort_word, h->cluster_ctl.as<uint32_t>() + 16, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (abort_word) {
     h->inlaunch_failed = true;
@@ -709,8 +749,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
             (double)tc[75] * 0.01 / (double)maxT);
   }
 #endif
-  int n_over = 0;
-  for (int u = 0; u < U; ++u) n_over += h->last_overflow[u] != 0;
+  int n_over = 0, n_level = 0;
+  for (int u = 0; u < U; ++u) {
+    n_level += (h->last_overflow[u] & 2) != 0;  // look_ahead >= 2: an intermediate level was full
+    n_over += h->last_overflow[u] != 0;
+  }
   if (stats) {
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
@@ -735,6 +778,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       }
     }
   }
+  if (n_level)
+    return fail(UIS_ERR_UNSUPPORTED,
+                std::to_string(n_level) + " utterance(s) had more than " + std::to_string((long long)NC) +
+                    " live assignment prefixes inside a look-ahead window (beam_size * clusters ^ (look_ahead - 1)); "
+                    "a larger max_clusters cannot help: lower look_ahead or beam_size");
   if (n_over)
     return fail(UIS_ERR_CLUSTER_CAP, std::to_string(n_over) + " utterance(s) needed more than max_clusters=" +
                                          std::to_string(Kmax) + " clusters per hypothesis");
@@ -744,12 +792,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 // One decode; if the one-launch path was chosen automatically and its placement / barrier checks
 // failed, repeat on the launch-per-step path and stay there for this handle.
 int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
-                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats) {
+                const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats,
+                const float* h_frames = nullptr) {
   if (h) h->inlaunch_failed = false;
-  int rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats);
+  int rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats, h_frames);
   if (rc == UIS_ERR_HIP && h && h->inlaunch_failed && opts &&
-      !(opts->flags & (UIS_FLAG_RESIDENT | UIS_FLAG_FUSED | UIS_FLAG_DATAFLOW))) {
-    h->resident_off = true;
+      !(opts->flags & UIS_FLAG_RESIDENT)) {
+    h->resident_off = true;  // (the frames, if they came from the host, are on the device by now)
     rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats);
   }
   return rc;
@@ -787,7 +836,8 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
                     &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
-                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena};
+                    &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
+                    &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
   if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
@@ -796,6 +846,8 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   for (GraphCache& gc : h->gcache) if (gc.exec) (void)hipGraphExecDestroy(gc.exec);
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t sg : h->gstreams) { (void)hipStreamSynchronize(sg); (void)hipStreamDestroy(sg); }
+  for (hipEvent_t e : h->h2d_done) (void)hipEventDestroy(e);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -824,7 +876,9 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   h->alpha = d->crp_alpha;
   if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->n_cu = 0;
   auto bail = [&](int rc) { uis_destroy(h); return rc; };
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(UIS_ERR_HIP, "stream create failed"));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(UIS_ERR_HIP, "stream create failed"));
   if (hipEventCreate(&h->ev_begin) != hipSuccess || hipEventCreate(&h->ev_end) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) != hipSuccess)
     return bail(fail(UIS_ERR_HIP, "event create failed"));
@@ -882,11 +936,11 @@ UIS_EXPORT int32_t uis_decode(uis_handle* h, const float* frames, const int64_t*
   if ((rc = h->io_frames.ensure((size_t)std::max<int64_t>(F, 1) * h->m.D * 4))) return rc;
   if ((rc = h->io_labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
   if ((rc = h->io_scores.ensure((size_t)std::max(n_utt, 1) * 4))) return rc;
-  if (F > 0)
-    HIPCHK(hipMemcpyAsync(h->io_frames.p, frames, (size_t)F * h->m.D * 4, hipMemcpyHostToDevice, h->stream));
+  h->io_offsets.clear();
   rc = decode_impl(h, h->io_frames.as<float>(), offsets, n_utt, opts, h->io_labels.as<int32_t>(),
-                   h->io_scores.as<float>(), stats);
+                   h->io_scores.as<float>(), stats, frames);
   if (rc != UIS_OK && rc != UIS_ERR_CLUSTER_CAP) return rc;
+  if (rc == UIS_OK) h->io_offsets.assign(offsets, offsets + n_utt + 1);
   if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, h->io_labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
   if (scores_out && n_utt > 0)
     HIPCHK(hipMemcpyAsync(scores_out, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1148,4 +1202,94 @@ UIS_EXPORT int32_t uis_stream_end(uis_handle* h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   stream_free(h);
   return UIS_OK;
+}
+
+
+// ------------------------------------------------------------------ evaluation
+//
+// Sequence-match accuracy on the device (uis_eval.hip): the step after predict() in the
+// reference's demo (demo.py:61-66, uisrnn/evals.py:40-73).
+
+namespace {
+
+int eval_run(uis_handle* h, const int32_t* d_a, const int32_t* d_b, const int64_t* offsets, int32_t n_utt,
+             int64_t* matched_out) {
+  if (n_utt == 0) return UIS_OK;
+  if (offsets[0] != 0) return fail(UIS_ERR_INVALID_ARG, "offsets[0] must be 0");
+  for (int u = 0; u < n_utt; ++u)
+    if (offsets[u + 1] < offsets[u]) return fail(UIS_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  int rc;
+  if ((rc = h->ev_off.ensure((size_t)(n_utt + 1) * 8))) return rc;
+  if ((rc = h->ev_out.ensure((size_t)n_utt * 12))) return rc;
+  long long* d_matched = h->ev_out.as<long long>();
+  int32_t* d_status = reinterpret_cast<int32_t*>(d_matched + n_utt);
+  HIPCHK(hipMemcpyAsync(h->ev_off.p, offsets, (size_t)(n_utt + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_eval, dim3(n_utt), dim3(256), 0, h->stream, d_a, d_b, h->ev_off.as<int64_t>(), n_utt, d_matched,
+                     d_status);
+  HIPCHK(hipGetLastError());
+  std::vector<int32_t> status(n_utt);
+  static_assert(sizeof(long long) == sizeof(int64_t), "matched counts");
+  HIPCHK(hipMemcpyAsync(matched_out, d_matched, (size_t)n_utt * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(status.data(), d_status, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int u = 0; u < n_utt; ++u) {
+    if (status[u] == 1)
+      return fail(UIS_ERR_UNSUPPORTED, "utterance " + std::to_string(u) + ": labels must lie in [0, 65536)");
+    if (status[u] == 2)
+      return fail(UIS_ERR_UNSUPPORTED, "utterance " + std::to_string(u) + ": more than 64 distinct labels in a sequence");
+  }
+  return UIS_OK;
+}
+
+}  // namespace
+
+UIS_EXPORT int32_t uis_eval_accuracy_device(uis_handle* h, const int32_t* d_labels_a, const int32_t* d_labels_b,
+                                            const int64_t* offsets, int32_t n_utt, int64_t* matched_out) {
+  if (!h || !offsets || n_utt < 0 || (n_utt > 0 && !matched_out)) return fail(UIS_ERR_INVALID_ARG, "null argument or negative n_utt");
+  if (n_utt > 0 && offsets[n_utt] > 0 && (!d_labels_a || !d_labels_b)) return fail(UIS_ERR_INVALID_ARG, "label pointer is null");
+  HIPCHK(hipSetDevice(h->device));
+  return eval_run(h, d_labels_a, d_labels_b, offsets, n_utt, matched_out);
+}
+
+UIS_EXPORT int32_t uis_eval_accuracy(uis_handle* h, const int32_t* labels_a, const int32_t* labels_b,
+                                     const int64_t* offsets, int32_t n_utt, int64_t* matched_out) {
+  if (!h || !offsets || n_utt < 0 || (n_utt > 0 && !matched_out)) return fail(UIS_ERR_INVALID_ARG, "null argument or negative n_utt");
+  const int64_t F = n_utt ? offsets[n_utt] : 0;
+  if (F > 0 && (!labels_a || !labels_b)) return fail(UIS_ERR_INVALID_ARG, "label pointer is null");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = h->ev_a.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
+  if ((rc = h->ev_b.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
+  if (F > 0) {
+    HIPCHK(hipMemcpyAsync(h->ev_a.p, labels_a, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->ev_b.p, labels_b, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  return eval_run(h, h->ev_a.as<int32_t>(), h->ev_b.as<int32_t>(), offsets, n_utt, matched_out);
+}
+
+UIS_EXPORT int32_t uis_eval_last_decode(uis_handle* h, const int32_t* truth, int32_t n_utt, int64_t* matched_out) {
+  if (!h || n_utt < 0 || (n_utt > 0 && !matched_out)) return fail(UIS_ERR_INVALID_ARG, "null argument or negative n_utt");
+  if (h->io_offsets.empty() || (int)h->io_offsets.size() != n_utt + 1)
+    return fail(UIS_ERR_INVALID_ARG, "no completed uis_decode with this many utterances on this handle");
+  const int64_t F = h->io_offsets[n_utt];
+  if (F > 0 && !truth) return fail(UIS_ERR_INVALID_ARG, "truth is null");
+  HIPCHK(hipSetDevice(h->device));
+  int rc;
+  if ((rc = h->ev_b.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
+  if (F > 0) HIPCHK(hipMemcpyAsync(h->ev_b.p, truth, (size_t)F * 4, hipMemcpyHostToDevice, h->stream));
+  // the predicted labels of the last uis_decode never left HBM for this
+  return eval_run(h, h->io_labels.as<int32_t>(), h->ev_b.as<int32_t>(), h->io_offsets.data(), n_utt, matched_out);
+}
+
+// ------------------------------------------------------------------ pinned host memory
+UIS_EXPORT int32_t uis_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(UIS_ERR_INVALID_ARG, "null out");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault);
+  if (e != hipSuccess) { *out = nullptr; return fail(UIS_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+  return UIS_OK;
+}
+
+UIS_EXPORT void uis_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }

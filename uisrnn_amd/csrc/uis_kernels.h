@@ -82,19 +82,16 @@ struct DecodeState {
   float* a1;              // [U*B][Hp]  relu(linear_mean1)
   // counters (device): [0] rnn rows, [1] rnn rows without dedup, [2] candidates, [3] max K
   unsigned long long* counters;
-  // k_rnn_fused: per-XCD-cluster arrival counters [8][16] (zeroed by every step's select),
-  // the XCC id each cluster's rank 0 saw [8], and a sticky abort word
-  uint32_t* cl_counter;
+  // in-launch barrier bookkeeping of k_decode_resident: the XCC id each cluster's rank 0 saw
+  // [ncl] and a sticky abort word (1 = barrier timed out, 2 = a cluster is not on one XCD)
   uint32_t* cl_xcc;
   uint32_t* cl_abort;
-  // k_rnn_dataflow: per-row-tile arrival counters [2][tile_cap] (GRU done, linear_mean1 done),
-  // zeroed by every step's select
-  uint32_t* tile_ctr;
-  int tile_cap;
-  // k_decode_resident: XCD c (the 32 workgroups observed on it) owns utterances c, c+8, ... and
+  // k_decode_resident: the device's CUs form `ncl` clusters of 32 workgroups (one per XCD: 8 on
+  // a whole MI355X, fewer in partitioned modes).  Cluster c owns utterances c, c+ncl, ... and
   // rows [c*rx_stride, (c+1)*rx_stride) of `rows` / `a1`; its row counters (by step parity) are
   // rx_nrows[c*32 + par], its barrier counter rx_bar[c*32].  pool_hid carries one extra slot
   // [U*S] holding h1 so that every GRU source row lives in one buffer.
+  int ncl;
   int rx_stride;
   int32_t* rx_nrows;
   uint32_t* rx_bar;

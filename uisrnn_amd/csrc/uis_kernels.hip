@@ -404,410 +404,14 @@ __global__ __launch_bounds__(512) void k_dense_head2(DevModel m, DecodeState st,
   }
 }
 
-// ------------------------------------------------------------ fused rnn step
-//
-// OPT-IN (UIS_FLAG_FUSED): GRU, linear_mean1 and linear_mean2 of one decode step in ONE launch
-// (depth-1 models).  256 workgroups, one per CU; workgroup b belongs to cluster b & 7 -- the XCD
-// it is observed to run on -- with rank b >> 3.  A cluster owns the row tiles {k, k+8, ...} and
-// walks them through the three phases; rank r owns feature tile r (+32, ...) in every phase, so
-// within a phase the weights of a tile are streamed once for up to three row tiles.  Between
-// phases the 32 workgroups of a cluster meet at a barrier (device-scope counter, ~0.9 us
-// measured, tools/probe_cluster.hip) and read what their siblings wrote with sc1 loads (L1
-// bypassed, served by the XCD's L2, which the siblings' plain stores have reached).
-// Placement is CHECKED, not assumed: every workgroup compares its XCC id with the one its
-// cluster's rank 0 published; a mismatch or a barrier time-out sets cl_abort and the host
-// reports an error instead of results.  Arithmetic and its order are those of k_dense_gru /
-// head1 / head2 (bit-identical, tested).
-// Measured (64 utterances): 27.8 us against 24.7 us for the three separate launches -- one fat
-// workgroup per CU serialises load, MFMA and epilogue that many small workgroups overlap -- so
-// it is not the default; it is the correct, tested starting point for a persistent variant.
-
-#define UIS_FUSED_R 3   // row tiles per pass (accumulators: 3 gates x 3 tiles)
-
-__device__ __forceinline__ void cluster_barrier(const DecodeState& st, int cluster, uint32_t target) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t* ctr = st.cl_counter + cluster * 16;
-    const uint32_t before = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (before + 1 < target &&
-           __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
-        __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-  }
-  __syncthreads();
-}
+// -------------------------------------------------- L2-coherent loads (resident decode)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// 16 bytes with sc1: bypasses this CU's L1, served by the XCD's L2 (where the sibling
+// workgroups' plain stores land)
 __device__ __forceinline__ f32x4 load_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */));
-}
-
-// splitk_tile with the B operand (rows) fetched by sc1 buffer loads: boff[r] = byte offset of
-// this lane's row of row tile r from the buffer base.
-template <int NG, int R>
-__device__ __forceinline__ void splitk_tile_sc1(const float* __restrict__ Wt, int tiles_per_gate, int tile0, int nKb,
-                                                __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[R],
-                                                const float* __restrict__ bias, int gate_stride, float* spart) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int q = lane >> 4;
-  const int per = uis_kseg_blocks(nKb);
-  const int kb0 = w * per;
-  const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
-  const f32x4* wp[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g)
-    wp[g] = reinterpret_cast<const f32x4*>(Wt) + ((size_t)(g * tiles_per_gate + tile0) * nKb) * 64 + lane;
-  f32x4 acc[R][NG];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-      acc[r][g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q)
-                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
-    f32x4 a[UIS_STAGE][NG], b[UIS_STAGE][R];
-#pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
-      const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) a[u][g] = wp[g][(size_t)kk * 64];
-#pragma unroll
-      for (int r = 0; r < R; ++r) b[u][r] = load_sc1(rsrc, boff[r] + (uint32_t)(kk * 64 + q * 16));
-    }
-#pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
-      if (kb + u < kb1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-              acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][e], b[u][r][e], acc[r][g], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * R + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) =
-          acc[r][g];
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(512) void k_rnn_fused(DevModel m, DecodeState st, int par) {
-  constexpr int R = UIS_FUSED_R;
-  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * R * 3 * 256];
-  const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
-  const int t = threadIdx.x;
-  const int nrows = st.nrows[par];
-  if (nrows == 0) return;  // the same for every workgroup: nobody waits at a barrier
-  const int nrt = (nrows + 15) >> 4;
-  const int my_tiles = nrt > cluster ? (nrt - cluster + 7) >> 3 : 0;  // row tiles cluster, cluster+8, ...
-  const int nft = m.Hp / 16, nft2 = m.Dp / 16;
-  uint32_t xcc = 0;
-  if (t == 0) {
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xfu;
-    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  constexpr int EPT = (R + 1) / 2;
-  const size_t slot_stride = (size_t)m.Hp;  // depth 1
-
-  // ---- phase 1: GRU (B operand: source hidden states, written by earlier launches)
-  for (int ft = rank; ft < nft; ft += 32) {
-    for (int i0 = 0; i0 < my_tiles; i0 += R) {
-      const float* hsrc[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
-        const RnnRow rb = st.rows[row0 + (t & 15)];
-        hsrc[r] = rb.src >= 0 ? hid_ptr(m, st, rb, rb.src, 0) : m.h1;
-      }
-      const int j = ft * 16 + (t & 15);
-      RnnRow re[EPT]; float gir[EPT], giz[EPT], gin[EPT], hprev[EPT]; bool ework[EPT];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int r = (t >> 8) + 2 * k;
-        const int erow = (cluster + 8 * (i0 + r)) * 16 + ((t & 255) >> 4);
-        ework[k] = r < R && i0 + r < my_tiles && erow < nrows;
-        gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
-        re[k] = RnnRow{};
-        if (ework[k]) {
-          re[k] = st.rows[erow];
-          const float* gi = st.gi0 + (size_t)re[k].frame * m.G;
-          const float* hs = re[k].src >= 0 ? hid_ptr(m, st, re[k], re[k].src, 0) : m.h1;
-          gir[k] = gi[j]; giz[k] = gi[m.Hp + j]; gin[k] = gi[2 * m.Hp + j]; hprev[k] = hs[j];
-        }
-      }
-      splitk_tile<3, R, 1>(m.whh[0], nft, ft, m.Hp / 16, hsrc, m.bhh[0] + ft * 16, m.Hp, spart);
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        if (!ework[k]) continue;
-        const int r = (t >> 8) + 2 * k, e = t & 255;
-        const float ghr = splitk_combine<R, 3>(spart, r, 0, e);
-        const float ghz = splitk_combine<R, 3>(spart, r, 1, e);
-        const float ghn = splitk_combine<R, 3>(spart, r, 2, e);
-        const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
-        st.pool_hid[((size_t)re[k].utt * st.S + re[k].dst) * slot_stride + j] = out;
-      }
-      __syncthreads();  // spart is reused by the next pass
-    }
-  }
-  cluster_barrier(st, cluster, 32u);
-  if (t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
-    __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
-
-  // ---- phase 2: linear_mean1 + relu (B operand: the hidden states the siblings just wrote)
-  const __amdgpu_buffer_rsrc_t rs_hid =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
-  for (int ft = rank; ft < nft; ft += 32) {
-    for (int i0 = 0; i0 < my_tiles; i0 += R) {
-      uint32_t boff[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
-        const RnnRow rb = st.rows[row0 + (t & 15)];
-        boff[r] = (uint32_t)((((size_t)rb.utt * st.S + rb.dst) * slot_stride) * 4);
-      }
-      splitk_tile_sc1<1, R>(m.w1, 0, ft, m.Hp / 16, rs_hid, boff, m.b1 + ft * 16, 0, spart);
-      for (int e = t; e < R * 256; e += 512) {
-        const int r = e >> 8, row = (cluster + 8 * (i0 + r)) * 16 + ((e & 255) >> 4);
-        if (i0 + r < my_tiles && row < nrows) {
-          const float v = splitk_combine<R, 1>(spart, r, 0, e & 255);
-          st.a1[(size_t)row * m.Hp + ft * 16 + (e & 15)] = v > 0.0f ? v : 0.0f;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  cluster_barrier(st, cluster, 64u);
-
-  // ---- phase 3: linear_mean2 + running-mean update (B operand: a1 rows of the siblings)
-  const __amdgpu_buffer_rsrc_t rs_a1 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
-  for (int ft = rank; ft < nft2; ft += 32) {
-    for (int i0 = 0; i0 < my_tiles; i0 += R) {
-      uint32_t boff[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int row0 = i0 + r < my_tiles ? (cluster + 8 * (i0 + r)) * 16 : 0;
-        boff[r] = (uint32_t)(((size_t)(row0 + (t & 15)) * m.Hp) * 4);
-      }
-      const int f = ft * 16 + (t & 15);
-      RnnRow re[EPT]; float old[EPT]; bool ework[EPT];
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const int r = (t >> 8) + 2 * k;
-        const int erow = (cluster + 8 * (i0 + r)) * 16 + ((t & 255) >> 4);
-        ework[k] = r < R && i0 + r < my_tiles && erow < nrows;
-        old[k] = 0.0f;
-        re[k] = RnnRow{};
-        if (ework[k]) {
-          re[k] = st.rows[erow];
-          if (re[k].src >= 0) old[k] = st.pool_mean[((size_t)re[k].utt * st.S + re[k].src) * m.Dp + f];
-        }
-      }
-      splitk_tile_sc1<1, R>(m.w2, 0, ft, m.Hp / 16, rs_a1, boff, m.b2 + ft * 16, 0, spart);
-#pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        if (!ework[k]) continue;
-        const int r = (t >> 8) + 2 * k;
-        float v = splitk_combine<R, 1>(spart, r, 0, t & 255);
-        if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
-        if (f >= m.D) v = 0.0f;
-        st.pool_mean[((size_t)re[k].utt * st.S + re[k].dst) * m.Dp + f] = v;
-      }
-      __syncthreads();
-    }
-  }
-}
-
-// --------------------------------------------------------- dataflow rnn step
-//
-// OPT-IN (UIS_FLAG_DATAFLOW): the workgroups of k_dense_gru<1>, k_dense_head1<1,1> and
-// k_dense_head2<1> in ONE launch (depth-1 models).  Same tiles, same arithmetic; instead of a
-// kernel boundary a consumer tile waits for its row tile's producers on an arrival counter:
-// GRU tile (rt, *) -> counter[rt] -> head1 tile (rt, *) -> counter[cap + rt] -> head2 tile (rt, *).
-// Producers and consumers of a row tile sit on different XCDs, so what they exchange is stored
-// write-through (sc0 sc1) and loaded with sc0 sc1 (the reader's L2 may hold a stale copy of a
-// re-used slot), flags are device-scope atomics, and every storing wave drains its stores
-// before the flag (MI355X_MICROARCH.md, hand-off forms).  GRU workgroups come first in the
-// grid, then head1, then head2, so producers are dispatched before their consumers; a consumer
-// that waits too long sets cl_abort instead of hanging.
-
-__device__ __forceinline__ void st_wt(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, byte_off, 0, 17 /* sc0 sc1 */);
-}
-__device__ __forceinline__ f32x4 ld_sys(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 17 /* sc0 sc1 */));
-}
-
-__device__ __forceinline__ void tile_signal(uint32_t* ctr) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tile_wait(const DecodeState& st, uint32_t* ctr, uint32_t target) {
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(12);
-      if (++spins > (1u << 19)) { __hip_atomic_store(st.cl_abort, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-  }
-  __syncthreads();
-}
-
-// splitk_tile<1, 1, 1> with the B operand loaded sc0 sc1
-__device__ __forceinline__ void splitk_tile_sys(const float* __restrict__ Wt, int tile0, int nKb,
-                                                __amdgpu_buffer_rsrc_t rsrc, uint32_t boff,
-                                                const float* __restrict__ bias, float* spart) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int q = lane >> 4;
-  const int per = uis_kseg_blocks(nKb);
-  const int kb0 = w * per;
-  const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(Wt) + ((size_t)tile0 * nKb) * 64 + lane;
-  f32x4 acc = w == 0 ? *reinterpret_cast<const f32x4*>(bias + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  for (int kb = kb0; kb < kb1; kb += UIS_STAGE) {
-    f32x4 a[UIS_STAGE], b[UIS_STAGE];
-#pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
-      const int kk = kb + u < kb1 ? kb + u : kb1 - 1;
-      a[u] = wp[(size_t)kk * 64];
-      b[u] = ld_sys(rsrc, boff + (uint32_t)(kk * 64 + q * 16));
-    }
-#pragma unroll
-    for (int u = 0; u < UIS_STAGE; ++u) {
-      if (kb + u < kb1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
-      }
-    }
-  }
-  *reinterpret_cast<f32x4*>(spart + (size_t)w * 256 + (lane & 15) * 16 + 4 * q) = acc;
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(512) void k_rnn_dataflow(DevModel m, DecodeState st, int par) {
-  __shared__ __attribute__((aligned(16))) float spart[UIS_KSPLIT * 3 * 256];
-  const int nft = m.Hp / 16, nft2 = m.Dp / 16;
-  const int g1 = step_grid_blocks(st.max_rows, nft, 1, 1);   // GRU workgroups, then head1, then head2
-  const int t = threadIdx.x;
-  const int bid = blockIdx.x;
-  const size_t slot_stride = (size_t)m.Hp;  // depth 1
-  const __amdgpu_buffer_rsrc_t rs_hid =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
-  RnnRow rb[1];
-  if (bid < g1) {
-    // ---- GRU tile (as k_dense_gru<1>, layer 0); h' stored write-through, then counter[rt]
-    const StepTile tl = step_tile<1, 1>(st, par, nft, rb, bid);
-    if (!tl.active) return;
-    // epilogue by 64 threads: thread t owns row t>>2, units 4*(t&3) .. +3 (one 16-byte store)
-    const int j = tl.ft0 * 16 + 4 * (t & 3);
-    const int erow = tl.row0 + (t >> 2);
-    const bool ework = t < 64 && erow < tl.nrows;
-    RnnRow re{};
-    f32x4 gir{}, giz{}, gin{}, hprev{};
-    if (ework) {
-      re = st.rows[erow];
-      const float* gi = st.gi0 + (size_t)re.frame * m.G;
-      const float* hs = re.src >= 0 ? hid_ptr(m, st, re, re.src, 0) : m.h1;
-      gir = *reinterpret_cast<const f32x4*>(gi + j);
-      giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j);
-      gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j);
-      hprev = *reinterpret_cast<const f32x4*>(hs + j);
-    }
-    const float* hsrc[1] = {rb[0].src >= 0 ? hid_ptr(m, st, rb[0], rb[0].src, 0) : m.h1};
-    splitk_tile<3, 1, 1>(m.whh[0], nft, tl.ft0, m.Hp / 16, hsrc, m.bhh[0] + tl.ft0 * 16, m.Hp, spart);
-    if (ework) {
-      const int el = (t >> 2) * 16 + 4 * (t & 3);
-      f32x4 gh[3];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        gh[g] = *reinterpret_cast<const f32x4*>(spart + (size_t)g * 256 + el);
-#pragma unroll
-        for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) {
-          const f32x4 p4 = *reinterpret_cast<const f32x4*>(spart + (size_t)(sgm * 3 + g) * 256 + el);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gh[g][i] = gh[g][i] + p4[i];
-        }
-      }
-      f32x4 out;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        out[i] = j + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), rs_hid,
-                                             (uint32_t)((((size_t)re.utt * st.S + re.dst) * slot_stride + j) * 4), 0, 17);
-    }
-    tile_signal(st.tile_ctr + tl.rt0);
-    return;
-  }
-  if (bid < 2 * g1) {
-    // ---- head1 tile: waits for the nft GRU tiles of its row tile
-    const StepTile tl = step_tile<1, 1>(st, par, nft, rb, bid - g1);
-    if (!tl.active) return;
-    tile_wait(st, st.tile_ctr + tl.rt0, (uint32_t)nft);
-    const uint32_t boff = (uint32_t)((((size_t)rb[0].utt * st.S + rb[0].dst) * slot_stride) * 4);
-    splitk_tile_sys(m.w1, tl.ft0, m.Hp / 16, rs_hid, boff, m.b1 + tl.ft0 * 16, spart);
-    if (t < 64) {
-      const int row = tl.row0 + (t >> 2);
-      if (row < tl.nrows) {
-        const int el = (t >> 2) * 16 + 4 * (t & 3);
-        f32x4 v = *reinterpret_cast<const f32x4*>(spart + el);
-#pragma unroll
-        for (int sgm = 1; sgm < UIS_KSPLIT; ++sgm) {
-          const f32x4 p4 = *reinterpret_cast<const f32x4*>(spart + (size_t)sgm * 256 + el);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = v[i] + p4[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_a1,
-                                               (uint32_t)(((size_t)row * m.Hp + tl.ft0 * 16 + 4 * (t & 3)) * 4), 0, 17);
-      }
-    }
-    tile_signal(st.tile_ctr + st.tile_cap + tl.rt0);
-    return;
-  }
-  {
-    // ---- head2 tile: waits for the nft head1 tiles of its row tile; its output is read by the
-    // next launch (plain stores)
-    const StepTile tl = step_tile<1, 1>(st, par, nft2, rb, bid - 2 * g1);
-    if (!tl.active) return;
-    const int erow = tl.row0 + ((t & 255) >> 4);
-    const bool ework = t < 256 && erow < tl.nrows;
-    const int f = tl.ft0 * 16 + (t & 15);
-    RnnRow re{};
-    float old = 0.0f;
-    if (ework) {
-      re = st.rows[erow];
-      if (re.src >= 0) old = st.pool_mean[((size_t)re.utt * st.S + re.src) * m.Dp + f];
-    }
-    tile_wait(st, st.tile_ctr + st.tile_cap + tl.rt0, (uint32_t)nft);
-    const uint32_t boff = (uint32_t)(((size_t)(tl.row0 + (t & 15)) * m.Hp) * 4);
-    splitk_tile_sys(m.w2, tl.ft0, m.Hp / 16, rs_a1, boff, m.b2 + tl.ft0 * 16, spart);
-    if (ework) {
-      float v = splitk_combine<1, 1>(spart, 0, 0, t);
-      if (re.src >= 0) v = uis_mean_update(old, v, re.nprev);
-      if (f >= m.D) v = 0.0f;
-      st.pool_mean[((size_t)re.utt * st.S + re.dst) * m.Dp + f] = v;
-    }
-  }
 }
 
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
@@ -954,8 +558,6 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   const int nb = st.beam_n[(size_t)tpar * U + u];
   // next step's row counter: its readers (the previous step's GEMMs) finished a launch ago
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
-  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
-  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
   for (int i = tid; i < m.Dp; i += 256) swgt[i] = m.wgt[i];
   for (int e = tid; e < B * Kmax; e += 256) {
     sslot[e] = st.beam_slot[bcur * Kmax + e];
@@ -1712,8 +1314,6 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int u = blockIdx.x, tid = threadIdx.x;
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
-  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;  // this step's k_rnn_fused barriers
-  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;  // k_rnn_dataflow
   select_fast_body<256, false, false>(m, st, par, u, smem_raw, RowSink{st.rows, st.nrows + par});
 }
 
@@ -1721,8 +1321,9 @@ __global__ __launch_bounds__(256) void k_select_fast(DevModel m, DecodeState st,
 //
 // The whole lock-step decode (look_ahead 1, depth 1, rnn_hidden_size 512) in ONE launch with the
 // weights held in registers.  256 workgroups of 512 threads, one per CU; workgroup b belongs to
-// cluster b & 7 -- the XCD it is observed to run on, checked against HW_REG_XCC_ID -- with rank
-// b >> 3.  A cluster decodes utterances c, c+8, ... on its own: nothing is exchanged between
+// cluster b % ncl (ncl = CUs / 32 = the number of XCDs: 8 on a whole MI355X) -- the XCD it is
+// observed to run on, checked against HW_REG_XCC_ID -- with rank b / ncl.  A cluster decodes
+// utterances c, c+ncl, ... on its own: nothing is exchanged between
 // XCDs, so everything the 32 workgroups of a cluster hand each other stays in that XCD's L2
 // (plain stores, `s_waitcnt vmcnt(0)`, a cluster barrier, sc1 loads that bypass the reader's
 // L1; tools/probe_cluster.hip: 0 stale reads, ~0.9 us per barrier).
@@ -1930,7 +1531,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   static_assert(UIS_RES_HEAD_TILES % SH1 == 0 && UIS_RES_HEAD_TILES % SH2 == 0, "chunks start at a rank's first tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int cluster = blockIdx.x & 7, rank = blockIdx.x >> 3;
+  const int ncl = st.ncl;  // clusters of 32 workgroups: workgroup b is observed on XCD b % (number of XCDs)
+  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
   const int U = st.U, S = st.S;
   const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
   float* spart = reinterpret_cast<float*>(smem_raw + ((L.total + 255) & ~255));
@@ -1955,8 +1557,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   __syncthreads();
   {  // decode steps of this cluster = the longest of its utterances
     int myT = 0;
-    for (int i = t; cluster + 8 * i < U; i += 512) {
-      const int u = cluster + 8 * i;
+    for (int i = t; cluster + ncl * i < U; i += 512) {
+      const int u = cluster + ncl * i;
       const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
       myT = T > myT ? (int)T : myT;
     }
@@ -1996,10 +1598,10 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
-  const bool keep_beam = U <= 256;
-  const bool did_select = cluster + 8 * rank < U;  // keep_beam: this workgroup owns an utterance
+  const bool keep_beam = U <= 32 * ncl;
+  const bool did_select = cluster + ncl * rank < U;  // keep_beam: this workgroup owns an utterance
   long my_off0 = 0, my_off1 = 0;
-  if (keep_beam && cluster + 8 * rank < U) { my_off0 = (long)st.off[cluster + 8 * rank]; my_off1 = (long)st.off[cluster + 8 * rank + 1]; }
+  if (keep_beam && cluster + ncl * rank < U) { my_off0 = (long)st.off[cluster + ncl * rank]; my_off1 = (long)st.off[cluster + ncl * rank + 1]; }
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rt_prev = wall_clock64();
@@ -2033,16 +1635,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
       if (did_select) {
         if (s == 0) {  // (later steps: prepared while waiting for the previous step's last barrier)
-          select_fast_body<512, true, true, DP, 5>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1);
+          select_fast_body<512, true, true, DP, 5>(m, st, par, cluster + ncl * rank, smem_raw, sink, s, my_off0, my_off1);
           __syncthreads();
         }
-        select_fast_body<512, true, true, DP, 2>(m, st, par, cluster + 8 * rank, smem_raw, sink, s, my_off0, my_off1,
+        select_fast_body<512, true, true, DP, 2>(m, st, par, cluster + ncl * rank, smem_raw, sink, s, my_off0, my_off1,
                                                  [&]() { xcd_arrive_wave0(st, cluster, s_ctl); });
       }
       __syncthreads();
     } else {
-      for (int i = rank; cluster + 8 * i < U; i += 32) {
-        select_fast_body<512, true, false, DP>(m, st, par, cluster + 8 * i, smem_raw, sink);
+      for (int i = rank; cluster + ncl * i < U; i += 32) {
+        select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
         __syncthreads();
       }
     }
@@ -2131,7 +1733,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       // arrive, do the first half of the next step's select preparation (this workgroup's own LDS
       // tables: nobody else's data), then wait
       xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + ncl * rank, smem_raw, sink, s + 1, my_off0, my_off1);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(3);
@@ -2161,7 +1763,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(4);
     if (prep_next) {  // ... and the second half inside the next barrier
       xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 4>(m, st, par ^ 1, cluster + 8 * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+      select_fast_body<512, true, true, DP, 4>(m, st, par ^ 1, cluster + ncl * rank, smem_raw, sink, s + 1, my_off0, my_off1);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
@@ -2344,11 +1946,12 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   const int step = st.utt_step[u];
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
   if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
-  if (u == 0 && tid < 8 && st.cl_counter) st.cl_counter[tid * 16] = 0;
-  if (u == 0 && st.tile_ctr) for (int i = tid; i < 2 * st.tile_cap; i += 256) st.tile_ctr[i] = 0;
   const long N = off1 - off0;
   const long T = (long)st.tau * N;
   if (step >= T) return;
+  // an intermediate level overflowed earlier: the utterance's result is void (the host reports
+  // UIS_ERR_UNSUPPORTED); do not grind through full levels for it
+  if (st.overflow[u] & 2) return;
   const long frame = off0 + (step % N);
   const long win = step / L;
   const long t0 = win * L;
@@ -2461,7 +2064,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
     const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; },
                                 [&](int i, int pre) { if (key[i] != ~0ull && pre < NC) winv[pre] = i; }, lds4);
     keep = nfin;
-    if (keep > NC) { keep = NC; if (tid == 0) st.overflow[u] = 1; }
+    if (keep > NC) { keep = NC; if (tid == 0) atomicOr(&st.overflow[u], 2); }  // level capacity (not the cluster cap): bit 1
   } else {
     const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
     keep = nfin < B ? nfin : B;
@@ -2529,7 +2132,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
     const int Kb = in.K[b];
     const bool is_new = c == Kb;
     int Knew = Kb + (is_new ? 1 : 0);
-    if (Knew > Kmax) { Knew = Kmax; st.overflow[u] = 1; }
+    if (Knew > Kmax) { Knew = Kmax; atomicOr(&st.overflow[u], 1); }
     out.K[r] = Knew;
     out.last[r] = c;
     out.sum[r] = in.sum[b] + ((is_new || c != in.last[b]) ? 1 : 0);
@@ -2594,6 +2197,7 @@ __global__ void k_backtrace_window(DecodeState st, int32_t* __restrict__ labels,
       if (tt >= T - N) out[tt - (T - N)] = (int32_t)rec[1 + k];
     }
     r = (int)rec[0];
+    if (r >= st.B) r = st.B - 1;  // records of windows that never ran (overflowed utterance) are stale
   }
 }
 
@@ -2637,7 +2241,12 @@ __global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __res
       for (int k = 0; k < 8; ++k) r[k] = r0 + k < B ? r0 + k : 0;
       for (long s2 = hi; s2 >= lo; --s2) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = (int)(bp[(size_t)s2 * B + r[k]] >> 16);
+        for (int k = 0; k < 8; ++k) {
+          // ranks >= that step's beam width were never written (stale words): clamp, so the walk
+          // stays inside this utterance's records; such entry ranks are never stitched in
+          const int pr = (int)(bp[(size_t)s2 * B + r[k]] >> 16);
+          r[k] = pr < B ? pr : B - 1;
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k)

@@ -59,6 +59,7 @@ class UISRNN:
     self._decoder = None
     self._extra_decoders = {}
     self.last_stats = None
+    self._single_pass = False
 
   # ---- the attributes callers of the reference read and write
   @property
@@ -205,7 +206,48 @@ class UISRNN:
           raise RuntimeError(
               'more than {} clusters per hypothesis'.format(_MAX_CLUSTERS_LIMIT))
     self.last_stats = stats  # (parallel_predict: the last worker to finish wins)
+    self._single_pass = cap == _initial_cluster_cap(args)  # no retry: one decode covered everything
     return results
+
+  def predict_and_evaluate(self, test_sequences, test_cluster_ids, args):
+    """predict() followed by the demo's accuracy step with the labels kept on the device.
+
+    The reference's demo.py:58-64 calls predict and compute_sequence_match_accuracy per
+    utterance on the host.  Here the batch is decoded once and the predicted labels, still in
+    HBM, are matched against the ground truth by uis_eval_last_decode (confusion matrix +
+    exact assignment per utterance in one launch).  Not part of the reference's API.
+
+    Args:
+      test_sequences: list of [N_i, D] float arrays.
+      test_cluster_ids: list of lists of ground-truth ids (any hashable, e.g. str).
+    Returns:
+      (predicted label lists, accuracies) -- accuracies equal
+      compute_sequence_match_accuracy(truth, predicted) exactly.
+    """
+    from uisrnn_amd import evals  # pylint: disable=import-outside-toplevel
+    if not isinstance(test_sequences, list) or not isinstance(test_cluster_ids, list):
+      raise TypeError('test_sequences and test_cluster_ids must be lists')
+    if len(test_sequences) != len(test_cluster_ids):
+      raise ValueError('one list of cluster ids per test sequence')
+    for seq, ids in zip(test_sequences, test_cluster_ids):
+      self._check_sequence(seq)
+      if len(ids) != seq.shape[0] or not len(ids):
+        raise ValueError('sequence1 and sequence2 must be non-empty and of the same size')
+    if not test_sequences:
+      return [], []
+    decoder = self._get_decoder()
+    self._single_pass = False
+    predicted = self._decode_batch(test_sequences, args)
+    truth = np.concatenate([evals.dense_ids(list(ids)) for ids in test_cluster_ids])
+    lens = np.array([s.shape[0] for s in test_sequences], dtype=np.int64)
+    if self._single_pass:  # the labels of that one decode are still resident: no upload
+      matched = decoder.eval_last_decode(truth, len(test_sequences))
+    else:  # the cluster-cap retry decoded a subset last: hand the labels back
+      offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+      offsets[1:] = np.cumsum(lens)
+      flat = np.concatenate([evals.dense_ids(p) for p in predicted])
+      matched = decoder.eval_matched(truth, flat, offsets)
+    return predicted, [float(m) / int(n) for m, n in zip(matched, lens)]
 
   def predict_single(self, test_sequence, args):
     """Predict labels for one test sequence (uisrnn/uisrnn.py:479-562).

@@ -203,7 +203,10 @@ def read_torch_zip(filepath):
         storages[key] = arr.astype(storage_type.dtype, copy=False)
       return storages[key]
 
-    import numpy.core.multiarray as _np_multiarray  # noqa: alias of numpy._core
+    try:  # numpy >= 2 (numpy.core is a deprecated alias there and will go away)
+      import numpy._core.multiarray as _np_multiarray  # pylint: disable=import-outside-toplevel
+    except ImportError:
+      import numpy.core.multiarray as _np_multiarray  # pylint: disable=import-outside-toplevel
     allowed = {
         ('collections', 'OrderedDict'): collections.OrderedDict,
         ('torch._utils', '_rebuild_tensor_v2'): _rebuild_tensor_v2,
