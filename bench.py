@@ -68,7 +68,6 @@ CONFIGS = {
             utterances_per_gpu=64, frames=500, observation_dim=512, rnn_hidden_size=512,
             rnn_depth=1, beam_size=20, look_ahead=1, test_iteration=2, max_clusters=11),
 }
-TRAINED_D256 = os.path.join(ROOT, 'tests', 'golden', 'trained_d256.uisrnn')
 
 
 def flops_per_frame(cfg, clusters=4):
@@ -138,9 +137,9 @@ def parse(argv=None):
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--beam_size', type=int, default=None)
   ap.add_argument('--model', default='auto', choices=['auto', 'trained', 'tracker'],
-                  help='trained = tests/golden/trained_d256.uisrnn (the reference\'s fit, '
-                       'SURVEY.md 8d; D=256 configs only); tracker = closed-form weights '
-                       '(uisrnn_amd.synth); auto = trained where it applies')
+                  help='trained = tests/golden/trained_d{256,512}.uisrnn (the reference\'s fit, '
+                       'SURVEY.md 8d); tracker = closed-form weights (uisrnn_amd.synth); '
+                       'auto = trained where it applies')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--no_host_buffers', action='store_true',
                   help='skip the PCIe-inclusive pass (value_host_buffers)')
@@ -201,16 +200,17 @@ def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None)
 
 
 def load_model(cfg, which):
-  """(params, description): the trained checkpoint where it applies, else closed-form weights."""
+  """(params, description): a checkpoint trained by the reference where one exists, else closed-form weights."""
   from uisrnn_amd import synth, weights  # pylint: disable=import-outside-toplevel
   dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
-  can_train = dim == 256 and hid == 512 and os.path.exists(TRAINED_D256)
+  path = os.path.join(ROOT, 'tests', 'golden', 'trained_d{}.uisrnn'.format(dim))
+  can_train = dim in (256, 512) and hid == 512 and cfg['rnn_depth'] == 1 and os.path.exists(path)
   if which == 'trained' and not can_train:
-    raise SystemExit('--model trained needs tests/golden/trained_d256.uisrnn and a D=256/H=512 config')
+    raise SystemExit('--model trained needs tests/golden/trained_d{256,512}.uisrnn and a matching config')
   if which in ('auto', 'trained') and can_train:
-    return (weights.load_checkpoint(TRAINED_D256),
-            'tests/golden/trained_d256.uisrnn: trained by the reference\'s fit(), 300 iterations '
-            '(tests/golden/make_trained.py)')
+    return (weights.load_checkpoint(path),
+            'tests/golden/trained_d{}.uisrnn: trained by the reference\'s fit(), 300 iterations on synthetic '
+            'd-vectors (tests/golden/make_trained.py, SURVEY.md 8d)'.format(dim))
   return (synth.tracker_params(dim, hid, cfg['rnn_depth'], seed=0),
           'closed-form tracker (uisrnn_amd.synth)')
 

@@ -6,6 +6,7 @@ Nothing here is used by the product; the files it writes under tests/golden/ are
   python tests/golden/make_trained.py train_single     # tests/uisrnn_test.py:26-70 shape
   python tests/golden/make_trained.py train_toy4       # tests/integration_test.py:56-134 shape
   python tests/golden/make_trained.py train_d256       # SURVEY.md 8(d) model (D=256, H=512)
+  python tests/golden/make_trained.py train_d512       # same recipe at D=512 (BASELINE configs[4])
   python tests/golden/make_trained.py predict_d256 100 # reference predict() on 100-frame utterances
   python tests/golden/make_trained.py predict_d256 500
   python tests/golden/make_trained.py predict_d256 1000
@@ -219,33 +220,34 @@ def train_toy4():
   print('trained_toy4 accuracy', acc)
 
 
-def _d256_args(uisrnn):
+def _d256_args(uisrnn, dim=256):
   model_args, training_args, inference_args = _args(uisrnn)
   model_args.enable_cuda = False
-  model_args.observation_dim = 256
+  model_args.observation_dim = dim
   model_args.rnn_hidden_size = 512
   model_args.rnn_depth = 1
   model_args.verbosity = 0
   return model_args, training_args, inference_args
 
 
-def train_d256():
-  """the reference's fit, 300 iterations, on synthetic d-vectors."""
+def train_d256(dim=256):
+  """the reference's fit, 300 iterations, on synthetic d-vectors
+  (dim 512: the model of BASELINE configs[4], same recipe)."""
   from uisrnn_amd import synth  # pylint: disable=import-outside-toplevel
   uisrnn = make_golden.import_reference()
   _seed_all()
-  model_args, training_args, _ = _d256_args(uisrnn)
+  model_args, training_args, _ = _d256_args(uisrnn, dim)
   training_args.learning_rate = 1e-3
   training_args.train_iteration = 300
   training_args.batch_size = 10
-  seqs, ids = synth.make_utterances(D256_TRAIN_SEED, 40, 300, 256)
+  seqs, ids = synth.make_utterances(D256_TRAIN_SEED, 40, 300, dim)
   ids = [['s{}'.format(int(i)) for i in row] for row in ids]
   model = uisrnn.UISRNN(model_args)
   t0 = time.time()
   model.fit(seqs, ids, training_args)
   print('fit: {:.0f}s, transition_bias {}, sigma2 mean {}'.format(
       time.time() - t0, model.transition_bias, float(model.sigma2.mean())), flush=True)
-  model.save(os.path.join(HERE, 'trained_d256.uisrnn'))
+  model.save(os.path.join(HERE, 'trained_d{}.uisrnn'.format(dim)))
 
 
 def _predict_d256_one(job):
@@ -348,6 +350,8 @@ def main():
     train_toy4()
   elif cmd == 'train_d256':
     train_d256()
+  elif cmd == 'train_d512':
+    train_d256(512)
   elif cmd == 'predict_d256':
     predict_d256(int(sys.argv[2]))
   elif cmd == 'wholebox':

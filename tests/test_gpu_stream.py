@@ -21,9 +21,9 @@ def _bits(a):
   return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def _stream(dec, seqs, beam, schedule, max_frames, max_clusters=0, check_every_push=None):
+def _stream(dec, seqs, beam, schedule, max_frames, max_clusters=0, check_every_push=None, flags=0):
   """schedule: list of per-push lists of frame counts (one per utterance)."""
-  dec.stream_begin(len(seqs), beam, max_frames, max_clusters=max_clusters)
+  dec.stream_begin(len(seqs), beam, max_frames, max_clusters=max_clusters, flags=flags)
   try:
     pos = [0] * len(seqs)
     for counts in schedule:
@@ -74,14 +74,18 @@ def test_any_chunking_equals_offline_decode(max_chunk, oracle_lib):
   off, offsets = _offline(dec, seqs, 10)
   ref = oracle_lib.decode(params, seqs, 10, 1, 1, n_threads=8)
   rng = np.random.default_rng(max_chunk)
-  labels, scores, overflow, status, beam = _stream(dec, seqs, 10, _random_schedule(rng, lens, max_chunk), 100)
-  assert status == 0 and not overflow.any()
-  for u in range(len(seqs)):
-    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
-    assert np.array_equal(labels[u], ref['labels'][u]), u
-  assert np.array_equal(_bits(scores), _bits(off['scores']))
-  assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
-  assert np.array_equal(_bits(beam), _bits(ref['beam_scores']))
+  schedule = _random_schedule(rng, lens, max_chunk)
+  # a push runs its steps in ONE launch of the resident decode kernel where that applies (this
+  # shape: UIS_FLAG_RESIDENT demands it) and as four kernels per step under UIS_FLAG_STEPWISE
+  for flags in (_capi.UIS_FLAG_RESIDENT, _capi.UIS_FLAG_STEPWISE, 0):
+    labels, scores, overflow, status, beam = _stream(dec, seqs, 10, schedule, 100, flags=flags)
+    assert status == 0 and not overflow.any()
+    for u in range(len(seqs)):
+      assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
+      assert np.array_equal(labels[u], ref['labels'][u]), u
+    assert np.array_equal(_bits(scores), _bits(off['scores']))
+    assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
+    assert np.array_equal(_bits(beam), _bits(ref['beam_scores']))
   # the handle is usable for ordinary decodes again
   again, _ = _offline(dec, seqs, 10)
   assert np.array_equal(again['labels'], off['labels'])
@@ -112,6 +116,25 @@ def test_prefix_labels_after_every_push(oracle_lib):
 
   schedule = [[5, 0, 2], [0, 0, 9], [7, 10, 0], [12, 0, 20]]
   _stream(dec, seqs, 6, schedule, 40, check_every_push=check)
+  _stream(dec, seqs, 6, schedule, 40, check_every_push=check, flags=_capi.UIS_FLAG_STEPWISE)
+
+
+def test_many_utterances_one_frame_pushes(oracle_lib):
+  """More utterances than workgroups per cluster, one frame per push, some silent: the
+  one-launch step kernel against the offline decode."""
+  params = synth.tracker_params(256, 256, 1, seed=25)   # hidden 256: two ranks share a feature tile
+  lens = [6 + (5 * u) % 9 for u in range(70)]
+  seqs, _ = synth.make_utterances(12_400, len(lens), lens, 256)
+  dec = _capi.Decoder(params)
+  off, offsets = _offline(dec, seqs, 10)
+  schedule = [[1 if (n > t and (u + t) % 4) else 0 for u, n in enumerate(lens)] for t in range(14)]
+  left = [n - sum(row[u] for row in schedule) for u, n in enumerate(lens)]
+  schedule.append(left)
+  labels, scores, overflow, status, beam = _stream(dec, seqs, 10, schedule, 16, flags=_capi.UIS_FLAG_RESIDENT)
+  assert status == 0 and not overflow.any()
+  for u in range(len(seqs)):
+    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
+  assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
 
 
 def test_odd_model_shapes_general_select_and_depth(oracle_lib):

@@ -1,0 +1,44 @@
+"""Latency of uis_stream_push: one frame per utterance per push (and 16-frame chunks), the
+one-launch step kernel against the four-kernels-per-step path.  Prints JSON.
+
+  python tools/stream_latency.py [utterances] [pushes]
+"""
+import json, sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from uisrnn_amd import _capi, synth, weights
+import os
+n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n_push = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+path = 'tests/golden/trained_d256.uisrnn'
+params = weights.load_checkpoint(path) if os.path.exists(path) else synth.tracker_params(256, 512, 1, seed=0)
+seqs, _ = synth.make_utterances(30_000, n_utt, n_push + 64 * 16, 256)
+dec = _capi.Decoder(params)
+out = {'utterances': n_utt, 'model': path if os.path.exists(path) else 'tracker'}
+for name, flags in (('one_launch', _capi.UIS_FLAG_RESIDENT), ('four_kernels_per_step', _capi.UIS_FLAG_STEPWISE)):
+  dec.stream_begin(n_utt, 10, n_push + 64 * 16, flags=flags)
+  for t in range(20):  # warm-up
+    dec.stream_push([s[t:t + 1] for s in seqs])
+  lat = []
+  for t in range(20, n_push):
+    chunks = [s[t:t + 1] for s in seqs]
+    t0 = time.perf_counter()
+    dec.stream_push(chunks)
+    lat.append(time.perf_counter() - t0)
+  chunk_lat = []
+  for k in range(48):
+    lo = n_push + 16 * k
+    chunks = [s[lo:lo + 16] for s in seqs]
+    t0 = time.perf_counter()
+    dec.stream_push(chunks)
+    chunk_lat.append(time.perf_counter() - t0)
+  labels, scores, _, _ = dec.stream_labels()
+  dec.stream_end()
+  lat, chunk_lat = np.array(lat) * 1e6, np.array(chunk_lat) * 1e6
+  out[name] = {'push_1_frame_us_median': round(float(np.median(lat)), 1),
+               'push_1_frame_us_p90': round(float(np.percentile(lat, 90)), 1),
+               'push_16_frames_us_median': round(float(np.median(chunk_lat)), 1),
+               'per_frame_step_in_16_chunk_us': round(float(np.median(chunk_lat)) / 16, 1),
+               'score0': float(scores[0])}
+assert out['one_launch']['score0'] == out['four_kernels_per_step']['score0']
+print(json.dumps(out))

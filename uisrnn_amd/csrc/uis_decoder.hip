@@ -68,6 +68,7 @@ struct DevBuf {
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
+#define UIS_STREAM_RESIDENT_MIN_STEPS 4  // uis_stream_push: steps per push from which the one-launch kernel is used
 #define UIS_H2D_CHUNKS 4     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection
 
 struct GraphCache {
@@ -109,6 +110,10 @@ struct uis_handle {
     int64_t* d_lab_off = nullptr;
     float* d_beam_scores = nullptr;
     int64_t steps_run = 0;
+    // one-launch steps (k_decode_resident per push) where the shape allows it
+    bool resident = false;
+    uint32_t* d_ctl = nullptr;
+    size_t ctl_words = 0;
   } stream_state;
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
@@ -1058,7 +1063,18 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   DecodeState& st = ss.st;
   st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = 1; st.tau = 1; st.flags = opts->flags;
   st.max_rows = U * B;
-  const long rows_cap = (long)U * B + 48;
+  // a push advances the session with ONE launch of the resident decode kernel where that kernel
+  // applies (same conditions as uis_decode); UIS_FLAG_STEPWISE keeps the four kernels per step
+  const int ncl = (h->n_cu >= 32 && h->n_cu % 32 == 0 && h->n_cu / 32 <= UIS_MAX_CLUSTERS) ? h->n_cu / 32 : 0;
+  const int nclq = std::max(ncl, 1);
+  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * B + 15) / 16 * 16);
+  const long rows_cap = std::max((long)U * B + 48, (long)nclq * rx_stride);
+  ss.resident = m.depth == 1 && (m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) &&
+                select_fast_ok(B, Kmax, S) && ncl >= 1 && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
+                ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
+                resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+  if ((opts->flags & UIS_FLAG_RESIDENT) && !ss.resident)
+    { ss = uis_handle::Stream{}; return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT: the one-launch decode does not apply to this session's shape"); }
   int rc = UIS_OK;
   int64_t* d_off = nullptr; double *d_logblk = nullptr, *d_logden = nullptr;
 #define SALLOC(ptr, count, zero) if ((rc = stream_alloc(h, &(ptr), (size_t)(count), zero))) { stream_free(h); return rc; }
@@ -1083,12 +1099,23 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   SALLOC(st.bp, (size_t)U * max_frames * B, false);
   SALLOC(st.rows, rows_cap, true);
   SALLOC(st.nrows, 2, true);
-  SALLOC(st.gi_up, m.depth > 1 ? (size_t)rows_cap * m.G : 16, false);
+  SALLOC(st.gi_up, m.depth > 1 ? (size_t)rows_cap * m.G : (size_t)rows_cap * m.Hp, false);  // depth 1: the resident kernel's h' staging
   SALLOC(st.a1, (size_t)rows_cap * m.Hp, true);
   SALLOC(st.counters, 96, true);
-  SALLOC(st.cl_abort, 16, true);
+  ss.ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
+  SALLOC(ss.d_ctl, ss.ctl_words, true);
+  st.cl_abort = ss.d_ctl + 16;
+  if (ss.resident) {
+    st.ncl = ncl;
+    st.cl_xcc = ss.d_ctl;
+    st.rx_stride = rx_stride;
+    st.rx_nrows = reinterpret_cast<int32_t*>(ss.d_ctl) + 32;
+    st.rx_bar = ss.d_ctl + 32 + UIS_MAX_CLUSTERS * 32;
+  }
   SALLOC(ss.d_beam_scores, (size_t)U * B, false);
 #undef SALLOC
+  if (ss.resident)  // the extra slot every GRU source row of a fresh cluster reads
+    HIPCHK(hipMemcpyAsync(st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, h->stream));
   std::vector<int64_t> off(U + 1);
   for (int u = 0; u <= U; ++u) off[u] = (int64_t)u * max_frames;  // capacity offsets: they address the back-pointers
   std::vector<double> logblk(max_frames + 2), logden(max_frames + 2);
@@ -1152,8 +1179,41 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   DecodeState st = ss.st;
   st.x = d_x; st.gi0 = ss.chunk_gi0.as<float>(); st.mse0 = ss.chunk_mse0.as<float>();
   const SelectLds lds = select_lds_layout(m.Dp, ss.B, ss.Kmax, ss.S);
-  if ((rc = enqueue_steps(h, lch, st, lds.total, (int)max_new))) return rc;
+  // measured (tools/stream_latency.py, profiles/): a one-step push is cheaper as four small
+  // launches (the one-launch kernel reloads its weights into registers / LDS every launch); from
+  // a few steps per push on the single launch wins.  UIS_FLAG_RESIDENT forces it.
+  bool stepwise = !ss.resident || h->resident_off ||
+                  (max_new < UIS_STREAM_RESIDENT_MIN_STEPS && !(ss.st.flags & UIS_FLAG_RESIDENT));
+  if (!stepwise) {
+    // every step of this push in ONE launch (the kernel runs max over utterances of
+    // avail - utt_step steps; utterances without new frames sit them out)
+    HIPCHK(hipMemsetAsync(ss.d_ctl, 0, ss.ctl_words * 4, h->stream));
+    const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Hp, m.Dp, ss.B, ss.Kmax, ss.S), 96 * 1024);
+    h->inlaunch_failed = false;
+#define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
+  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
+    rc = lch.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV>, h->n_cu, dim3(32 * st.ncl), dim3(512), shmem, \
+                             m, st);                                                                                 \
+  }
+    UIS_RESIDENT_CASE(512, 256)
+    UIS_RESIDENT_CASE(512, 512)
+    UIS_RESIDENT_CASE(512, 128)
+    UIS_RESIDENT_CASE(256, 256)
+    UIS_RESIDENT_CASE(256, 128)
+    UIS_RESIDENT_CASE(256, 512)
+#undef UIS_RESIDENT_CASE
+    if (rc && h->inlaunch_failed) { h->resident_off = true; stepwise = true; }  // refused before anything ran
+    else if (rc) return rc;
+  }
+  if (stepwise && (rc = enqueue_steps(h, lch, st, lds.total, (int)max_new))) return rc;
+  uint32_t abort_word = 0;
+  HIPCHK(hipMemcpyAsync(&abort_word, ss.d_ctl + 16, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));  // foff / avail / the caller's frames may be reused
+  if (abort_word)  // an in-launch barrier gave up mid-push: the session's state is not trustworthy any more
+    return fail(UIS_ERR_HIP, "in-launch barrier failed during uis_stream_push; close the session (uis_stream_end) and reopen it "
+                             "with UIS_FLAG_STEPWISE");
   for (int u = 0; u < U; ++u) ss.have[u] = avail[u];
   ss.steps_run += max_new;
   return UIS_OK;

@@ -1559,7 +1559,9 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     int myT = 0;
     for (int i = t; cluster + ncl * i < U; i += 512) {
       const int u = cluster + ncl * i;
-      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      // streaming (uis_stream_push): the steps this utterance can run now = frames received - steps done
+      const long T = st.avail ? (long)st.avail[u] - (long)st.utt_step[u]
+                              : (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
       myT = T > myT ? (int)T : myT;
     }
     if (myT > 0) atomicMax(&s_ctl[1], myT);
@@ -1598,7 +1600,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
-  const bool keep_beam = U <= 32 * ncl;
+  const bool keep_beam = U <= 32 * ncl && !st.avail;  // (a streaming session's beam must outlive the launch: global tables)
   const bool did_select = cluster + ncl * rank < U;  // keep_beam: this workgroup owns an utterance
   long my_off0 = 0, my_off1 = 0;
   if (keep_beam && cluster + ncl * rank < U) { my_off0 = (long)st.off[cluster + ncl * rank]; my_off1 = (long)st.off[cluster + ncl * rank + 1]; }
