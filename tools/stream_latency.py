@@ -19,12 +19,23 @@ for name, flags in (('one_launch', _capi.UIS_FLAG_RESIDENT), ('four_kernels_per_
   dec.stream_begin(n_utt, 10, n_push + 64 * 16, flags=flags)
   for t in range(20):  # warm-up
     dec.stream_push([s[t:t + 1] for s in seqs])
-  lat = []
+  lat, lat_c = [], []
+  import ctypes
+  ones = np.ones(n_utt, dtype=np.int32)
   for t in range(20, n_push):
     chunks = [s[t:t + 1] for s in seqs]
-    t0 = time.perf_counter()
-    dec.stream_push(chunks)
-    lat.append(time.perf_counter() - t0)
+    if t % 2:   # through the Python host (packs the chunks with numpy)
+      t0 = time.perf_counter()
+      dec.stream_push(chunks)
+      lat.append(time.perf_counter() - t0)
+    else:       # the C entry point alone, frames already packed
+      flat = np.ascontiguousarray(np.concatenate(chunks), dtype=np.float32)
+      t0 = time.perf_counter()
+      rc = dec._lib.uis_stream_push(dec._handle, flat.ctypes.data_as(_capi._fp),
+                                    ones.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+      lat_c.append(time.perf_counter() - t0)
+      assert rc == 0
+      dec._stream_have += ones
   chunk_lat = []
   for k in range(48):
     lo = n_push + 16 * k
@@ -34,8 +45,9 @@ for name, flags in (('one_launch', _capi.UIS_FLAG_RESIDENT), ('four_kernels_per_
     chunk_lat.append(time.perf_counter() - t0)
   labels, scores, _, _ = dec.stream_labels()
   dec.stream_end()
-  lat, chunk_lat = np.array(lat) * 1e6, np.array(chunk_lat) * 1e6
-  out[name] = {'push_1_frame_us_median': round(float(np.median(lat)), 1),
+  lat, chunk_lat, lat_c = np.array(lat) * 1e6, np.array(chunk_lat) * 1e6, np.array(lat_c) * 1e6
+  out[name] = {'push_1_frame_us_median_c_abi': round(float(np.median(lat_c)), 1),
+               'push_1_frame_us_median': round(float(np.median(lat)), 1),
                'push_1_frame_us_p90': round(float(np.percentile(lat, 90)), 1),
                'push_16_frames_us_median': round(float(np.median(chunk_lat)), 1),
                'per_frame_step_in_16_chunk_us': round(float(np.median(chunk_lat)) / 16, 1),

@@ -104,6 +104,10 @@ struct uis_handle {
     std::vector<int32_t> have;        // frames received per utterance
     std::vector<void*> allocs;
     DevBuf chunk_x, chunk_pad, chunk_gi0, chunk_mse0, labels, scores;
+    // one push = one H2D copy: [foff U x int64][avail U x int32, padded][frames] staged in pinned
+    // host memory (h_stage) and mirrored in chunk_x
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
     DecodeState st{};
     int32_t* d_avail = nullptr;
     int64_t* d_foff = nullptr;
@@ -828,6 +832,7 @@ static void stream_free_on_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->stream_state.chunk_x, &h->stream_state.chunk_pad, &h->stream_state.chunk_gi0,
                     &h->stream_state.chunk_mse0, &h->stream_state.labels, &h->stream_state.scores};
   for (DevBuf* b : bufs) b->release();
+  if (h->stream_state.h_stage) { (void)hipHostFree(h->stream_state.h_stage); h->stream_state.h_stage = nullptr; }
 }
 
 UIS_EXPORT void uis_destroy(uis_handle* h) {
@@ -1021,6 +1026,7 @@ void stream_free(uis_handle* h) {
   ss.allocs.clear();
   DevBuf* bufs[] = {&ss.chunk_x, &ss.chunk_pad, &ss.chunk_gi0, &ss.chunk_mse0, &ss.labels, &ss.scores};
   for (DevBuf* b : bufs) b->release();
+  if (ss.h_stage) { (void)hipHostFree(ss.h_stage); ss.h_stage = nullptr; ss.h_stage_cap = 0; }
   ss.active = false;
   ss.have.clear();
 }
@@ -1142,25 +1148,46 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   const DevModel& m = h->m;
   const int U = ss.U;
   int64_t F = 0, max_new = 0;
-  std::vector<int64_t> foff(U);
-  std::vector<int32_t> avail(U);
   for (int u = 0; u < U; ++u) {
     if (counts[u] < 0) return fail(UIS_ERR_INVALID_ARG, "negative frame count");
     if ((int64_t)ss.have[u] + counts[u] > ss.cap) return fail(UIS_ERR_INVALID_ARG, "utterance exceeds the session's max_frames");
-    foff[u] = F - ss.have[u];  // row of step s's frame in this chunk = foff + s
     F += counts[u];
     max_new = std::max<int64_t>(max_new, counts[u]);
-    avail[u] = ss.have[u] + counts[u];
   }
   if (F == 0) return UIS_OK;
   if (!frames) return fail(UIS_ERR_INVALID_ARG, "frames is null");
   HIPCHK(hipSetDevice(h->device));
   int rc;
-  if ((rc = ss.chunk_x.ensure((size_t)F * m.D * 4))) return rc;
+  // ---- one staging block, one H2D: [foff][avail][frames]
+  const size_t hdr = (size_t)U * 8 + (((size_t)U * 4 + 15) & ~(size_t)15);
+  const size_t need = hdr + (size_t)F * m.D * 4;
+  if (need > ss.h_stage_cap) {
+    if (ss.h_stage) { (void)hipHostFree(ss.h_stage); ss.h_stage = nullptr; ss.h_stage_cap = 0; }
+    const size_t want = need + need / 4 + 4096;
+    hipError_t e = hipHostMalloc(&ss.h_stage, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ss.h_stage = nullptr; return fail(UIS_ERR_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    ss.h_stage_cap = want;
+  }
+  if ((rc = ss.chunk_x.ensure(need))) return rc;
   if ((rc = ss.chunk_gi0.ensure((size_t)F * m.G * 4))) return rc;
   if ((rc = ss.chunk_mse0.ensure((size_t)F * 4))) return rc;
-  HIPCHK(hipMemcpyAsync(ss.chunk_x.p, frames, (size_t)F * m.D * 4, hipMemcpyHostToDevice, h->stream));
-  const float* d_x = ss.chunk_x.as<float>();
+  int64_t* h_foff = static_cast<int64_t*>(ss.h_stage);
+  int32_t* h_avail = reinterpret_cast<int32_t*>(static_cast<char*>(ss.h_stage) + (size_t)U * 8);
+  {
+    int64_t pos = 0;
+    for (int u = 0; u < U; ++u) {
+      h_foff[u] = pos - ss.have[u];  // row of step s's frame in this chunk = foff + s
+      pos += counts[u];
+      h_avail[u] = ss.have[u] + counts[u];
+    }
+  }
+  memcpy(static_cast<char*>(ss.h_stage) + hdr, frames, (size_t)F * m.D * 4);
+  HIPCHK(hipMemcpyAsync(ss.chunk_x.p, ss.h_stage, need, hipMemcpyHostToDevice, h->stream));
+  ss.d_foff = ss.chunk_x.as<int64_t>();
+  ss.d_avail = reinterpret_cast<int32_t*>(ss.chunk_x.as<char>() + (size_t)U * 8);
+  ss.st.foff = ss.d_foff;
+  ss.st.avail = ss.d_avail;
+  const float* d_x = reinterpret_cast<const float*>(ss.chunk_x.as<char>() + hdr);
   if (m.D != m.Dp) {
     if ((rc = ss.chunk_pad.ensure((size_t)F * m.Dp * 4))) return rc;
     const long total = (long)F * m.Dp;
@@ -1173,8 +1200,6 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
   LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
          ss.chunk_mse0.as<float>(), (long)F);
-  HIPCHK(hipMemcpyAsync(ss.d_foff, foff.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(ss.d_avail, avail.data(), (size_t)U * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
   DecodeState st = ss.st;
   st.x = d_x; st.gi0 = ss.chunk_gi0.as<float>(); st.mse0 = ss.chunk_mse0.as<float>();
@@ -1184,6 +1209,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   // a few steps per push on the single launch wins.  UIS_FLAG_RESIDENT forces it.
   bool stepwise = !ss.resident || h->resident_off ||
                   (max_new < UIS_STREAM_RESIDENT_MIN_STEPS && !(ss.st.flags & UIS_FLAG_RESIDENT));
+  bool ran_resident = false;
   if (!stepwise) {
     // every step of this push in ONE launch (the kernel runs max over utterances of
     // avail - utt_step steps; utterances without new frames sit them out)
@@ -1206,15 +1232,16 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
 #undef UIS_RESIDENT_CASE
     if (rc && h->inlaunch_failed) { h->resident_off = true; stepwise = true; }  // refused before anything ran
     else if (rc) return rc;
+    else ran_resident = true;
   }
   if (stepwise && (rc = enqueue_steps(h, lch, st, lds.total, (int)max_new))) return rc;
   uint32_t abort_word = 0;
-  HIPCHK(hipMemcpyAsync(&abort_word, ss.d_ctl + 16, 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));  // foff / avail / the caller's frames may be reused
+  if (ran_resident) HIPCHK(hipMemcpyAsync(&abort_word, ss.d_ctl + 16, 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));  // the staging block and the caller's frames may be reused
   if (abort_word)  // an in-launch barrier gave up mid-push: the session's state is not trustworthy any more
     return fail(UIS_ERR_HIP, "in-launch barrier failed during uis_stream_push; close the session (uis_stream_end) and reopen it "
                              "with UIS_FLAG_STEPWISE");
-  for (int u = 0; u < U; ++u) ss.have[u] = avail[u];
+  for (int u = 0; u < U; ++u) ss.have[u] += counts[u];
   ss.steps_run += max_new;
   return UIS_OK;
 }
