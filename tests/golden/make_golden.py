@@ -5,6 +5,7 @@ writes are committed and travel to the GPU box, the reference does not.
 
   python tests/golden/make_golden.py            # all cases
   python tests/golden/make_golden.py tiny_d16   # one case
+  python tests/golden/make_golden.py --probes   # probes.json: the reference at the edges (nan frames, quirk 7)
 
 What is recorded per case (an .npz):
   * the model parameters (small models) or the seed that regenerates them
@@ -316,12 +317,52 @@ def write_reference_checkpoint(uisrnn):
   print('wrote', path, os.path.getsize(path), 'bytes')
 
 
+def write_probes(uisrnn):
+  """probes.json: what the REFERENCE does at the edges the decoder documents as deviations or
+  quirks -- non-finite frames (which exception, depending on where the beam empties:
+  uisrnn/uisrnn.py:531 `max()` of an empty beam vs :561 `beam_set[0]`) and a frame whose first
+  component equals m0[0] (loss_func.py:36,41: the fresh-cluster candidate becomes inf)."""
+  import json  # pylint: disable=import-outside-toplevel
+  from oracle import oracle  # pylint: disable=import-outside-toplevel
+  params = CASES['tiny_d16'](uisrnn)[0]
+  seqs = CASES['tiny_d16'](uisrnn)[1]
+  model, inference_args = reference_model(uisrnn, params)
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 5, 1, 1
+  seq = seqs[0]
+  m0, _ = oracle.constants(params)
+
+  def run(x):
+    try:
+      return {'labels': [int(v) for v in model.predict(x, inference_args)]}
+    except Exception as exc:  # pylint: disable=broad-except
+      return {'raises': type(exc).__name__, 'message': str(exc)}
+
+  out = {'case': 'tiny_d16 utterance 0, beam 5, look_ahead 1, test_iteration 1', 'n_frames': len(seq)}
+  bad = seq.copy(); bad[3, 2] = np.nan
+  out['nan_mid_frame'] = run(bad)
+  bad = seq.copy(); bad[len(seq) - 1, 2] = np.nan
+  out['nan_last_frame'] = run(bad)
+  bad = seq.copy(); bad[0, 0] = np.inf
+  out['inf_first_frame'] = run(bad)
+  q = seq.copy(); q[0, 0] = np.float64(m0[0])
+  out['first_component_equals_m0_frame0'] = run(q)
+  q = seq.copy(); q[4, 0] = np.float64(m0[0])
+  out['first_component_equals_m0_frame4'] = run(q)
+  out['clean'] = run(seq)
+  with open(os.path.join(HERE, 'probes.json'), 'w') as f:
+    json.dump(out, f, indent=1)
+  print(json.dumps(out, indent=1))
+
+
 def main():
   uisrnn = import_reference()
   import torch  # pylint: disable=import-outside-toplevel
   torch.set_num_threads(1)
   if sys.argv[1:] == ['--checkpoint']:
     write_reference_checkpoint(uisrnn)
+    return
+  if sys.argv[1:] == ['--probes']:
+    write_probes(uisrnn)
     return
   names = sys.argv[1:] or list(CASES)
   for name in names:

@@ -163,3 +163,41 @@ def test_trained_toy4_accuracy_is_one(oracle_lib):
   out = oracle_lib.decode(case['params'], case['seqs'], *case['cfg'])
   acc = evals.compute_sequence_match_accuracy(out['labels'][0].tolist(), case['truth'].tolist())
   assert acc == 1.0
+
+
+def test_reference_probes_at_the_edges(oracle_lib):
+  """tests/golden/probes.json (make_golden.py --probes): what the reference does on a frame whose
+  first component equals m0[0] (loss_func.py:36,41 -> the fresh-cluster candidate is inf) and on
+  non-finite frames.  The oracle reproduces the finite cases exactly; where the reference's beam
+  empties it raises (ValueError or IndexError, depending on the step) and the oracle returns -1
+  labels, which the Python host turns into EmptyBeamError (both exception types)."""
+  import json
+  import os
+  import uisrnn_amd
+  with open(os.path.join(golden_util.GOLDEN_DIR, 'probes.json')) as f:
+    probes = json.load(f)
+  case = golden_util.load_case('tiny_d16')
+  params, seq = case['params'], case['seqs'][0]
+  m0, _ = oracle_lib.constants(params)
+
+  def oracle_labels(x):
+    return oracle_lib.decode(params, [x], 5, 1, 1)['labels'][0].tolist()
+
+  assert oracle_labels(seq) == probes['clean']['labels']
+  q = seq.copy(); q[4, 0] = np.float64(m0[0])
+  assert oracle_labels(q) == probes['first_component_equals_m0_frame4']['labels']
+  q = seq.copy(); q[0, 0] = np.float64(m0[0])
+  assert probes['first_component_equals_m0_frame0']['raises'] == 'ValueError'
+  assert set(oracle_labels(q)) == {-1}
+  bad = seq.copy(); bad[3, 2] = np.nan
+  assert probes['nan_mid_frame']['raises'] == 'ValueError'
+  assert set(oracle_labels(bad)) == {-1}
+  bad = seq.copy(); bad[0, 0] = np.inf
+  assert probes['inf_first_frame']['raises'] == 'IndexError'
+  assert set(oracle_labels(bad)) == {-1}
+  assert issubclass(uisrnn_amd.EmptyBeamError, ValueError)
+  assert issubclass(uisrnn_amd.EmptyBeamError, IndexError)
+  # documented deviation: with NaN in the LAST frame the reference keeps NaN-scored hypotheses
+  # (numpy sorts NaN behind inf, trim_zeros does not drop it) and returns labels; here the
+  # beam is empty
+  assert 'labels' in probes['nan_last_frame']

@@ -15,3 +15,4 @@ output_result = utils.output_result
 UISRNN = _uisrnn.UISRNN
 parallel_predict = _uisrnn.parallel_predict
 OnlineSession = _uisrnn.OnlineSession  # extension: streaming decode
+EmptyBeamError = _uisrnn.EmptyBeamError

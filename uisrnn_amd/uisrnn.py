@@ -38,6 +38,19 @@ def _initial_cluster_cap(args):
 _MAX_CLUSTERS_LIMIT = 1024
 
 
+class EmptyBeamError(ValueError, IndexError):
+  """Every candidate of some decode step was non-finite: no hypothesis survived.
+
+  The reference fails in the same situation, with an exception that depends on WHERE the beam
+  empties: `ValueError: max() arg is an empty sequence` at the next step's
+  uisrnn/uisrnn.py:531 if frames remain, `IndexError: list index out of range` at
+  uisrnn/uisrnn.py:561 after the last one (recorded in tests/golden/probes.json).  This class
+  is both, so a caller's handler for either keeps working.  (With a NaN -- not inf -- score the
+  reference can instead keep NaN-scored hypotheses, numpy sorts NaN behind inf; that is not
+  reproduced: non-finite candidates are never selected here)
+  """
+
+
 class UISRNN:
   """Unbounded Interleaved-State RNN -- MI355X decode."""
 
@@ -194,8 +207,9 @@ class UISRNN:
             # every candidate of some step was non-finite (nan/inf in the input or the
             # weights): the reference ends up indexing an empty beam_set
             # (uisrnn/uisrnn.py:561) and raises the same exception type
-            raise IndexError('list index out of range (the beam became empty: '
-                             'non-finite scores in utterance {})'.format(u))
+            raise EmptyBeamError('the beam became empty (max() arg is an empty sequence / list '
+                                 'index out of range in the reference): non-finite scores in '
+                                 'utterance {}'.format(u))
           results[u] = labels.tolist()
       pending = still
       if pending:
