@@ -868,7 +868,10 @@ struct RowSink {
 // KEEP (resident decode, one utterance per workgroup): the beam tables and the per-slot frame
 // counts stay in LDS from one step to the next -- a step reads table set `par` and writes set
 // `par ^ 1` -- so the only global state a select reads back is the cluster means; the caller
-// passes the step number and the utterance's frame range.
+// passes the step number and the utterance's frame range.  In a streaming session (st.avail) the
+// step number is the utterance's own (the launch starts at first_step_in, where the tables and
+// the per-slot frame counts are fetched from the global copies the previous push left), `par` its
+// parity, and the resident decode writes the tables back when the launch ends.
 // DPT: the padded observation_dim when the caller knows it at compile time (0 = read m.Dp).
 // PARTS (bit mask, KEEP only; 7 = everything): 1 and 4 = the two halves of the PREPARATION of a
 // step -- live slots and the candidate table, then the list of live slots: all of it depends on
@@ -880,7 +883,8 @@ struct SelectNoHook { __device__ __forceinline__ void operator()() const {} };
 template <int NT, bool RES, bool KEEP, int DPT = 0, int PARTS = 7, typename Pub = SelectNoHook>
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
                                                  unsigned char* smem_raw, RowSink sink, int step_in = 0,
-                                                 long off0_in = 0, long off1_in = 0, Pub published = Pub()) {
+                                                 long off0_in = 0, long off1_in = 0, Pub published = Pub(),
+                                                 int first_step_in = 0) {
   static_assert(PARTS == 7 || KEEP, "the split needs the beam in LDS");
   int tid_ = threadIdx.x;
   // inside the resident decode's step loop: keep the compiler from hoisting every tid-derived
@@ -893,7 +897,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   unsigned long long t_prev_ = wall_clock64();
 #endif
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
-  // streaming (never KEEP): the parity of an utterance's tables is its own step's
+  // streaming: the parity of an utterance's tables is its own step's (KEEP: the caller passes it)
   const int tpar = (!KEEP && st.avail) ? (st.utt_step[u] & 1) : par;
   const int nxt = tpar ^ 1;
   const FastLds L = fast_lds_layout(m.Dp, B, Kmax, S);
@@ -931,7 +935,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   // as load-then-store pairs the compiler waits for each load before it issues the next).
   // B * Kmax < 256 <= NT (select_fast_ok): one table entry per thread.
   // KEEP, after the first step: nothing to fetch -- the tables are in LDS set `par`.
-  const bool fresh = !KEEP || step_in == 0;
+  const bool fresh = !KEEP || step_in == first_step_in;
   int step = step_in, nb = 0, myK = 0;
   long off0 = off0_in, off1 = off1_in;
   const bool has_e = tid < B * Kmax, has_b = tid < B;
@@ -955,7 +959,8 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
       if (has_e) { sslot[tid] = r_slot; sblk[tid] = r_blk; }
       if (has_b) { sK[tid] = myK; slast[tid] = r_last; ssum[tid] = r_sum; sscore[tid] = r_score; }
       if (KEEP) {
-        for (int sl = tid; sl < S; sl += NT) spcnt[sl] = 0;
+        // frames per slot: none yet at the start of a decode; a streaming session continues
+        for (int sl = tid; sl < S; sl += NT) spcnt[sl] = st.avail ? st.pool_cnt[(size_t)u * S + sl] : 0;
         if (tid == 0) *reinterpret_cast<int*>(set_cur + L.off_nb) = nb;
       }
     } else {
@@ -968,9 +973,9 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     nb = *reinterpret_cast<const int*>(set_cur + L.off_nb);
   }
   const long N = off1 - off0;
-  const long T = (!KEEP && st.avail) ? (long)st.avail[u] : (long)st.tau * N;
+  const long T = st.avail ? (long)st.avail[u] : (long)st.tau * N;
   if (step >= T) return;
-  const long frame = (!KEEP && st.foff) ? (long)st.foff[u] + step : off0 + (step % N);
+  const long frame = st.foff ? (long)st.foff[u] + step : off0 + (step % N);
   if (PARTS & 1) {
     // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
     if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
@@ -1600,10 +1605,17 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
   RowSink sink{st.rows + rbase, nullptr};
   uint32_t bar = 0;
-  const bool keep_beam = U <= 32 * ncl && !st.avail;  // (a streaming session's beam must outlive the launch: global tables)
+  const bool keep_beam = U <= 32 * ncl;
   const bool did_select = cluster + ncl * rank < U;  // keep_beam: this workgroup owns an utterance
   long my_off0 = 0, my_off1 = 0;
-  if (keep_beam && cluster + ncl * rank < U) { my_off0 = (long)st.off[cluster + ncl * rank]; my_off1 = (long)st.off[cluster + ncl * rank + 1]; }
+  // a streaming session (st.avail): the utterance continues at its own step count; the beam
+  // tables are fetched from their global copies at the first step and written back at the end
+  int my_step0 = 0;
+  if (keep_beam && did_select) {
+    my_off0 = (long)st.off[cluster + ncl * rank];
+    my_off1 = (long)st.off[cluster + ncl * rank + 1];
+    if (st.avail) my_step0 = st.utt_step[cluster + ncl * rank];
+  }
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rt_prev = wall_clock64();
@@ -1634,14 +1646,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       pa[0] += c1 - c0; pa[1] += c2 - c1; pa[2] += c3 - c2; pa[3] += c4 - c3;
     }
 #endif
+    const int ustep = my_step0 + s, upar = ustep & 1;  // the utterance's own step and table parity
     if (keep_beam) {  // at most one utterance per workgroup: its beam lives in LDS
       if (did_select) {
         if (s == 0) {  // (later steps: prepared while waiting for the previous step's last barrier)
-          select_fast_body<512, true, true, DP, 5>(m, st, par, cluster + ncl * rank, smem_raw, sink, s, my_off0, my_off1);
+          select_fast_body<512, true, true, DP, 5>(m, st, upar, cluster + ncl * rank, smem_raw, sink, ustep, my_off0, my_off1,
+                                                   SelectNoHook(), my_step0);
           __syncthreads();
         }
-        select_fast_body<512, true, true, DP, 2>(m, st, par, cluster + ncl * rank, smem_raw, sink, s, my_off0, my_off1,
-                                                 [&]() { xcd_arrive_wave0(st, cluster, s_ctl); });
+        select_fast_body<512, true, true, DP, 2>(m, st, upar, cluster + ncl * rank, smem_raw, sink, ustep, my_off0, my_off1,
+                                                 [&]() { xcd_arrive_wave0(st, cluster, s_ctl); }, my_step0);
       }
       __syncthreads();
     } else {
@@ -1735,7 +1749,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       // arrive, do the first half of the next step's select preparation (this workgroup's own LDS
       // tables: nobody else's data), then wait
       xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 1>(m, st, par ^ 1, cluster + ncl * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+      select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                               SelectNoHook(), my_step0);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(3);
@@ -1765,7 +1780,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(4);
     if (prep_next) {  // ... and the second half inside the next barrier
       xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 4>(m, st, par ^ 1, cluster + ncl * rank, smem_raw, sink, s + 1, my_off0, my_off1);
+      select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                               SelectNoHook(), my_step0);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
@@ -1821,6 +1837,32 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(6);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
+  }
+  if (st.avail && keep_beam && did_select) {
+    // streaming: the session outlives this launch -- the beam tables (the set the NEXT step reads)
+    // and the per-slot frame counts go back to their global copies; beam_n / beam_score / the
+    // back-pointers were written step by step
+    const int u = cluster + ncl * rank;
+    long done = (long)st.avail[u] - my_step0;
+    done = done < 0 ? 0 : (done > nsteps ? nsteps : done);
+    if (done > 0) {
+      const int B = st.B, Kmax = st.Kmax;
+      const int cur = (my_step0 + (int)done) & 1;
+      const unsigned char* set = smem_raw + cur * L.set_stride;
+      const size_t bb = ((size_t)cur * U + u) * B;
+      for (int e = t; e < B * Kmax; e += 512) {
+        st.beam_slot[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_slot)[e];
+        st.beam_blk[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_blk)[e];
+      }
+      for (int b2 = t; b2 < B; b2 += 512) {
+        st.beam_K[bb + b2] = reinterpret_cast<const int*>(set + L.off_K)[b2];
+        st.beam_last[bb + b2] = reinterpret_cast<const int*>(set + L.off_last)[b2];
+        st.beam_sum[bb + b2] = reinterpret_cast<const int*>(set + L.off_sum)[b2];
+      }
+      const int* spc = reinterpret_cast<const int*>(smem_raw + L.off_pcnt);
+      for (int sl = t; sl < S; sl += 512) st.pool_cnt[(size_t)u * S + sl] = spc[sl];
+      if (t == 0) st.utt_step[u] = my_step0 + (int)done;
+    }
   }
 #if defined(UIS_RESIDENT_PROBE)
   if (t == 0 && blockIdx.x == 0)
