@@ -116,6 +116,7 @@ struct uis_handle {
     int64_t steps_run = 0;
     // one-launch steps (k_decode_resident per push) where the shape allows it
     bool resident = false;
+    bool coop_checked = false;        // one push of this session already went through the cooperative launch
     uint32_t* d_ctl = nullptr;
     size_t ctl_words = 0;
   } stream_state;
@@ -224,8 +225,11 @@ struct Launcher {
   // resident at once.  hipLaunchCooperativeKernel guarantees that (or refuses the launch); the
   // occupancy query is checked as well so that the refusal has a readable reason.  With
   // `profile`, events recorded around the launch on the same (otherwise idle) stream.
+  // `cooperative` = false: a plain launch of the same grid after the occupancy check (same
+  // residency, 15-19 us less host time per launch: MI355X_MICROARCH.md "coop-launch"); used by the
+  // streaming pushes after the session's first push went through the cooperative path.
   int run_cooperative(int cls, void (*kernel)(DevModel, DecodeState), int n_cu, dim3 grid, dim3 block, size_t shmem,
-                      DevModel m, DecodeState st) {
+                      DevModel m, DecodeState st, bool cooperative = true) {
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), (int)block.x, shmem));
     if ((long)per_cu * n_cu < (long)grid.x) {
@@ -240,7 +244,13 @@ struct Launcher {
       HIPCHK(hipEventRecord(a, stream));
     }
     void* argv[2] = {&m, &st};
-    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, (unsigned)shmem, stream);
+    hipError_t e;
+    if (cooperative) {
+      e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, (unsigned)shmem, stream);
+    } else {
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, m, st);
+      e = hipGetLastError();
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       h->inlaunch_failed = true;  // the caller falls back to the launch-per-step path
@@ -1197,18 +1207,27 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
     d_x = ss.chunk_pad.as<float>();
   }
   Launcher lch{h, h->stream, false};
-  LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
-  LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-         ss.chunk_mse0.as<float>(), (long)F);
-  HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
   DecodeState st = ss.st;
   st.x = d_x; st.gi0 = ss.chunk_gi0.as<float>(); st.mse0 = ss.chunk_mse0.as<float>();
   const SelectLds lds = select_lds_layout(m.Dp, ss.B, ss.Kmax, ss.S);
-  // measured (tools/stream_latency.py, profiles/): a one-step push is cheaper as four small
-  // launches (the one-launch kernel reloads its weights into registers / LDS every launch); from
-  // a few steps per push on the single launch wins.  UIS_FLAG_RESIDENT forces it.
+  // One-launch path: the chunk's projection fused into the kernel and plain launches after the
+  // session's first push make a push one H2D, one memset and ONE kernel.  Measured
+  // (tools/stream_latency.py, profiles/): that kernel re-reads its weights into registers / LDS at
+  // every launch (~10 us), so for 1-3 steps per push the four small kernels per step are still
+  // quicker (79 vs 96 us for one frame of 64 utterances); from 4 steps on the single launch wins
+  // (16 frames: 690 vs 880 us).  UIS_FLAG_RESIDENT forces it, UIS_FLAG_STEPWISE forbids it.
   bool stepwise = !ss.resident || h->resident_off ||
                   (max_new < UIS_STREAM_RESIDENT_MIN_STEPS && !(ss.st.flags & UIS_FLAG_RESIDENT));
+  // the chunk's gi0 / mse0: inside the one-launch kernel when the frames need no padding and the
+  // chunk's rows fit the kernel's LDS list, else by the two once-per-chunk kernels
+  const bool fused = !stepwise && m.D == m.Dp && F <= (int64_t)UIS_RES_HEAD_TILES * 16 * 6;
+  if (!fused) {
+    LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
+    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
+           ss.chunk_mse0.as<float>(), (long)F);
+  }
+  HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
+  st.push_F = fused ? (int)F : 0;
   bool ran_resident = false;
   if (!stepwise) {
     // every step of this push in ONE launch (the kernel runs max over utterances of
@@ -1221,7 +1240,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
     rc = lch.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV>, h->n_cu, dim3(32 * st.ncl), dim3(512), shmem, \
-                             m, st);                                                                                 \
+                             m, st, !ss.coop_checked);                                                               \
   }
     UIS_RESIDENT_CASE(512, 256)
     UIS_RESIDENT_CASE(512, 512)
@@ -1230,9 +1249,16 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
     UIS_RESIDENT_CASE(256, 128)
     UIS_RESIDENT_CASE(256, 512)
 #undef UIS_RESIDENT_CASE
-    if (rc && h->inlaunch_failed) { h->resident_off = true; stepwise = true; }  // refused before anything ran
-    else if (rc) return rc;
-    else ran_resident = true;
+    if (rc && h->inlaunch_failed) {  // refused before anything ran: the per-step kernels take over
+      h->resident_off = true; stepwise = true;
+      if (fused) {  // ... and they need the chunk's gi0 / mse0
+        LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
+        LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
+               ss.chunk_mse0.as<float>(), (long)F);
+        st.push_F = 0;
+      }
+    } else if (rc) return rc;
+    else { ran_resident = true; ss.coop_checked = true; }
   }
   if (stepwise && (rc = enqueue_steps(h, lch, st, lds.total, (int)max_new))) return rc;
   uint32_t abort_word = 0;

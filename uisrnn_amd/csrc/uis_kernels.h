@@ -103,6 +103,10 @@ struct DecodeState {
   const int32_t* avail;
   const int64_t* foff;
   const int64_t* lab_off;
+  // streaming push with the chunk's once-per-frame work fused into k_decode_resident: push_F > 0 =
+  // the chunk holds push_F frames whose gi0 / mse0 the kernel computes itself (each cluster for
+  // its own utterances' frames) before its first step, instead of two extra launches
+  int push_F;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

@@ -1616,6 +1616,47 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     my_off1 = (long)st.off[cluster + ncl * rank + 1];
     if (st.avail) my_step0 = st.utt_step[cluster + ncl * rank];
   }
+  if (st.push_F > 0) {
+    // ---- streaming push: the chunk's once-per-frame work, by this cluster for its own utterances'
+    // new frames -- gi0 = W_ih0 x + b_ih0 (k_dense_input_proj's fullk_tile per 16 rows x 16
+    // features, one wave each) and mse0 (k_mse0's wave_weighted_mse, one wave per frame); same
+    // arithmetic, same order.  The chunk rows are listed in LDS first (the descriptor area is
+    // not in use yet).
+    int* s_prow = reinterpret_cast<int*>(s_head);
+    const int prow_cap = UIS_RES_HEAD_TILES * 16 * 6;
+    if (t == 0) {
+      int n = 0;
+      for (int u = cluster; u < U; u += ncl) {
+        const int s0 = st.utt_step[u], a = st.avail[u];
+        const long f0 = (long)st.foff[u];
+        for (int k = s0; k < a && n < prow_cap; ++k) s_prow[n++] = (int)(f0 + k);
+      }
+      s_ctl[3] = n;
+    }
+    __syncthreads();
+    const int R = s_ctl[3];
+    if (R > 0) {
+      const int NGT = m.G / 16;
+      const int prt = (R + 15) >> 4;
+      float* gi0w = const_cast<float*>(st.gi0);
+      float* mse0w = const_cast<float*>(st.mse0);
+      for (int task = rank * 8 + w; task < prt * NGT; task += 256) {
+        const int rt = task / NGT, ft = task - rt * NGT;
+        int li = rt * 16 + (lane & 15);
+        const bool valid = li < R;
+        if (!valid) li = R - 1;
+        const size_t row = (size_t)s_prow[li];
+        const f32x4 v = fullk_tile(m.wih[0], ft, m.Dp / 16, st.x + row * m.Dp, m.bih[0] + ft * 16);
+        if (valid) *reinterpret_cast<f32x4*>(gi0w + row * m.G + ft * 16 + (lane >> 4) * 4) = v;
+      }
+      for (int i = rank * 8 + w; i < R; i += 256) {
+        const size_t row = (size_t)s_prow[i];
+        const float v = wave_weighted_mse(m.m0, st.x + row * m.Dp, m.wgt, m.Dp, m.D, lane);
+        if (lane == 0) mse0w[row] = v;
+      }
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+  }
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rt_prev = wall_clock64();
