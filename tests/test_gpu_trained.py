@@ -91,3 +91,37 @@ def test_trained_d256_against_reference_and_oracle(name, oracle_lib):
     same = [u for u in range(len(case['seqs']))
             if np.array_equal(ref['labels'][u], case['labels'][u])]
     np.testing.assert_allclose(out['scores'][same], case['best'][same], rtol=1e-4)
+
+
+def test_config_shapes_with_trained_models_against_the_oracle(oracle_lib):
+  """BASELINE configs[4] (D=512, H=512, beam 20; the model the reference trained at D=512) and
+  configs[2] (beam 50, look_ahead 2; the D=256 model) at sizes well beyond a handful of
+  utterances: HIP vs oracle element-wise and bit-exact, and the labels are a sane diarization."""
+  from uisrnn_amd import evals, synth, weights
+  # configs[4]: 16 utterances x 150 frames, beam 20, cluster cap 11 (= the one-launch decode's limit)
+  p512 = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d512.uisrnn'))
+  seqs, truth = synth.make_utterances(40_000, 16, 150, 512)
+  ref = oracle_lib.decode(p512, seqs, 20, 1, 2, n_threads=16)
+  assert int(ref['max_clusters'].max()) <= 11
+  dec = _capi.Decoder(p512)
+  frames, offsets = oracle_lib.pack(seqs)
+  for flags in (_capi.UIS_FLAG_RESIDENT, _capi.UIS_FLAG_STEPWISE):
+    out = dec.decode(frames, offsets, 20, 1, 2, max_clusters=11, flags=flags, want_beam_scores=True)
+    assert out['status'] == 0
+    for u in range(len(seqs)):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u])
+    assert np.array_equal(out['beam_scores'].view(np.uint32), ref['beam_scores'].view(np.uint32))
+  acc = [evals.compute_sequence_match_accuracy(ref['labels'][u].tolist(), truth[u].tolist()) for u in range(len(seqs))]
+  assert np.mean(acc) > 0.97
+  # configs[2]: 12 utterances x 80 frames, beam 50, look_ahead 2
+  p256 = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d256.uisrnn'))
+  seqs, truth = synth.make_utterances(41_000, 12, 80, 256)
+  ref = oracle_lib.decode(p256, seqs, 50, 2, 2, n_threads=12)
+  cap = int(ref['max_clusters'].max()) + 1
+  dec = _capi.Decoder(p256)
+  frames, offsets = oracle_lib.pack(seqs)
+  out = dec.decode(frames, offsets, 50, 2, 2, max_clusters=max(cap, 12), want_beam_scores=True)
+  assert out['status'] == 0
+  for u in range(len(seqs)):
+    assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u])
+  assert np.array_equal(out['beam_scores'].view(np.uint32), ref['beam_scores'].view(np.uint32))
