@@ -15,6 +15,8 @@ done
 timeout 600 python bench.py --gpus 1 --force_dist --no_cpu_baseline --no_host_buffers \
   > gpurun_out/r02_force_dist.json 2> gpurun_out/r02_force_dist.err
 echo "rc=$?" >> gpurun_out/r02_force_dist.err
+# the closed-form model of round 1 on this round's build, for continuity
+timeout 600 python bench.py --model tracker --no_cpu_baseline --no_host_buffers > gpurun_out/r02_bench_c1_tracker.json 2>/dev/null
 # the launch-per-step path, for comparison
 timeout 600 python bench.py --flags 128 --no_cpu_baseline --no_host_buffers > gpurun_out/r02_bench_c1_stepwise.json 2>/dev/null
 # kernel trace of the SAME default command
