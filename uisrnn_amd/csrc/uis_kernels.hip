@@ -2153,19 +2153,34 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   } else {
     const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
     keep = nfin < B ? nfin : B;
-    if (tid == 0) key[C] = ~0ull;  // pad to an even count for the paired reads below
-    __syncthreads();
-    const int C2 = (C + 1) & ~1;
-    for (int i = tid; i < C; i += 256) {
-      const unsigned long long k = key[i];
-      if (k == ~0ull) continue;
-      int rank = 0;  // no early exit: the reads are independent and pipeline
-#pragma unroll 8
-      for (int j2 = 0; j2 < C2; j2 += 2) {
-        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(key + j2);
-        rank += (kk.x < k) + (kk.y < k);
+    if (keep > 0) {
+      // The `keep` smallest keys, in order.  Keys are unique (score bits, candidate index), so
+      // the keep-th smallest one, K*, is the largest T with #{key < T} <= keep - 1: found bit by
+      // bit from the top, one workgroup-wide count per bit (64 counts over C keys instead of
+      // the C^2 / 2 comparisons of ranking every candidate against every other).
+      unsigned long long kstar = 0ull;
+      for (int bit = 63; bit >= 0; --bit) {
+        const unsigned long long t2 = kstar | (1ull << bit);
+        int c = 0;
+        for (int i = tid; i < C; i += 256) c += key[i] < t2 ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((tid & 63) == 0) lds4[tid >> 6] = c;
+        __syncthreads();
+        const int total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        if (total <= keep - 1) kstar = t2;
+        __syncthreads();
       }
-      if (rank < keep) winv[rank] = i;
+      // the winners (key <= K*) in candidate order, then each one's rank among them
+      int* wl = ordv;  // (free until the leader bookkeeping below)
+      block_scan(C, [&](int i) { return key[i] <= kstar ? 1 : 0; },
+                 [&](int i, int pre) { if (key[i] <= kstar) wl[pre] = i; }, lds4);
+      for (int a = tid; a < keep; a += 256) {
+        const unsigned long long ka = key[wl[a]];
+        int rank = 0;
+        for (int b2 = 0; b2 < keep; ++b2) rank += key[wl[b2]] < ka ? 1 : 0;
+        winv[rank] = wl[a];
+      }
     }
   }
   __syncthreads();
