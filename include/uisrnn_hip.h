@@ -103,6 +103,9 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */
+#define UIS_FLAG_SMALL_TILES 0x200u /* launch-per-step path: keep the split-K dense kernels even where
+                                    the big-tile ones (thousands of rnn rows per step) apply; A/B
+                                    switch, results are bit-identical either way                */
 #define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
                                     a wrong XCD, as if the (observed, not promised) workgroup
                                     placement had changed.  The call must then fall back to the

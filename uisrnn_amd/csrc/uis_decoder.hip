@@ -272,6 +272,17 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
   const DevModel& m = h->m;
   const int mr = (int)max_rows;
   const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
+  // thousands of rows: the big-tile kernels (4 row tiles x several feature tiles per workgroup,
+  // full-K chains per wave) where the feature-tile counts divide
+  if (wide && (m.Hp / 16) % 4 == 0 && (m.Dp / 16) % 4 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES)) {
+    for (int l = 0; l < m.depth; ++l) {
+      if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
+      LAUNCH(UIS_K_GRU, k_big_gru<2>, dim3(big_grid_blocks(mr, m.Hp / 16, 2)), dim3(256), 0, m, st, par, l);
+    }
+    LAUNCH(UIS_K_HEAD1, k_big_head1<4>, dim3(big_grid_blocks(mr, m.Hp / 16, 4)), dim3(256), 0, m, st, par);
+    LAUNCH(UIS_K_HEAD2, k_big_head2<4>, dim3(big_grid_blocks(mr, m.Dp / 16, 4)), dim3(256), 0, m, st, par);
+    return UIS_OK;
+  }
   for (int l = 0; l < m.depth; ++l) {
     if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
     if (wide) LAUNCH(UIS_K_GRU, k_dense_gru<2>, dim3(step_grid_blocks(mr, m.Hp / 16, 2, 1)), dim3(512), 0, m, st, par, l);

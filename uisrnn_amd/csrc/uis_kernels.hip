@@ -404,6 +404,182 @@ __global__ __launch_bounds__(512) void k_dense_head2(DevModel m, DecodeState st,
   }
 }
 
+// ------------------------------------------------- big-tile dense kernels (thousands of rows)
+//
+// With thousands of rnn rows per step (wide beams under look_ahead, thousands of utterances) the
+// split-K kernels above are bound by the L2 -> CU stream: a workgroup re-reads 3 x 32 KB of weights
+// for every 32 rows.  Here a 256-thread workgroup owns FOUR row tiles x FT feature tiles (x 3
+// gates); a wave owns one row tile and walks the FULL K of every weight stream (segment chains
+// combined on the fly, the order of uis_numerics.h -- bit-identical to the split-K schedule), so a
+// weight fragment fetched once serves the four waves out of the CU's L1 and a row fragment serves
+// NA MFMAs.  No LDS: after the chains lane l holds row (l & 15), features 4 (l >> 4) .. + 3 of
+// every stream and runs the stage's elementwise tail on them as float4s.
+template <int NA>
+__device__ __forceinline__ void fullk_multi(const f32x4* const (&wp)[NA], const float* const (&bias)[NA], int nKb,
+                                            const float* __restrict__ inrow, f32x4 (&total)[NA]) {
+  const int lane = threadIdx.x & 63;
+  const int q = lane >> 4;
+  const int per = uis_kseg_blocks(nKb);
+  const f32x4* bp[1] = {reinterpret_cast<const f32x4*>(inrow) + q};
+#pragma unroll 1
+  for (int sgm = 0; sgm < UIS_KSPLIT; ++sgm) {
+    const int kb0 = sgm * per;
+    const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
+    f32x4 acc[1][NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+      acc[0][a] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias[a] + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (kb0 < kb1) chain_blocks<NA, 1>(wp, bp, kb0, kb1, acc);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      if (sgm == 0) total[a] = acc[0][a];
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) total[a][i] = total[a][i] + acc[0][a][i];
+      }
+    }
+  }
+}
+
+#define UIS_BIG_RT 4  // row tiles per workgroup = waves per workgroup
+
+// Which (row tiles, feature tiles) a big-tile workgroup owns; this lane's row.
+struct BigTile {
+  int ft0, row, nrows;
+  bool active, valid;
+};
+template <int FT>
+__device__ __forceinline__ BigTile big_tile(const DecodeState& st, int par, int nft, RnnRow& mine) {
+  BigTile t;
+  const int max_rt = (st.max_rows + 15) >> 4;
+  const int n_rg = (max_rt + UIS_BIG_RT - 1) / UIS_BIG_RT, n_fg = nft / FT;
+  int rg, fg;
+  dense_block_map((int)blockIdx.x, n_rg, n_fg, rg, fg);
+  t.ft0 = fg * FT;
+  const bool in_grid = rg < n_rg && fg < n_fg;
+  t.row = (rg * UIS_BIG_RT + (int)(threadIdx.x >> 6)) * 16 + (int)(threadIdx.x & 15);
+  if (!in_grid || t.row >= st.max_rows) t.row = 0;  // (never a valid row: nrows <= max_rows; keeps every address inside its buffer)
+  mine = st.rows[t.row];
+  t.nrows = st.nrows[par];
+  t.active = in_grid && (rg * UIS_BIG_RT + (int)(threadIdx.x >> 6)) * 16 < t.nrows;  // per wave
+  t.valid = t.active && t.row < t.nrows;
+  return t;
+}
+__host__ __device__ inline int big_grid_blocks(int max_rows, int nft, int FT) {
+  const int max_rt = (max_rows + 15) >> 4;
+  return dense_grid_blocks((max_rt + UIS_BIG_RT - 1) / UIS_BIG_RT, nft / FT);
+}
+
+// GRU layer, FT feature tiles x 3 gates per workgroup
+template <int FT>
+__global__ __launch_bounds__(256) void k_big_gru(DevModel m, DecodeState st, int par, int layer) {
+  const int nft = m.Hp / 16, nKb = m.Hp / 16;
+  RnnRow me;
+  const BigTile tl = big_tile<FT>(st, par, nft, me);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const float* hs = me.src >= 0 ? hid_ptr(m, st, me, me.src, layer) : m.h1 + (size_t)layer * m.Hp;
+  const f32x4* wp[3 * FT];
+  const float* bias[3 * FT];
+#pragma unroll
+  for (int c = 0; c < FT; ++c)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      wp[c * 3 + g] = reinterpret_cast<const f32x4*>(m.whh[layer]) + ((size_t)(g * nft + tl.ft0 + c) * nKb) * 64 + lane;
+      bias[c * 3 + g] = m.bhh[layer] + (size_t)g * m.Hp + (tl.ft0 + c) * 16;
+    }
+  // epilogue operands first: they are used after the chains
+  const float* gi = layer == 0 ? st.gi0 + (size_t)me.frame * m.G : st.gi_up + (size_t)tl.row * m.G;
+  f32x4 gir[FT], giz[FT], gin[FT], hprev[FT];
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    const int j4 = (tl.ft0 + c) * 16 + 4 * q;
+    gir[c] = *reinterpret_cast<const f32x4*>(gi + j4);
+    giz[c] = *reinterpret_cast<const f32x4*>(gi + m.Hp + j4);
+    gin[c] = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j4);
+    hprev[c] = *reinterpret_cast<const f32x4*>(hs + j4);
+  }
+  f32x4 total[3 * FT];
+  fullk_multi<3 * FT>(wp, bias, nKb, hs, total);
+  if (!tl.valid) return;
+  float* hd = const_cast<float*>(hid_ptr(m, st, me, me.dst, layer));
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    const int j4 = (tl.ft0 + c) * 16 + 4 * q;
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      out[i] = j4 + i < m.H ? uis_gru_unit(gir[c][i], giz[c][i], gin[c][i], total[c * 3 + 0][i], total[c * 3 + 1][i],
+                                           total[c * 3 + 2][i], hprev[c][i])
+                            : 0.0f;
+    *reinterpret_cast<f32x4*>(hd + j4) = out;
+  }
+}
+
+// a1[row] = relu(b1 + W1 h'_top), FT feature tiles per workgroup
+template <int FT>
+__global__ __launch_bounds__(256) void k_big_head1(DevModel m, DecodeState st, int par) {
+  const int nft = m.Hp / 16, nKb = m.Hp / 16;
+  RnnRow me;
+  const BigTile tl = big_tile<FT>(st, par, nft, me);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const float* in = hid_ptr(m, st, me, me.dst, m.depth - 1);
+  const f32x4* wp[FT];
+  const float* bias[FT];
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    wp[c] = reinterpret_cast<const f32x4*>(m.w1) + ((size_t)(tl.ft0 + c) * nKb) * 64 + lane;
+    bias[c] = m.b1 + (tl.ft0 + c) * 16;
+  }
+  f32x4 total[FT];
+  fullk_multi<FT>(wp, bias, nKb, in, total);
+  if (!tl.valid) return;
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    f32x4 v = total[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+    *reinterpret_cast<f32x4*>(st.a1 + (size_t)tl.row * m.Hp + (tl.ft0 + c) * 16 + 4 * q) = v;
+  }
+}
+
+// m = b2 + W2 a1; running-mean update -> dst slot, FT feature tiles per workgroup
+template <int FT>
+__global__ __launch_bounds__(256) void k_big_head2(DevModel m, DecodeState st, int par) {
+  const int nft = m.Dp / 16, nKb = m.Hp / 16;
+  RnnRow me;
+  const BigTile tl = big_tile<FT>(st, par, nft, me);
+  if (!tl.active) return;
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const float* in = st.a1 + (size_t)tl.row * m.Hp;  // (rows past nrows: stale but inside the buffer)
+  const f32x4* wp[FT];
+  const float* bias[FT];
+  f32x4 old[FT];
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    wp[c] = reinterpret_cast<const f32x4*>(m.w2) + ((size_t)(tl.ft0 + c) * nKb) * 64 + lane;
+    bias[c] = m.b2 + (tl.ft0 + c) * 16;
+    old[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (tl.valid && me.src >= 0)
+      old[c] = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.src) * m.Dp + (tl.ft0 + c) * 16 + 4 * q);
+  }
+  f32x4 total[FT];
+  fullk_multi<FT>(wp, bias, nKb, in, total);
+  if (!tl.valid) return;
+#pragma unroll
+  for (int c = 0; c < FT; ++c) {
+    const int f4 = (tl.ft0 + c) * 16 + 4 * q;
+    f32x4 v = total[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (me.src >= 0) v[i] = uis_mean_update(old[c][i], v[i], me.nprev);
+      if (f4 + i >= m.D) v[i] = 0.0f;
+    }
+    *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v;
+  }
+}
+
 // -------------------------------------------------- L2-coherent loads (resident decode)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
