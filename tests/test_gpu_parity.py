@@ -18,7 +18,8 @@ from uisrnn_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-_PATH_FLAGS = _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_GRAPH
+_PATH_FLAGS = (_capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_GRAPH |
+               _capi.UIS_FLAG_SMALL_TILES)
 
 
 def _bits(a):
@@ -155,12 +156,19 @@ def test_streams_and_graph_are_bit_identical(oracle_lib):
 
 
 def test_wide_tiles_bit_exact(oracle_lib):
-  """row capacity > 2048 switches the dense kernels to their 2x2 tile shape."""
+  """row capacity > 2048 switches the launch-per-step dense kernels to the big-tile ones (full-K
+  chains per wave); UIS_FLAG_SMALL_TILES keeps the split-K kernels in their 2x2 tile shape.  Also
+  a two-layer model (k_dense_upper_in feeds the big GRU kernel) and dims that fall back."""
   params = synth.tracker_params(256, 512, 1, seed=2)
   n_utt = 224
   lengths = [10 + (7 * u) % 23 for u in range(n_utt)]
   seqs, _ = synth.make_utterances(6000, n_utt, lengths, 256)
   _compare(params, seqs, 10, 1, 2, oracle_lib)
+  _compare(params, seqs, 10, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_SMALL_TILES)
+  deep = synth.tracker_params(128, 128, 2, seed=12)       # depth 2: never the one-launch decode
+  seqs2, _ = synth.make_utterances(6100, n_utt, [8 + (5 * u) % 11 for u in range(n_utt)], 128)
+  _compare(deep, seqs2, 10, 1, 1, oracle_lib)
+  _compare(deep, seqs2, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_SMALL_TILES)
 
 
 def test_generic_select_flag_is_bit_identical(oracle_lib):
