@@ -63,6 +63,21 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Device allocations of a one-off call (uis_rnn_step, the bootstrap of uis_create): freed on every
+// return path.
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T> int get(T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? UIS_ERR_OOM : UIS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    ptrs.push_back(p);
+    *out = static_cast<T*>(p);
+    return UIS_OK;
+  }
+};
+
 #define UIS_WIDE_TILE_ROWS 2048   // row capacity (about twice the rows actually run, after dedup) above which the 2x2 tiles win
 #define UIS_MAX_GROUPS 8
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
@@ -306,13 +321,13 @@ int rnn_step_once(uis_handle* h, const float* d_x, const float* d_hin, float* d_
   float *d_gi0 = nullptr, *d_gi_up = nullptr, *d_a1 = nullptr;
   RnnRow* d_rows = nullptr;
   int32_t* d_nrows = nullptr;
-  HIPCHK(hipMalloc(&d_gi0, m.G * sizeof(float)));
-  HIPCHK(hipMalloc(&d_gi_up, 64 * m.G * sizeof(float)));
-  HIPCHK(hipMalloc(&d_a1, 64 * m.Hp * sizeof(float)));
-  HIPCHK(hipMalloc(&d_rows, 64 * sizeof(RnnRow)));
+  Scratch tmp;
+  int rc;
+  if ((rc = tmp.get(&d_gi0, (size_t)m.G)) || (rc = tmp.get(&d_gi_up, (size_t)64 * m.G)) ||
+      (rc = tmp.get(&d_a1, (size_t)64 * m.Hp)) || (rc = tmp.get(&d_rows, 64)) || (rc = tmp.get(&d_nrows, 2)))
+    return rc;
   HIPCHK(hipMemsetAsync(d_rows, 0, 64 * sizeof(RnnRow), h->stream));
   HIPCHK(hipMemsetAsync(d_a1, 0, 64 * m.Hp * sizeof(float), h->stream));
-  HIPCHK(hipMalloc(&d_nrows, 2 * sizeof(int32_t)));
   RnnRow rr{};
   rr.utt = 0; rr.src = -1; rr.dst = 0; rr.nprev = 0; rr.frame = 0;
   int32_t nr[2] = {1, 1};
@@ -325,11 +340,11 @@ int rnn_step_once(uis_handle* h, const float* d_x, const float* d_hin, float* d_
   st.gi_up = d_gi_up; st.a1 = d_a1;
   const float* saved_h1 = m.h1;
   m.h1 = d_hin;  // a row with src = -1 reads its hidden state from "h1": point that at h_in
-  int rc = launch_rnn(h, lch, st, 0, 1);
+  rc = launch_rnn(h, lch, st, 0, 1);
   m.h1 = saved_h1;
+  hipError_t se = hipStreamSynchronize(h->stream);  // before `tmp` frees what the kernels use
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
-  (void)hipFree(d_gi0); (void)hipFree(d_gi_up); (void)hipFree(d_a1); (void)hipFree(d_rows); (void)hipFree(d_nrows);
+  HIPCHK(se);
   return UIS_OK;
 }
 
@@ -338,15 +353,13 @@ int bootstrap_constants(uis_handle* h, const float* d_hinit) {
   DevModel& m = h->m;
   float *d_x = nullptr, *d_pm = nullptr, *d_ph = nullptr;
   const size_t hid_elems = (size_t)m.depth * m.Hp;
-  HIPCHK(hipMalloc(&d_x, m.Dp * sizeof(float)));
-  HIPCHK(hipMalloc(&d_pm, m.Dp * sizeof(float)));
-  HIPCHK(hipMalloc(&d_ph, hid_elems * sizeof(float)));
+  Scratch tmp;
+  int rc;
+  if ((rc = tmp.get(&d_x, (size_t)m.Dp)) || (rc = tmp.get(&d_pm, (size_t)m.Dp)) || (rc = tmp.get(&d_ph, hid_elems))) return rc;
   HIPCHK(hipMemsetAsync(d_x, 0, m.Dp * sizeof(float), h->stream));
-  int rc = rnn_step_once(h, d_x, d_hinit, d_pm, d_ph);
-  if (rc) return rc;
+  if ((rc = rnn_step_once(h, d_x, d_hinit, d_pm, d_ph))) return rc;
   HIPCHK(hipMemcpy(const_cast<float*>(m.m0), d_pm, m.Dp * sizeof(float), hipMemcpyDeviceToDevice));
   HIPCHK(hipMemcpy(const_cast<float*>(m.h1), d_ph, hid_elems * sizeof(float), hipMemcpyDeviceToDevice));
-  (void)hipFree(d_x); (void)hipFree(d_pm); (void)hipFree(d_ph);
   return UIS_OK;
 }
 
@@ -1005,19 +1018,19 @@ UIS_EXPORT int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in
   memcpy(xp.data(), x, (size_t)m.D * 4);
   for (int l = 0; l < m.depth; ++l) memcpy(hp.data() + (size_t)l * m.Hp, h_in + (size_t)l * m.H, (size_t)m.H * 4);
   float *d_x = nullptr, *d_h = nullptr, *d_m = nullptr, *d_o = nullptr;
-  HIPCHK(hipMalloc(&d_x, xp.size() * 4)); HIPCHK(hipMalloc(&d_h, hp.size() * 4));
-  HIPCHK(hipMalloc(&d_m, mo.size() * 4)); HIPCHK(hipMalloc(&d_o, ho.size() * 4));
+  Scratch tmp;
+  int rc;
+  if ((rc = tmp.get(&d_x, xp.size())) || (rc = tmp.get(&d_h, hp.size())) || (rc = tmp.get(&d_m, mo.size())) ||
+      (rc = tmp.get(&d_o, ho.size())))
+    return rc;
   HIPCHK(hipMemcpy(d_x, xp.data(), xp.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_h, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
-  int rc = rnn_step_once(h, d_x, d_h, d_m, d_o);
-  if (rc == UIS_OK) {
-    HIPCHK(hipMemcpy(mo.data(), d_m, mo.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ho.data(), d_o, ho.size() * 4, hipMemcpyDeviceToHost));
-    memcpy(mean_out, mo.data(), (size_t)m.D * 4);
-    for (int l = 0; l < m.depth; ++l) memcpy(h_out + (size_t)l * m.H, ho.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
-  }
-  (void)hipFree(d_x); (void)hipFree(d_h); (void)hipFree(d_m); (void)hipFree(d_o);
-  return rc;
+  if ((rc = rnn_step_once(h, d_x, d_h, d_m, d_o))) return rc;
+  HIPCHK(hipMemcpy(mo.data(), d_m, mo.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ho.data(), d_o, ho.size() * 4, hipMemcpyDeviceToHost));
+  memcpy(mean_out, mo.data(), (size_t)m.D * 4);
+  for (int l = 0; l < m.depth; ++l) memcpy(h_out + (size_t)l * m.H, ho.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+  return UIS_OK;
 }
 
 UIS_EXPORT int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out) {
@@ -1037,7 +1050,8 @@ UIS_EXPORT int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, fl
 // uis_stream_labels() reads the best hypothesis' labels for everything received so far.
 // Semantics = predict_single with test_iteration 1 (uisrnn.py:479-562): pushing an utterance
 // in any chunking gives bit for bit the labels / scores of one uis_decode over the whole of it
-// (tests/test_gpu_stream.py).  look_ahead 1.  Runs on the launch-per-step kernels.
+// (tests/test_gpu_stream.py).  look_ahead 1.  A push of four or more steps runs as ONE launch of
+// k_decode_resident where that kernel applies, shorter pushes on the launch-per-step kernels.
 
 namespace {
 
