@@ -397,7 +397,7 @@ def main(argv=None):
     }
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # (N > 1: the other ranks would wait at the barrier)
       from oracle import oracle
       cores = os.cpu_count() or 1
       threads = min(cores, 64)

@@ -106,6 +106,15 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_SMALL_TILES 0x200u /* launch-per-step path: keep the split-K dense kernels even where
                                     the big-tile ones (thousands of rnn rows per step) apply; A/B
                                     switch, results are bit-identical either way                */
+#define UIS_FLAG_PERSISTENT 0x400u /* uis_stream_begin only: the one-launch decode kernel STAYS on the device
+                                    between pushes and takes pushes / label requests from a mailbox in
+                                    host-coherent pinned memory -- a push costs no launch and no copy
+                                    engine, only the steps themselves.  The kernel occupies every compute
+                                    unit until uis_stream_end or until it has been idle for
+                                    UIS_PERSIST_IDLE_MS (environment, default 50 ms; it then leaves and
+                                    the next push starts a new one).  Needs the one-launch shape, at
+                                    most one utterance per compute unit, unpadded observation_dim;
+                                    pushes of more than 16 frames per utterance go the ordinary way */
 #define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
                                     a wrong XCD, as if the (observed, not promised) workgroup
                                     placement had changed.  The call must then fall back to the
@@ -218,7 +227,10 @@ int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in, float* me
  * (bit for bit).  One session per handle; uis_decode is refused while it is open.
  *
  *   uis_stream_begin  opts->test_iteration and look_ahead must be 1; max_frames = the most frames
- *                     any utterance will receive in this session (4 * beam_size bytes each)
+ *                     any utterance will receive in this session (4 * beam_size bytes each).
+ *                     opts->flags: UIS_FLAG_PERSISTENT keeps the decode kernel on the device
+ *                     between pushes (lowest latency, occupies the whole device; UIS_ERR_UNSUPPORTED
+ *                     where the session's shape does not allow it)
  *   uis_stream_push   frames: host float32, the new frames of utterance 0, then 1, ...;
  *                     counts[u] >= 0 = how many of them belong to utterance u (0 is fine)
  *   uis_stream_labels labels_out: host int32, for every utterance all frames received so far

@@ -137,6 +137,81 @@ def test_many_utterances_one_frame_pushes(oracle_lib):
   assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
 
 
+@pytest.mark.parametrize('max_chunk', [1, 5, 16])
+def test_persistent_launch_any_chunking_equals_offline_decode(max_chunk, oracle_lib):
+  """UIS_FLAG_PERSISTENT: the decode kernel stays on the device between pushes and takes them from
+  the host-memory mailbox; labels are back-traced inside it.  Same contract as every other path."""
+  params = synth.tracker_params(256, 512, 1, seed=31)
+  lens = [60, 33, 1, 90, 17, 45, 72, 8, 64, 2, 29]
+  seqs, _ = synth.make_utterances(12_500, len(lens), lens, 256)
+  dec = _capi.Decoder(params)
+  off, offsets = _offline(dec, seqs, 10)
+  ref = oracle_lib.decode(params, seqs, 10, 1, 1, n_threads=8)
+  schedule = _random_schedule(np.random.default_rng(100 + max_chunk), lens, max_chunk)
+  prefix_checks = []
+
+  def check(d, pos):   # labels after every few pushes: prefixes of the final answer are NOT expected
+    if len(prefix_checks) % 7 == 0:      # (the best hypothesis may change), lengths and status are
+      labels, scores, _, status = d.stream_labels()
+      assert status == 0 and [len(x) for x in labels] == pos
+    prefix_checks.append(1)
+
+  labels, scores, overflow, status, beam = _stream(dec, seqs, 10, schedule, 100, flags=_capi.UIS_FLAG_PERSISTENT,
+                                                   check_every_push=check)
+  assert status == 0 and not overflow.any()
+  for u in range(len(seqs)):
+    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
+    assert np.array_equal(labels[u], ref['labels'][u]), u
+  assert np.array_equal(_bits(scores), _bits(off['scores']))
+  assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
+  again, _ = _offline(dec, seqs, 10)   # the launch has left: ordinary decodes work again
+  assert np.array_equal(again['labels'], off['labels'])
+
+
+def test_persistent_launch_leaves_when_idle_and_comes_back(oracle_lib, monkeypatch):
+  """Idle for longer than UIS_PERSIST_IDLE_MS: the kernel writes its tables back and leaves; the
+  next push starts a new one; a push too large for the mailbox goes the ordinary way in between."""
+  import time
+  monkeypatch.setenv('UIS_PERSIST_IDLE_MS', '5')
+  params = synth.tracker_params(256, 512, 1, seed=32)
+  lens = [70, 70, 41, 70, 12, 70, 70, 55, 70]
+  seqs, _ = synth.make_utterances(12_600, len(lens), lens, 256)
+  dec = _capi.Decoder(params)
+  off, offsets = _offline(dec, seqs, 10)
+  schedule = []
+  left = list(lens)
+  for take in (1, 1, 3, 1, 40, 2, 1, 1, 16, 1, 99):   # 40 and 99: more than 16 frames per utterance
+    counts = [min(n, take) for n in left]
+    left = [n - c for n, c in zip(left, counts)]
+    if any(counts):
+      schedule.append(counts)
+  assert not any(left)
+  naps = iter([0, 0.05, 0, 0, 0.05, 0, 0.02, 0, 0, 0.05, 0, 0, 0])
+
+  def nap(d, pos):
+    time.sleep(next(naps))
+    if len(pos) and pos[0] in (2, 6):
+      labels, _, _, status = d.stream_labels()   # once with the launch gone, once (usually) with it resident
+      assert status == 0 and [len(x) for x in labels] == pos
+
+  labels, scores, overflow, status, beam = _stream(dec, seqs, 10, schedule, 100, flags=_capi.UIS_FLAG_PERSISTENT,
+                                                   check_every_push=nap)
+  assert status == 0 and not overflow.any()
+  for u in range(len(seqs)):
+    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), u
+  assert np.array_equal(_bits(scores), _bits(off['scores']))
+  assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
+
+
+def test_persistent_flag_is_refused_where_it_cannot_work():
+  params = weights.init_params(20, 24, 1, sigma2=0.08, transition_bias=0.2, seed=4)
+  dec = _capi.Decoder(params)
+  opts = _capi.make_opts(4, 1, 1, 0, _capi.UIS_FLAG_PERSISTENT, 0)
+  assert dec._lib.uis_stream_begin(dec._handle, 2, opts, 8) == _capi.UIS_ERR_UNSUPPORTED
+  dec.stream_begin(2, 4, 8)    # the handle is still good
+  dec.stream_end()
+
+
 def test_odd_model_shapes_general_select_and_depth(oracle_lib):
   """Padded dims, depth 2 (k_dense_upper_in), a beam too wide for the fast select kernel."""
   rng = np.random.default_rng(3)
@@ -196,6 +271,11 @@ def test_python_online_session_matches_predict():
     assert session.labels() == offline
     with pytest.raises(TypeError):
       session.push([seqs[0].astype(np.float32), None, None])   # the reference's float64 rule
+  with model.online(3, inference_args, max_frames=64, persistent=True) as session:
+    assert session.persistent
+    for lo in range(0, 50, 5):
+      session.push([s[lo:lo + 5] if lo < len(s) else None for s in seqs])
+    assert session.labels() == offline
   inference_args.look_ahead = 2
   with pytest.raises(ValueError):
     model.online(3, inference_args, max_frames=64)

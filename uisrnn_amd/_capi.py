@@ -33,6 +33,7 @@ UIS_FLAG_RESIDENT = 0x40
 UIS_FLAG_STEPWISE = 0x80
 UIS_FLAG_TEST_MISPLACED = 0x100
 UIS_FLAG_SMALL_TILES = 0x200
+UIS_FLAG_PERSISTENT = 0x400
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
@@ -178,6 +179,7 @@ def make_opts(beam_size, look_ahead, test_iteration, max_clusters=0, flags=0,
 
 class HipLibraryError(RuntimeError):
   """The HIP decoder library is missing, failed to load or reported an error."""
+  status = None   # the uis_status of a failed call, where there was one
 
 
 _lib = None
@@ -322,7 +324,9 @@ class Decoder:
     msg = last_error(self._lib)
     if rc == UIS_ERR_DIM_MISMATCH:
       raise ValueError(msg)
-    raise HipLibraryError('{} failed ({}): {}'.format(what, rc, msg))
+    err = HipLibraryError('{} failed ({}): {}'.format(what, rc, msg))
+    err.status = rc
+    raise err
 
   def decode(self, frames, offsets, beam_size, look_ahead, test_iteration,
              max_clusters=0, flags=0, want_beam_scores=False, n_streams=0):

@@ -10,6 +10,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +136,21 @@ struct uis_handle {
     bool coop_checked = false;        // one push of this session already went through the cooperative launch
     uint32_t* d_ctl = nullptr;
     size_t ctl_words = 0;
+    // persistent launch (UIS_FLAG_PERSISTENT): k_decode_resident<.., true> stays on the device between
+    // pushes; commands, tables, frames and labels travel through pm_block (host-coherent pinned memory)
+    bool persist = false;             // the session asked for it and its shape allows it
+    bool pm_running = false;          // the launch is on the device
+    unsigned char* pm_block = nullptr;
+    uint32_t pm_seq = 0;              // commands issued to the running launch
+    int64_t pm_cap_frames = 0;        // frames one push can carry through the mailbox
+    size_t pm_o_foff = 0, pm_o_avail = 0, pm_o_laboff = 0, pm_o_frames = 0, pm_o_labels = 0, pm_o_scores = 0,
+           pm_o_bscores = 0, pm_o_overflow = 0;
+    unsigned long long* d_go = nullptr;
+    unsigned char* d_hdr = nullptr;
+    PersistArgs pm_args{};            // host copy of what d_pm_args holds
+    PersistArgs* d_pm_args = nullptr;
+    size_t hdr_stride = 0;
+    int64_t pm_launches = 0, pm_commands = 0;
   } stream_state;
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
@@ -156,6 +173,21 @@ struct uis_handle {
 };
 
 namespace {
+
+inline volatile uint32_t* pm_ctl(uis_handle::Stream& ss) { return reinterpret_cast<volatile uint32_t*>(ss.pm_block); }
+
+// every cluster's doorbell: command words first, then the sequence numbers
+void pm_ring(uis_handle::Stream& ss, uint32_t seq, uint32_t type, uint32_t frames, const uint32_t* row0) {
+  volatile uint32_t* ctl = pm_ctl(ss);
+  const int ncl = ss.st.ncl;
+  for (int c = 0; c < ncl; ++c) {
+    ctl[UIS_PM_BELL_WORD + 16 * c + 1] = type | (frames << 8);
+    ctl[UIS_PM_BELL_WORD + 16 * c + 2] = row0 ? (row0[c] | ((row0[c + 1] - row0[c]) << 16)) : 0u;
+  }
+  std::atomic_thread_fence(std::memory_order_release);
+  for (int c = 0; c < ncl; ++c) ctl[UIS_PM_BELL_WORD + 16 * c] = seq;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
 
 // Re-pack a (n_out x K) row-major matrix (optionally 3 stacked gates of `rows_per_gate`
 // rows each, padded to `rows_per_gate_p`) into MFMA tile order:
@@ -867,11 +899,16 @@ static void stream_free_on_destroy(uis_handle* h) {
                     &h->stream_state.chunk_mse0, &h->stream_state.labels, &h->stream_state.scores};
   for (DevBuf* b : bufs) b->release();
   if (h->stream_state.h_stage) { (void)hipHostFree(h->stream_state.h_stage); h->stream_state.h_stage = nullptr; }
+  if (h->stream_state.pm_block) { (void)hipHostFree(h->stream_state.pm_block); h->stream_state.pm_block = nullptr; }
 }
 
 UIS_EXPORT void uis_destroy(uis_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->stream_state.pm_running) {  // tell the resident launch to leave before waiting for the stream
+    pm_ring(h->stream_state, h->stream_state.pm_seq + 1, UIS_PM_QUIT, 0, nullptr);
+    h->stream_state.pm_running = false;
+  }
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   stream_free_on_destroy(h);
   for (void* p : h->model_allocs) (void)hipFree(p);
@@ -1062,6 +1099,8 @@ void stream_free(uis_handle* h) {
   DevBuf* bufs[] = {&ss.chunk_x, &ss.chunk_pad, &ss.chunk_gi0, &ss.chunk_mse0, &ss.labels, &ss.scores};
   for (DevBuf* b : bufs) b->release();
   if (ss.h_stage) { (void)hipHostFree(ss.h_stage); ss.h_stage = nullptr; ss.h_stage_cap = 0; }
+  if (ss.pm_block) { (void)hipHostFree(ss.pm_block); ss.pm_block = nullptr; }
+  ss.persist = false; ss.pm_running = false;
   ss.active = false;
   ss.have.clear();
 }
@@ -1076,6 +1115,147 @@ int stream_alloc(uis_handle* h, T** out, size_t count, bool zero = false) {
   if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, h->stream));
   *out = static_cast<T*>(p);
   return UIS_OK;
+}
+
+// ---- the persistent launch of a UIS_FLAG_PERSISTENT session
+//
+// Mailbox protocol (pm_block, host-coherent pinned memory; uint32 view, one 64-byte line per item,
+// uis_kernels.h UIS_PM_*_WORD): a doorbell line per cluster {sequence number, command | frames << 8,
+// first row | rows << 16} whose sequence number the host writes LAST (release) and rank 0 of the
+// cluster polls with one 16-byte read; the sequence number of the last command each cluster
+// completed; a word per cluster that turns non-zero when the cluster has left the kernel.
+// While the launch is on the device the host makes NO HIP call that could wait for the device:
+// everything a command needs was allocated by uis_stream_begin.
+
+double pm_now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+unsigned long long pm_idle_ticks() {
+  double ms = 50.0;  // without a command for this long the launch ends by itself (the next push starts a new one)
+  if (const char* e = getenv("UIS_PERSIST_IDLE_MS")) ms = atof(e);
+  ms = std::min(std::max(ms, 0.05), 2000.0);
+  return (unsigned long long)(ms * 1e5);  // s_memrealtime ticks of 10 ns
+}
+
+// After the launch has ended (every cluster left, or an in-launch barrier gave up): look at the abort word.
+int pm_reap(uis_handle* h) {
+  uis_handle::Stream& ss = h->stream_state;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  ss.pm_running = false;
+  uint32_t abort_word = 0;
+  HIPCHK(hipMemcpy(&abort_word, ss.d_ctl + 16, 4, hipMemcpyDeviceToHost));
+  if (abort_word) {
+    ss.persist = false;
+    h->resident_off = true;
+    return fail(UIS_ERR_HIP, "in-launch barrier failed inside the persistent streaming launch; close the session "
+                             "(uis_stream_end) and reopen it with UIS_FLAG_STEPWISE");
+  }
+  return UIS_OK;
+}
+
+int pm_launch(uis_handle* h) {
+  uis_handle::Stream& ss = h->stream_state;
+  const DevModel& m = h->m;
+  DecodeState st = ss.st;
+  unsigned char* blk = ss.pm_block;
+  st.x = reinterpret_cast<const float*>(ss.chunk_x.as<char>());
+  st.gi0 = ss.chunk_gi0.as<float>();
+  st.mse0 = ss.chunk_mse0.as<float>();
+  st.push_F = 0;
+  PersistArgs& pa = ss.pm_args;
+  pa.ctl = reinterpret_cast<uint32_t*>(blk);
+  pa.foff = reinterpret_cast<const int64_t*>(blk + ss.pm_o_foff);
+  pa.avail = reinterpret_cast<const int32_t*>(blk + ss.pm_o_avail);
+  pa.lab_off = reinterpret_cast<const int64_t*>(blk + ss.pm_o_laboff);
+  pa.frames = reinterpret_cast<const float*>(blk + ss.pm_o_frames);
+  pa.labels = reinterpret_cast<int32_t*>(blk + ss.pm_o_labels);
+  pa.scores = reinterpret_cast<float*>(blk + ss.pm_o_scores);
+  pa.beam_scores = reinterpret_cast<float*>(blk + ss.pm_o_bscores);
+  pa.overflow = reinterpret_cast<int32_t*>(blk + ss.pm_o_overflow);
+  pa.go = ss.d_go;
+  pa.hdr = ss.d_hdr;
+  pa.hdr_stride = ss.hdr_stride;
+  pa.idle_ticks = pm_idle_ticks();
+  HIPCHK(hipMemcpyAsync(ss.d_pm_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
+  st.pm = ss.d_pm_args;
+  // avail / foff only have to be non-null here (the kernel points them at its cluster's copies)
+  st.avail = reinterpret_cast<const int32_t*>(ss.d_hdr);
+  st.foff = reinterpret_cast<const int64_t*>(ss.d_hdr);
+  HIPCHK(hipMemsetAsync(ss.d_ctl, 0, ss.ctl_words * 4, h->stream));
+  HIPCHK(hipMemsetAsync(ss.d_go, 0, (size_t)UIS_PM_MAX_CLUSTERS * 128, h->stream));
+  HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
+  Launcher lch{h, h->stream, false};
+  const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Hp, m.Dp, ss.B, ss.Kmax, ss.S), 96 * 1024);
+  int rc = UIS_ERR_UNSUPPORTED;
+  h->inlaunch_failed = false;
+#define UIS_PERSIST_CASE(HPV, DPV)                                                                                    \
+  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV, true>),                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
+    rc = lch.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV, true>, h->n_cu, dim3(32 * st.ncl), dim3(512), \
+                             shmem, m, st, true);                                                                    \
+  }
+  UIS_PERSIST_CASE(512, 256)
+  UIS_PERSIST_CASE(512, 512)
+  UIS_PERSIST_CASE(256, 256)
+#undef UIS_PERSIST_CASE
+  if (rc) return rc;
+  ss.pm_running = true;
+  ss.pm_launches += 1;
+  return UIS_OK;
+}
+
+// Issue one command and wait until every cluster has completed it.  A launch that is not on the
+// device (never started, or left because it was idle) is started first when `may_launch`; a
+// launch that left while the command was on its way is reaped and the command issued again to a
+// new one -- harmless: a cluster that did take a push has nothing left to do for it.
+// Returns UIS_OK, an error, or 1 = not running and may_launch was false.
+int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, const uint32_t* row0 = nullptr) {
+  uis_handle::Stream& ss = h->stream_state;
+  volatile uint32_t* ctl = pm_ctl(ss);
+  const int ncl = ss.st.ncl;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    int rc;
+    if (!ss.pm_running) {
+      if (!may_launch) return 1;
+      for (int i = 0; i < UIS_PM_CTL_WORDS; ++i) ctl[i] = 0;
+      ss.pm_seq = 1;
+      pm_ring(ss, 1, type, frames, row0);
+      if ((rc = pm_launch(h))) return rc;
+    } else {
+      ss.pm_seq += 1;
+      pm_ring(ss, ss.pm_seq, type, frames, row0);
+    }
+    ss.pm_commands += 1;
+    const double t0 = pm_now_s();
+    bool left = false;
+    unsigned spins = 0;
+    for (;;) {
+      bool all = true;
+      for (int c = 0; c < ncl; ++c) all = all && ctl[UIS_PM_DONE_WORD + 16 * c] == ss.pm_seq;
+      if (all) return UIS_OK;
+      for (int c = 0; c < ncl; ++c) left = left || ctl[UIS_PM_LEFT_WORD + 16 * c] != 0;
+      if (left) break;
+      if ((++spins & 1023u) == 0 && pm_now_s() - t0 > 10.0) break;
+      __builtin_ia32_pause();
+    }
+    // a cluster left before (or instead of) completing the command: tell the others to leave too
+    // (they complete this command first if they had not seen it yet), then look at what happened
+    ss.pm_seq += 1;
+    pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0, nullptr);
+    if ((rc = pm_reap(h))) return rc;
+    if (!left) return fail(UIS_ERR_HIP, "the persistent streaming launch did not answer within 10 s");
+  }
+  return fail(UIS_ERR_HIP, "the persistent streaming launch kept leaving before it took the command");
+}
+
+int pm_quit(uis_handle* h) {
+  uis_handle::Stream& ss = h->stream_state;
+  if (!ss.pm_running) return UIS_OK;
+  ss.pm_seq += 1;
+  pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0, nullptr);
+  return pm_reap(h);
 }
 
 }  // namespace
@@ -1154,6 +1334,45 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
     st.rx_bar = ss.d_ctl + 32 + UIS_MAX_CLUSTERS * 32;
   }
   SALLOC(ss.d_beam_scores, (size_t)U * B, false);
+  if (opts->flags & UIS_FLAG_PERSISTENT) {
+    // the launch that stays: needs the one-launch shape with the beam in LDS (at most one utterance
+    // per workgroup), unpadded frames, and a mailbox that holds every label of the session
+    const bool shape = (m.Hp == 512 && (m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && m.Dp == 256);
+    const double label_bytes = (double)U * (double)max_frames * 4.0;
+    if (!(ss.resident && shape && U <= 32 * ncl && m.D == m.Dp && label_bytes <= 256e6)) {
+      stream_free(h);
+      return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_PERSISTENT needs the one-launch shape (rnn_depth 1, rnn_hidden_size 512 with "
+                                       "observation_dim 256 / 512 or 256 with 256, unpadded), at most one utterance per compute "
+                                       "unit and n_utt * max_frames <= 64 M labels");
+    }
+    ss.pm_cap_frames = std::min<int64_t>((int64_t)U * 16, (int64_t)UIS_RES_HEAD_TILES * 16 * 6);
+    size_t o = (size_t)UIS_PM_CTL_WORDS * 4;
+    auto take = [&](size_t bytes) { o = (o + 127) & ~(size_t)127; const size_t r = o; o += bytes; return r; };
+    ss.pm_o_foff = take((size_t)U * 8);
+    ss.pm_o_avail = take((size_t)U * 4);
+    ss.pm_o_laboff = take((size_t)U * 8);
+    ss.pm_o_scores = take((size_t)U * 4);
+    ss.pm_o_bscores = take((size_t)U * B * 4);
+    ss.pm_o_overflow = take((size_t)U * 4);
+    ss.pm_o_frames = take((size_t)ss.pm_cap_frames * m.D * 4);
+    ss.pm_o_labels = take((size_t)U * (size_t)max_frames * 4);
+    void* blk = nullptr;
+    hipError_t e = hipHostMalloc(&blk, o, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) { stream_free(h); return fail(UIS_ERR_OOM, std::string("hipHostMalloc (mailbox): ") + hipGetErrorString(e)); }
+    memset(blk, 0, o);
+    ss.pm_block = static_cast<unsigned char*>(blk);
+    ss.hdr_stride = (((size_t)U * 12) + 127) & ~(size_t)127;
+    SALLOC(ss.d_go, (size_t)UIS_PM_MAX_CLUSTERS * 16, true);
+    SALLOC(ss.d_hdr, (size_t)ncl * ss.hdr_stride, true);
+    SALLOC(ss.d_pm_args, 1, false);
+    // everything a push through the mailbox touches, now: no allocation while the launch is resident
+    if ((rc = ss.chunk_x.ensure((size_t)U * 16 + (size_t)ss.pm_cap_frames * m.Dp * 4)) ||
+        (rc = ss.chunk_gi0.ensure((size_t)ss.pm_cap_frames * m.G * 4)) || (rc = ss.chunk_mse0.ensure((size_t)ss.pm_cap_frames * 4))) {
+      stream_free(h);
+      return rc;
+    }
+    ss.persist = true;
+  }
 #undef SALLOC
   if (ss.resident)  // the extra slot every GRU source row of a fresh cluster reads
     HIPCHK(hipMemcpyAsync(st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -1193,6 +1412,57 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   if (!frames) return fail(UIS_ERR_INVALID_ARG, "frames is null");
   HIPCHK(hipSetDevice(h->device));
   int rc;
+#if defined(UIS_PM_TIMING)
+  const double t_enter = pm_now_s();
+#endif
+  if (ss.persist && !h->resident_off && F <= ss.pm_cap_frames) {
+    // ---- the launch that stays on the device: tables and frames into the mailbox, ring, wait
+    int64_t* p_foff = reinterpret_cast<int64_t*>(ss.pm_block + ss.pm_o_foff);
+    int32_t* p_avail = reinterpret_cast<int32_t*>(ss.pm_block + ss.pm_o_avail);
+    // frames cluster by cluster (cluster c owns utterances c, c + ncl, ...): each cluster's rank 0
+    // fetches ONE contiguous row range
+    const int ncl = ss.st.ncl;
+    uint32_t row0[UIS_PM_MAX_CLUSTERS + 1];
+    std::vector<int64_t> src(U + 1, 0);  // where utterance u's frames start in the caller's buffer
+    for (int u = 0; u < U; ++u) src[u + 1] = src[u] + counts[u];
+    int64_t pos = 0;
+    float* dst = reinterpret_cast<float*>(ss.pm_block + ss.pm_o_frames);
+    for (int c = 0; c < ncl; ++c) {
+      row0[c] = (uint32_t)pos;
+      for (int u = c; u < U; u += ncl) {
+        p_foff[u] = pos - ss.have[u];
+        p_avail[u] = ss.have[u] + counts[u];
+        if (counts[u]) memcpy(dst + (size_t)pos * m.D, frames + (size_t)src[u] * m.D, (size_t)counts[u] * m.D * 4);
+        pos += counts[u];
+      }
+    }
+    row0[ncl] = (uint32_t)pos;
+    h->inlaunch_failed = false;
+#if defined(UIS_PM_TIMING)
+    static double fill_s = 0.0, wait_s = 0.0; static long n_push = 0;
+    const double t_mid = pm_now_s();
+    fill_s += t_mid - t_enter;
+#endif
+    rc = pm_command(h, UIS_PM_PUSH, (uint32_t)F, true, row0);
+#if defined(UIS_PM_TIMING)
+    wait_s += pm_now_s() - t_mid;
+    if (++n_push % 100 == 0) {
+      const volatile unsigned long long* k = reinterpret_cast<const volatile unsigned long long*>(pm_ctl(ss) + UIS_PM_TIMING_WORD);
+      const unsigned long long k5 = k[5]; const double n = (double)(k5 ? k5 : 1);
+      fprintf(stderr, "[pm timing] host per push: fill %.1f us, ring + wait %.1f us; kernel (workgroup 0) per push: fetch %.1f, pass on %.1f, "
+              "count + chunk projection %.1f, steps %.1f us\n", 1e6 * fill_s / n_push, 1e6 * wait_s / n_push, k[0] * 0.01 / n, k[1] * 0.01 / n,
+              k[2] * 0.01 / n, k[3] * 0.01 / n);
+    }
+#endif
+    if (rc == UIS_OK) {
+      for (int u = 0; u < U; ++u) ss.have[u] += counts[u];
+      ss.steps_run += max_new;
+      return UIS_OK;
+    }
+    if (!h->inlaunch_failed) return rc;
+    ss.persist = false;  // the cooperative launch was refused: ordinary launches from here on
+  }
+  if (ss.pm_running && (rc = pm_quit(h))) return rc;
   // ---- one staging block, one H2D: [foff][avail][frames]
   const size_t hdr = (size_t)U * 8 + (((size_t)U * 4 + 15) & ~(size_t)15);
   const size_t need = hdr + (size_t)F * m.D * 4;
@@ -1308,6 +1578,30 @@ UIS_EXPORT int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* 
   if (F > 0 && !labels_out) return fail(UIS_ERR_INVALID_ARG, "labels_out is null");
   HIPCHK(hipSetDevice(h->device));
   int rc;
+  if (ss.persist && ss.pm_running) {
+    // the resident launch back-traces every utterance and writes into the mailbox
+    memcpy(ss.pm_block + ss.pm_o_laboff, lab_off.data(), (size_t)U * 8);
+    rc = pm_command(h, UIS_PM_LABELS, 0, false);
+    if (rc == UIS_OK) {
+      if (F > 0) memcpy(labels_out, ss.pm_block + ss.pm_o_labels, (size_t)F * 4);
+      if (scores_out) memcpy(scores_out, ss.pm_block + ss.pm_o_scores, (size_t)U * 4);
+      h->last_U = U; h->last_B = ss.B;
+      h->last_overflow.assign(reinterpret_cast<const int32_t*>(ss.pm_block + ss.pm_o_overflow),
+                              reinterpret_cast<const int32_t*>(ss.pm_block + ss.pm_o_overflow) + U);
+      h->last_beam_scores.assign(reinterpret_cast<const float*>(ss.pm_block + ss.pm_o_bscores),
+                                 reinterpret_cast<const float*>(ss.pm_block + ss.pm_o_bscores) + (size_t)U * ss.B);
+      int n_over = 0;
+      for (int u = 0; u < U; ++u) {
+        if (overflow_out) overflow_out[u] = h->last_overflow[u];
+        n_over += h->last_overflow[u] != 0;
+      }
+      if (n_over)
+        return fail(UIS_ERR_CLUSTER_CAP, std::to_string(n_over) + " utterance(s) needed more than max_clusters=" +
+                                             std::to_string(ss.Kmax) + " clusters per hypothesis");
+      return UIS_OK;
+    }
+    if (rc != 1) return rc;  // (1: the launch had left -- its tables are back in global memory)
+  }
   if ((rc = ss.labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
   if ((rc = ss.scores.ensure((size_t)U * 4))) return rc;
   HIPCHK(hipMemcpyAsync(ss.d_lab_off, lab_off.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
@@ -1337,9 +1631,10 @@ UIS_EXPORT int32_t uis_stream_end(uis_handle* h) {
   if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
   if (!h->stream_state.active) return UIS_OK;
   HIPCHK(hipSetDevice(h->device));
+  const int rc_quit = pm_quit(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   stream_free(h);
-  return UIS_OK;
+  return rc_quit;
 }
 
 

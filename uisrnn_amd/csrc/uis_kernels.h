@@ -29,6 +29,18 @@ struct RnnRow {
   int64_t pad;
 };
 
+#define UIS_PM_PUSH 1u
+#define UIS_PM_LABELS 2u
+#define UIS_PM_QUIT 3u
+#define UIS_PM_IDLE 4u          // (kernel-side only: nothing arrived for pm_idle_ticks)
+#define UIS_PM_MAX_CLUSTERS 16
+// the mailbox's control words (uint32 view of the block's first bytes), one 64-byte line each:
+#define UIS_PM_BELL_WORD 0      // + 16 c: cluster c's doorbell {sequence number, command | frames << 8, first row | rows << 16, 0}
+#define UIS_PM_DONE_WORD 256    // + 16 c: sequence number of the last command cluster c completed
+#define UIS_PM_LEFT_WORD 512    // + 16 c: non-zero once cluster c has left the kernel (1 told to, 2 idle)
+#define UIS_PM_TIMING_WORD 768  // 6 x uint64 of the -DUIS_PM_TIMING build
+#define UIS_PM_CTL_WORDS 832
+
 struct DevModel {
   int D, H, depth, Dp, Hp, G;  // G = 3*Hp (gates r|z|n, each padded to Hp)
   // weights in MFMA tile order: [feature tile][k block][lane 0..63][4]
@@ -42,6 +54,26 @@ struct DevModel {
   const float* m0;     // [Dp]  mean of a fresh cluster before its first frame
   const float* h1;     // [depth][Hp] hidden of a fresh cluster before its first frame
   double lp_stay, lp_sw, l_alpha;
+};
+
+// Persistent streaming launch (UIS_FLAG_PERSISTENT sessions): k_decode_resident stays on the device
+// between pushes and takes its commands from a block of host-coherent pinned memory.  `ctl` and
+// the other pointers below name HOST memory mapped into the device's address space, except go / hdr.
+// ctl: the UIS_PM_*_WORD lines above.
+struct PersistArgs {
+  uint32_t* ctl;
+  const int64_t* foff;      // [U]   as DecodeState::foff, of the current push
+  const int32_t* avail;     // [U]   as DecodeState::avail
+  const int64_t* lab_off;   // [U]   where utterance u's labels go in `labels` (LABELS command)
+  const float* frames;      // [push frames][D]
+  int32_t* labels;
+  float* scores;            // [U]
+  float* beam_scores;       // [U][B]
+  int32_t* overflow;        // [U]
+  unsigned long long* go;   // device, one 128-byte line per cluster: {sequence number, command | frames << 8, first row, rows}
+  unsigned char* hdr;       // device, per cluster: [foff U x 8][avail U x 4]; stride hdr_stride
+  size_t hdr_stride;
+  unsigned long long idle_ticks;  // 10 ns ticks without a command after which the launch ends by itself
 };
 
 // Everything the per-step kernels need about the running decode.
@@ -107,6 +139,9 @@ struct DecodeState {
   // the chunk holds push_F frames whose gi0 / mse0 the kernel computes itself (each cluster for
   // its own utterances' frames) before its first step, instead of two extra launches
   int push_F;
+  // persistent streaming launch (UIS_FLAG_PERSISTENT sessions): where the session's mailbox is
+  // (device memory copy of a PersistArgs); null in every other launch
+  const struct PersistArgs* pm;
 
   // ---- look_ahead >= 2 only (k_window): intermediate hypothesis levels of the current window.
   // Two level buffers (ping-pong over sub-steps), NC hypotheses each per utterance.

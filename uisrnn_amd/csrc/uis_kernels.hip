@@ -1701,7 +1701,33 @@ __host__ __device__ inline size_t resident_lds_bytes(int Hp, int Dp, int B, int 
 #define FSTAMP(k) do {} while (0)
 #endif
 
-template <int HP, int DP>
+__device__ __forceinline__ void backtrace_body(const DecodeState& st, int u, int32_t* __restrict__ labels,
+                                               float* __restrict__ scores, float* __restrict__ beam_scores,
+                                               unsigned char* bt_map);
+
+// Loads from / stores to host-coherent pinned memory (the persistent session's mailbox): system
+// scope, no cache on the way.
+__device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int32_t sys_load_i32(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ long long sys_load_i64(const int64_t* p) {
+  return __hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ f32x4 sys_load_f32x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// PERSIST: the launch of a persistent streaming session (pm.ctl): after its first push it
+// stays on the device and takes further commands (push / labels / quit) from the session's
+// mailbox in host-coherent memory, polled by rank 0 of every cluster and passed on through the
+// cluster's line of pm.go; it leaves by itself after pm.idle_ticks without a command.
+// Beam tables stay in LDS from push to push; needs at most one utterance per workgroup.
+template <int HP, int DP, bool PERSIST = false>
 __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState st) {
   constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
@@ -1731,25 +1757,12 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     s_ctl[0] = 0;
     s_ctl[1] = 0;
     s_ctl[2] = 0;  // "this workgroup has already arrived at the barrier it is about to wait at"
+    s_ctl[6] = 0;  // PERSIST, rank 0: the host's sequence number of the last command taken
 #if defined(UIS_RESIDENT_TIMING) || defined(UIS_RESIDENT_PROBE)
     for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k] = 0;
 #endif
   }
   __syncthreads();
-  {  // decode steps of this cluster = the longest of its utterances
-    int myT = 0;
-    for (int i = t; cluster + ncl * i < U; i += 512) {
-      const int u = cluster + ncl * i;
-      // streaming (uis_stream_push): the steps this utterance can run now = frames received - steps done
-      const long T = st.avail ? (long)st.avail[u] - (long)st.utt_step[u]
-                              : (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
-      myT = T > myT ? (int)T : myT;
-    }
-    if (myT > 0) atomicMax(&s_ctl[1], myT);
-  }
-  __syncthreads();
-  const int nsteps = s_ctl[1];
-
   // ---- this thread's share of the weights, for the whole decode
   // (hidden size 512: W_hh = 48 registers per thread, the two mean-head tiles 2 x 32 KB of LDS)
   f32x4 wg[3][PER];
@@ -1784,15 +1797,165 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   const bool keep_beam = U <= 32 * ncl;
   const bool did_select = cluster + ncl * rank < U;  // keep_beam: this workgroup owns an utterance
   long my_off0 = 0, my_off1 = 0;
-  // a streaming session (st.avail): the utterance continues at its own step count; the beam
-  // tables are fetched from their global copies at the first step and written back at the end
-  int my_step0 = 0;
   if (keep_beam && did_select) {
     my_off0 = (long)st.off[cluster + ncl * rank];
     my_off1 = (long)st.off[cluster + ncl * rank + 1];
-    if (st.avail) my_step0 = st.utt_step[cluster + ncl * rank];
   }
-  if (st.push_F > 0) {
+  // streaming: the beam tables (LDS) go back to their global copies when the launch ends
+  auto write_back = [&](int final_step) {
+    const int u = cluster + ncl * rank;
+    const int B = st.B, Kmax = st.Kmax;
+    const int cur = final_step & 1;
+    const unsigned char* set = smem_raw + cur * L.set_stride;
+    const size_t bb = ((size_t)cur * U + u) * B;
+    for (int e = t; e < B * Kmax; e += 512) {
+      st.beam_slot[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_slot)[e];
+      st.beam_blk[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_blk)[e];
+    }
+    for (int b2 = t; b2 < B; b2 += 512) {
+      st.beam_K[bb + b2] = reinterpret_cast<const int*>(set + L.off_K)[b2];
+      st.beam_last[bb + b2] = reinterpret_cast<const int*>(set + L.off_last)[b2];
+      st.beam_sum[bb + b2] = reinterpret_cast<const int*>(set + L.off_sum)[b2];
+    }
+    const int* spc = reinterpret_cast<const int*>(smem_raw + L.off_pcnt);
+    for (int sl = t; sl < S; sl += 512) st.pool_cnt[(size_t)u * S + sl] = spc[sl];
+    if (t == 0) st.utt_step[u] = final_step;
+  };
+  // PERSIST: the session's per-push tables are this cluster's device copies, filled by rank 0
+  // (read through the pointer where needed -- all of it outside the step loop)
+  const PersistArgs& pm = *st.pm;
+  if (PERSIST) {
+    st.foff = reinterpret_cast<const int64_t*>(pm.hdr + (size_t)cluster * pm.hdr_stride);
+    st.avail = reinterpret_cast<const int32_t*>(pm.hdr + (size_t)cluster * pm.hdr_stride + (size_t)U * 8);
+  }
+  uint32_t pseq = 0;    // PERSIST: commands taken so far (the cluster's own count, passed on through pm_go)
+  uint32_t gstep = 0;   // PERSIST: steps run by earlier pushes (parity of the cluster's row counters)
+  int launch_step0 = 0, my_cur = 0;  // PERSIST: the owned utterance's step count at launch / now
+  if (PERSIST && did_select) launch_step0 = my_cur = st.utt_step[cluster + ncl * rank];
+  uint32_t ctype = UIS_PM_PUSH;
+#if defined(UIS_PM_TIMING)  // diagnostic: phases of a push as workgroup 0 sees them, 10 ns ticks, into the mailbox
+  unsigned long long pm_t = 0, pm_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PMSTAMP(k) do { if (PERSIST && blockIdx.x == 0 && t == 0) { const unsigned long long n_ = wall_clock64(); pm_acc[k] += n_ - pm_t; pm_t = n_; } } while (0)
+#else
+#define PMSTAMP(k) do {} while (0)
+#endif
+  for (;;) {
+  int push_F = st.push_F;
+  int prow0 = 0, prows = 0;  // PERSIST: this cluster's rows of the push
+  if (PERSIST) {
+    // ---- the next command.  Rank 0 polls the mailbox (host memory), brings a push's tables and
+    // this cluster's new frames onto the device and passes the command on through pm_go (this
+    // XCD's L2); everybody drops the CU's L1 -- chunk buffers and step counters were rewritten.
+    ++pseq;
+    u32x4* go = reinterpret_cast<u32x4*>(pm.go + cluster * 16);
+    if (rank == 0) {
+      if (t == 0) {
+        const unsigned long long t0 = wall_clock64();
+        uint32_t ty = UIS_PM_IDLE, nf = 0u, polls = 0u;
+        for (;;) {
+          // this cluster's doorbell line in one 16-byte read (the host writes the sequence number last)
+          u32x4 bell;
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(bell) : "v"(pm.ctl + UIS_PM_BELL_WORD + 16 * cluster) : "memory");
+          if (bell[0] != (uint32_t)s_ctl[6]) {
+            ty = bell[1] & 0xffu; nf = bell[1] >> 8;
+            s_ctl[6] = (int)bell[0]; s_ctl[7] = (int)(bell[2] & 0xffffu); s_ctl[8] = (int)(bell[2] >> 16);
+#if defined(UIS_PM_TIMING)
+            if (blockIdx.x == 0) pm_t = wall_clock64();
+#endif
+            break;
+          }
+          if (wall_clock64() - t0 > pm.idle_ticks) break;
+          if ((++polls & 63u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ty = UIS_PM_QUIT; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        s_ctl[4] = (int)ty; s_ctl[5] = (int)nf;
+      }
+      __syncthreads();
+      ctype = (uint32_t)s_ctl[4]; push_F = s_ctl[5];
+      if (ctype == UIS_PM_PUSH) {
+        // the host packs a push cluster by cluster: this cluster's new frames are rows
+        // [prow0, prow0 + prows) of the chunk -- tables and frames cross PCIe in ONE round trip
+        prow0 = s_ctl[7]; prows = s_ctl[8];
+        const int q4 = m.D >> 2;  // (the host takes this path only when D == Dp)
+        float* xdev = const_cast<float*>(st.x);
+        int64_t* foff_c = const_cast<int64_t*>(st.foff);
+        int32_t* avail_c = const_cast<int32_t*>(st.avail);
+        for (int e = t; e < prows * q4; e += 512) {
+          const size_t row = (size_t)(prow0 + e / q4);
+          const int c4 = (e % q4) * 4;
+          *reinterpret_cast<f32x4*>(xdev + row * m.Dp + c4) = sys_load_f32x4(pm.frames + row * m.D + c4);
+        }
+        for (int u = t; u < U; u += 512) { foff_c[u] = sys_load_i64(pm.foff + u); avail_c[u] = sys_load_i32(pm.avail + u); }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      PMSTAMP(0);  // tables and frames fetched from the host
+      if (t == 0) {  // one 16-byte store: {sequence number, command | frames << 8, first row, rows}
+        const u32x4 word = {pseq, ctype | ((uint32_t)push_F << 8), (uint32_t)prow0, (uint32_t)prows};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(go), "v"(word) : "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+    } else {
+      if (t == 0) {
+        const unsigned long long t0 = wall_clock64();
+        u32x4 v = {0u, 0u, 0u, 0u};
+        uint32_t ty = UIS_PM_QUIT;
+        for (;;) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(go) : "memory");
+          if (v[0] == pseq) { ty = v[1] & 0xffu; break; }
+          if (wall_clock64() - t0 > 4 * pm.idle_ticks + 200000000ull) {  // rank 0 went missing: give up
+            __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ctl[4] = (int)ty; s_ctl[5] = (int)(v[1] >> 8); s_ctl[7] = (int)v[2]; s_ctl[8] = (int)v[3];
+      }
+      __syncthreads();
+      ctype = (uint32_t)s_ctl[4]; push_F = s_ctl[5]; prow0 = s_ctl[7]; prows = s_ctl[8];
+    }
+    if (ctype != UIS_PM_PUSH && ctype != UIS_PM_LABELS) break;
+    if (ctype == UIS_PM_LABELS) {
+      // the owned utterance's labels / scores / cap flag straight into the mailbox
+      if (did_select) {
+        const int u = cluster + ncl * rank;
+        DecodeState sl = st;
+        sl.lab_off = pm.lab_off;
+        backtrace_body(sl, u, pm.labels, pm.scores, pm.beam_scores, reinterpret_cast<unsigned char*>(spart));
+        if (t == 0) pm.overflow[u] = st.overflow[u];
+      }
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+      if (rank == 0 && t == 0) {
+        __threadfence_system();
+        __hip_atomic_store(pm.ctl + UIS_PM_DONE_WORD + 16 * cluster, (uint32_t)s_ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      continue;
+    }
+  }
+  PMSTAMP(1);  // command passed on, L1 dropped
+  {  // decode steps of this cluster = the longest of its utterances
+    if (t == 0) s_ctl[1] = 0;
+    __syncthreads();
+    int myT = 0;
+    for (int i = t; cluster + ncl * i < U; i += 512) {
+      const int u = cluster + ncl * i;
+      // streaming (uis_stream_push): the steps this utterance can run now = frames received - steps done
+      const long T = st.avail ? (long)st.avail[u] - (long)st.utt_step[u]
+                              : (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      myT = T > myT ? (int)T : myT;
+    }
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+  // a streaming session (st.avail): the utterance continues at its own step count; the beam
+  // tables are fetched from their global copies at the launch's first step and written back at its end
+  int my_step0 = 0;
+  if (keep_beam && did_select && st.avail) my_step0 = PERSIST ? my_cur : st.utt_step[cluster + ncl * rank];
+  const int first_step = PERSIST ? launch_step0 : my_step0;
+  if (push_F > 0) {
     // ---- streaming push: the chunk's once-per-frame work, by this cluster for its own utterances'
     // new frames -- gi0 = W_ih0 x + b_ih0 (k_dense_input_proj's fullk_tile per 16 rows x 16
     // features, one wave each) and mse0 (k_mse0's wave_weighted_mse, one wave per frame); same
@@ -1800,38 +1963,85 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     // not in use yet).
     int* s_prow = reinterpret_cast<int*>(s_head);
     const int prow_cap = UIS_RES_HEAD_TILES * 16 * 6;
-    if (t == 0) {
-      int n = 0;
-      for (int u = cluster; u < U; u += ncl) {
-        const int s0 = st.utt_step[u], a = st.avail[u];
-        const long f0 = (long)st.foff[u];
-        for (int k = s0; k < a && n < prow_cap; ++k) s_prow[n++] = (int)(f0 + k);
+    if (!PERSIST) {
+      // (every thread fetches one utterance's three words; thread 0 then lists from LDS)
+      const int ncu = (U - cluster + ncl - 1) / ncl, lcap = UIS_KSPLIT * UIS_RES_RC * 3 * 256 / 4;
+      int* l_s0 = reinterpret_cast<int*>(spart);
+      int* l_a = l_s0 + lcap;
+      int* l_f0 = l_a + lcap;
+      const bool staged = ncu <= lcap;
+      if (staged)
+        for (int i = t; i < ncu; i += 512) {
+          const int u = cluster + ncl * i;
+          l_s0[i] = st.utt_step[u]; l_a[i] = st.avail[u]; l_f0[i] = (int)st.foff[u];
+        }
+      __syncthreads();
+      if (t == 0) {
+        int n = 0;
+        for (int i = 0; i < ncu; ++i) {
+          const int u = cluster + ncl * i;
+          const int s0 = staged ? l_s0[i] : st.utt_step[u], a = staged ? l_a[i] : st.avail[u];
+          const long f0 = staged ? (long)l_f0[i] : (long)st.foff[u];
+          for (int k = s0; k < a && n < prow_cap; ++k) s_prow[n++] = (int)(f0 + k);
+        }
+        s_ctl[3] = n;
       }
-      s_ctl[3] = n;
+      __syncthreads();
     }
-    __syncthreads();
-    const int R = s_ctl[3];
+    // PERSIST: the host packs a push cluster by cluster, the rows are [prow0, prow0 + prows)
+    const int R = PERSIST ? prows : s_ctl[3];
+    auto chunk_row = [&](int li) -> size_t { return PERSIST ? (size_t)(prow0 + li) : (size_t)s_prow[li]; };
+    // With the beam in LDS and workgroups to spare, the projection does not get a barrier of its
+    // own: the workgroups that own an utterance compute mse0 of THEIR rows (all their first select
+    // needs) and go on to select, the others compute gi0 and meet them at the first step's barrier.
+    const int nown = keep_beam ? ((U - cluster + ncl - 1) / ncl < 32 ? (U - cluster + ncl - 1) / ncl : 32) : 32;
+    const bool overlap = keep_beam && nown < 32;
     if (R > 0) {
       const int NGT = m.G / 16;
       const int prt = (R + 15) >> 4;
       float* gi0w = const_cast<float*>(st.gi0);
       float* mse0w = const_cast<float*>(st.mse0);
-      for (int task = rank * 8 + w; task < prt * NGT; task += 256) {
-        const int rt = task / NGT, ft = task - rt * NGT;
-        int li = rt * 16 + (lane & 15);
-        const bool valid = li < R;
-        if (!valid) li = R - 1;
-        const size_t row = (size_t)s_prow[li];
-        const f32x4 v = fullk_tile(m.wih[0], ft, m.Dp / 16, st.x + row * m.Dp, m.bih[0] + ft * 16);
-        if (valid) *reinterpret_cast<f32x4*>(gi0w + row * m.G + ft * 16 + (lane >> 4) * 4) = v;
+      const int slot0 = overlap ? (rank - nown) * 8 + w : rank * 8 + w, nslots = overlap ? (32 - nown) * 8 : 256;
+      if (!overlap || !did_select) {
+        for (int task = slot0; task < prt * NGT; task += nslots) {
+          const int rt = task / NGT, ft = task - rt * NGT;
+          int li = rt * 16 + (lane & 15);
+          const bool valid = li < R;
+          if (!valid) li = R - 1;
+          const size_t row = chunk_row(li);
+          const f32x4 v = fullk_tile(m.wih[0], ft, m.Dp / 16, st.x + row * m.Dp, m.bih[0] + ft * 16);
+          if (valid) *reinterpret_cast<f32x4*>(gi0w + row * m.G + ft * 16 + (lane >> 4) * 4) = v;
+        }
       }
-      for (int i = rank * 8 + w; i < R; i += 256) {
-        const size_t row = (size_t)s_prow[i];
-        const float v = wave_weighted_mse(m.m0, st.x + row * m.Dp, m.wgt, m.Dp, m.D, lane);
-        if (lane == 0) mse0w[row] = v;
+      if (!overlap) {
+        for (int i = rank * 8 + w; i < R; i += 256) {
+          const size_t row = chunk_row(i);
+          const float v = wave_weighted_mse(m.m0, st.x + row * m.Dp, m.wgt, m.Dp, m.D, lane);
+          if (lane == 0) mse0w[row] = v;
+        }
+      } else if (did_select) {
+        const int u = cluster + ncl * rank;
+        const long f0 = (long)st.foff[u];
+        const int a = st.avail[u];
+        for (int k = my_step0 + w; k < a; k += 8) {
+          const size_t row = (size_t)(f0 + k);
+          const float v = wave_weighted_mse(m.m0, st.x + row * m.Dp, m.wgt, m.Dp, m.D, lane);
+          if (lane == 0) mse0w[row] = v;
+        }
       }
     }
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (!overlap) {
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the owner reads its mse0 back from L2)
+      __syncthreads();
+    }
+  }
+  PMSTAMP(2);  // steps counted, gi0 / mse0 of the chunk, barrier
+  if (PERSIST && did_select) {  // the owned utterance's step count after this push
+    long done = (long)st.avail[cluster + ncl * rank] - my_step0;
+    done = done < 0 ? 0 : (done > nsteps ? nsteps : done);
+    my_cur = my_step0 + (int)done;
   }
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1841,7 +2051,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #endif
 
   for (int s = 0; s < nsteps; ++s) {
-    const int par = s & 1;
+    const int par = PERSIST ? (int)((gstep + (uint32_t)s) & 1u) : (s & 1);
     sink.count = st.rx_nrows + cluster * 32 + par;
 #if defined(UIS_RESIDENT_PROBE)  // diagnostic: dependent-load latencies seen by thread 0 at the top of a step
     if (t == 0 && blockIdx.x == 0) {
@@ -1868,11 +2078,11 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       if (did_select) {
         if (s == 0) {  // (later steps: prepared while waiting for the previous step's last barrier)
           select_fast_body<512, true, true, DP, 5>(m, st, upar, cluster + ncl * rank, smem_raw, sink, ustep, my_off0, my_off1,
-                                                   SelectNoHook(), my_step0);
+                                                   SelectNoHook(), first_step);
           __syncthreads();
         }
         select_fast_body<512, true, true, DP, 2>(m, st, upar, cluster + ncl * rank, smem_raw, sink, ustep, my_off0, my_off1,
-                                                 [&]() { xcd_arrive_wave0(st, cluster, s_ctl); }, my_step0);
+                                                 [&]() { xcd_arrive_wave0(st, cluster, s_ctl); }, first_step);
       }
       __syncthreads();
     } else {
@@ -1884,6 +2094,10 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(0);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(1);
+    // PERSIST: the step count after this push goes to its global word (the next command reads it)
+    // once every workgroup has derived nsteps from the old value, i.e. behind this barrier; the
+    // next barrier drains the store
+    if (PERSIST && s == 0 && did_select && t == 0) st.utt_step[cluster + ncl * rank] = my_cur;
     if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
@@ -1967,7 +2181,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       // tables: nobody else's data), then wait
       xcd_arrive(st, cluster, s_ctl);
       select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
-                                               SelectNoHook(), my_step0);
+                                               SelectNoHook(), first_step);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(3);
@@ -1998,7 +2212,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (prep_next) {  // ... and the second half inside the next barrier
       xcd_arrive(st, cluster, s_ctl);
       select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
-                                               SelectNoHook(), my_step0);
+                                               SelectNoHook(), first_step);
     }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
@@ -2055,30 +2269,42 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
-  if (st.avail && keep_beam && did_select) {
-    // streaming: the session outlives this launch -- the beam tables (the set the NEXT step reads)
-    // and the per-slot frame counts go back to their global copies; beam_n / beam_score / the
-    // back-pointers were written step by step
-    const int u = cluster + ncl * rank;
-    long done = (long)st.avail[u] - my_step0;
-    done = done < 0 ? 0 : (done > nsteps ? nsteps : done);
-    if (done > 0) {
-      const int B = st.B, Kmax = st.Kmax;
-      const int cur = (my_step0 + (int)done) & 1;
-      const unsigned char* set = smem_raw + cur * L.set_stride;
-      const size_t bb = ((size_t)cur * U + u) * B;
-      for (int e = t; e < B * Kmax; e += 512) {
-        st.beam_slot[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_slot)[e];
-        st.beam_blk[bb * Kmax + e] = reinterpret_cast<const int*>(set + L.off_blk)[e];
-      }
-      for (int b2 = t; b2 < B; b2 += 512) {
-        st.beam_K[bb + b2] = reinterpret_cast<const int*>(set + L.off_K)[b2];
-        st.beam_last[bb + b2] = reinterpret_cast<const int*>(set + L.off_last)[b2];
-        st.beam_sum[bb + b2] = reinterpret_cast<const int*>(set + L.off_sum)[b2];
-      }
-      const int* spc = reinterpret_cast<const int*>(smem_raw + L.off_pcnt);
-      for (int sl = t; sl < S; sl += 512) st.pool_cnt[(size_t)u * S + sl] = spc[sl];
-      if (t == 0) st.utt_step[u] = my_step0 + (int)done;
+  if (!PERSIST) {
+    if (st.avail && keep_beam && did_select) {
+      // streaming: the session outlives this launch -- the beam tables (the set the NEXT step reads)
+      // and the per-slot frame counts go back to their global copies; beam_n / beam_score / the
+      // back-pointers were written step by step
+      long done = (long)st.avail[cluster + ncl * rank] - my_step0;
+      done = done < 0 ? 0 : (done > nsteps ? nsteps : done);
+      if (done > 0) write_back(my_step0 + (int)done);
+    }
+    break;
+  }
+  // ---- PERSIST: this push is done.  The owned utterance's step count goes to its global word
+  // (the next command's listing reads it), the cluster reports to the host.
+  // (the last step's closing barrier has drained everybody's stores, the step count's included)
+  gstep += (uint32_t)nsteps;
+  if (nsteps == 0 && xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;  // (nothing to run: my_cur is the old count)
+  PMSTAMP(3);  // the steps
+#if defined(UIS_PM_TIMING)
+  if (blockIdx.x == 0 && t == 0) {
+    pm_acc[5] += 1;
+    for (int k = 0; k < 6; ++k) reinterpret_cast<volatile unsigned long long*>(pm.ctl + UIS_PM_TIMING_WORD)[k] = pm_acc[k];
+  }
+#endif
+  // (a push leaves nothing in host memory but this word: no system-scope fence, which would write
+  // back the whole L2)
+  if (rank == 0 && t == 0)
+    __hip_atomic_store(pm.ctl + UIS_PM_DONE_WORD + 16 * cluster, (uint32_t)s_ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }  // command loop
+  if (PERSIST) {
+    // leaving (told to, or idle): the session goes on with ordinary launches from the global tables
+    if (did_select && my_cur > launch_step0) write_back(my_cur);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (rank == 0 && t == 0) {
+      __threadfence_system();
+      __hip_atomic_store(pm.ctl + UIS_PM_LEFT_WORD + 16 * cluster, ctype == UIS_PM_QUIT ? 1u : 2u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 #if defined(UIS_RESIDENT_PROBE)
@@ -2484,23 +2710,27 @@ __global__ void k_backtrace_window(DecodeState st, int32_t* __restrict__ labels,
 // -- B independent chains, so the loads overlap -- and records where each one leaves, (2) the
 // wave stitches the 64 maps (entry of segment l = exit of segment l-1), (3) every lane walks its
 // segment once more from its true entry rank and writes the labels.
-__global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __restrict__ labels, float* __restrict__ scores,
-                                                  float* __restrict__ beam_scores) {
-  extern __shared__ unsigned char bt_map[];  // [64][B] exit rank of entry rank r through segment l
-  const int u = blockIdx.x, lane = threadIdx.x;
-  if (u >= st.U) return;
+// The body of k_backtrace for utterance u, by wave 0 of the calling workgroup (every thread of
+// the workgroup calls it: there is one workgroup barrier inside).  bt_map: 64 * B bytes of LDS.
+__device__ __forceinline__ void backtrace_body(const DecodeState& st, int u, int32_t* __restrict__ labels,
+                                               float* __restrict__ scores, float* __restrict__ beam_scores,
+                                               unsigned char* bt_map) {
+  const int lane = threadIdx.x & 63;
+  const bool w0 = threadIdx.x < 64;
   // streaming: the frames received so far (test_iteration 1); labels go where the caller packs them
   const long N = st.avail ? (long)st.avail[u] : (long)(st.off[u + 1] - st.off[u]);
   const long T = st.avail ? N : (long)st.tau * N;
   const int par = (int)(T & 1);  // parity holding the final beam
   const int nb = N > 0 ? st.beam_n[(size_t)par * st.U + u] : 0;
   const size_t e = ((size_t)par * st.U + u) * st.B;
-  if (beam_scores)
-    for (int b = lane; b < st.B; b += 64) beam_scores[(size_t)u * st.B + b] = b < nb ? st.beam_score[e + b] : INFINITY;
-  if (scores && lane == 0) scores[u] = nb > 0 ? st.beam_score[e] : (N > 0 ? INFINITY : 0.0f);
-  if (N == 0) return;
+  if (w0) {
+    if (beam_scores)
+      for (int b = lane; b < st.B; b += 64) beam_scores[(size_t)u * st.B + b] = b < nb ? st.beam_score[e + b] : INFINITY;
+    if (scores && lane == 0) scores[u] = nb > 0 ? st.beam_score[e] : (N > 0 ? INFINITY : 0.0f);
+  }
   int32_t* out = labels + (st.lab_off ? st.lab_off[u] : st.off[u]);
-  if (nb == 0) { for (long i = lane; i < N; i += 64) out[i] = -1; return; }
+  if (w0 && N > 0 && nb == 0) for (long i = lane; i < N; i += 64) out[i] = -1;
+  const bool walk = N > 0 && nb > 0;
   const uint32_t* bp = st.bp + (size_t)st.tau * st.off[u] * st.B;
   const int B = st.B;
   // segment l: steps hi(l) .. lo(l) walked downwards, hi(0) = T - 1, the last lo = T - N
@@ -2508,7 +2738,7 @@ __global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __res
   const long hi = T - 1 - (long)lane * seg;
   long lo = hi - seg + 1;
   if (lo < T - N) lo = T - N;
-  const bool work = hi >= T - N;
+  const bool work = w0 && walk && hi >= T - N;
   unsigned char* mine = bt_map + (size_t)lane * B;
   if (work) {
     for (int r0 = 0; r0 < B; r0 += 8) {  // 8 entry ranks at a time: 8 loads in flight
@@ -2532,7 +2762,7 @@ __global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __res
   __syncthreads();
   // stitch: the entry rank of segment l (ranks < 256: select kernels cap the beam at 256)
   int entry = 0;
-  {
+  if (w0 && walk) {
     int cur = 0;  // the best hypothesis of the final beam
     for (int l = 0; l < 64; ++l) {
       if (lane == l) entry = cur;
@@ -2549,4 +2779,11 @@ __global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __res
       r = (int)(v >> 16);
     }
   }
+}
+
+__global__ __launch_bounds__(64) void k_backtrace(DecodeState st, int32_t* __restrict__ labels, float* __restrict__ scores,
+                                                  float* __restrict__ beam_scores) {
+  extern __shared__ unsigned char bt_map[];  // [64][B] exit rank of entry rank r through segment l
+  if ((int)blockIdx.x >= st.U) return;
+  backtrace_body(st, blockIdx.x, labels, scores, beam_scores, bt_map);
 }

@@ -280,13 +280,13 @@ class UISRNN:
     self._check_sequence(test_sequence)
     return self._decode_batch([test_sequence], args)[0]
 
-  def online(self, num_utterances, args, max_frames):
+  def online(self, num_utterances, args, max_frames, persistent=False):
     """An OnlineSession (streaming decode; extension, see the class)."""
     if args.look_ahead != 1:
       raise ValueError('online decoding needs look_ahead 1')
     if self.transition_bias is None:
       raise TypeError('transition_bias is None: the model was never fit or loaded')
-    return OnlineSession(self, num_utterances, args, max_frames)
+    return OnlineSession(self, num_utterances, args, max_frames, persistent)
 
   def predict(self, test_sequences, args):
     """Predict labels for one sequence or a list of them (uisrnn.py:564-590).
@@ -323,13 +323,29 @@ class OnlineSession:
       session.push([chunk_a, None])        # [n, D] float arrays; None = nothing new
       session.push([chunk_a2, chunk_b])
       labels = session.labels()            # list of lists of ints, one per utterance
+
+  persistent=True (UIS_FLAG_PERSISTENT): the decode kernel stays on the GPU between pushes and is
+  fed through a mailbox in pinned host memory -- the lowest push latency (no launch, no copy
+  engine), at the price of occupying the whole device until the session closes or has been idle
+  for UIS_PERSIST_IDLE_MS (default 50 ms).  Where the model's shape does not allow it the session
+  silently uses ordinary launches.
   """
 
-  def __init__(self, model, num_utterances, args, max_frames):
+  def __init__(self, model, num_utterances, args, max_frames, persistent=False):
     self._model = model
     self._decoder = _capi.Decoder(model.params, model.device_index)  # own handle: one session per handle
     cap = _initial_cluster_cap(args)
-    self._decoder.stream_begin(num_utterances, args.beam_size, max_frames, max_clusters=cap)
+    self.persistent = False
+    if persistent:
+      try:
+        self._decoder.stream_begin(num_utterances, args.beam_size, max_frames, max_clusters=cap,
+                                   flags=_capi.UIS_FLAG_PERSISTENT)
+        self.persistent = True
+      except _capi.HipLibraryError as err:
+        if err.status != _capi.UIS_ERR_UNSUPPORTED:
+          raise
+    if not self.persistent:
+      self._decoder.stream_begin(num_utterances, args.beam_size, max_frames, max_clusters=cap)
     self._open = True
 
   def push(self, chunks):
