@@ -349,6 +349,41 @@ def write_probes(uisrnn):
   q = seq.copy(); q[4, 0] = np.float64(m0[0])
   out['first_component_equals_m0_frame4'] = run(q)
   out['clean'] = run(seq)
+  # exact ties (np.argsort's order among equal scores, uisrnn.py:549).  An
+  # all-zero network makes every cluster mean exactly 0, so candidates differ by their priors only;
+  # with crp_alpha 1 "a new cluster" and "back to a cluster seen in one block" tie exactly, from
+  # the third frame on.  The decoder's rule is lowest flat index first: recorded here is what the
+  # reference does on this stack (numpy's argsort), for beams whose flattened score arrays are
+  # shorter and longer than the 16 elements below which numpy's quicksort is an insertion sort.
+  sys.path.insert(0, os.path.join(REPO, "tests"))
+  from golden_util import tie_probe_case  # pylint: disable=import-outside-toplevel
+  ties = []
+  # spec = (observation_dim, rnn_hidden_size, beam_size, frames, seed, look_ahead)
+  for spec in ((4, 4, 3, 10, 0, 1), (4, 4, 10, 14, 2, 1), (4, 4, 10, 30, 3, 1), (6, 8, 20, 40, 4, 1),
+               (4, 4, 3, 9, 5, 2), (4, 4, 6, 12, 6, 2), (4, 4, 4, 10, 7, 3)):
+    tie_params, tie_seq = tie_probe_case(*spec[:5])
+    tie_model, tie_args = reference_model(uisrnn, tie_params)
+    tie_args.beam_size, tie_args.look_ahead, tie_args.test_iteration = spec[2], spec[5], 1
+    ties.append({'spec': list(spec), 'labels': [int(v) for v in tie_model.predict(tie_seq, tie_args)]})
+  out['exact_ties'] = ties
+  # ... and where it does NOT: with crp_alpha 2 or 3 more candidates tie at once, and numpy's
+  # argsort (AVX-512 / introsort above 16 elements, not stable) picks another of the equally good
+  # ones than lowest-index-first.  Recorded: both label sequences and what the REFERENCE's own
+  # _update_beam_state (uisrnn.py:388-453) scores them at -- the same float32, bit for bit.
+  from make_trained import rescore_with_reference  # pylint: disable=import-outside-toplevel
+  unstable = []
+  for alpha, spec in ((2.0, (4, 4, 30, 30, 12, 1)), (2.0, (4, 4, 5, 12, 13, 2)), (3.0, (4, 4, 30, 30, 12, 1))):
+    tie_params, tie_seq = tie_probe_case(*spec[:5])
+    tie_params['crp_alpha'] = alpha
+    tie_model, tie_args = reference_model(uisrnn, tie_params)
+    tie_args.beam_size, tie_args.look_ahead, tie_args.test_iteration = spec[2], spec[5], 1
+    theirs = [int(v) for v in tie_model.predict(tie_seq, tie_args)]
+    ours = oracle.decode(tie_params, [tie_seq], spec[2], spec[5], 1)['labels'][0].tolist()
+    unstable.append({'spec': list(spec), 'crp_alpha': alpha, 'reference_labels': theirs, 'decoder_labels': ours,
+                     'reference_labels_rescored': rescore_with_reference(tie_model, tie_seq, theirs, 1),
+                     'decoder_labels_rescored': rescore_with_reference(tie_model, tie_seq, ours, 1)})
+  out['exact_ties_unstable'] = unstable
+  out['stack'] = 'numpy {} on a CPU with AVX-512 (np.argsort of float64: x86-simd-sort)'.format(np.__version__)
   with open(os.path.join(HERE, 'probes.json'), 'w') as f:
     json.dump(out, f, indent=1)
   print(json.dumps(out, indent=1))

@@ -129,3 +129,21 @@ def load_case(name):
   unit = {k: data[k] for k in ('unit_x', 'unit_h', 'unit_mean', 'unit_hout',
                                'mse_a', 'mse_b', 'mse_val')}
   return {'params': params, 'seqs': seqs, 'runs': runs, 'unit': unit}
+
+
+def tie_probe_case(dim, hidden, beam, n_frames, seed):
+  """The exact-tie probe of tests/golden/probes.json: an all-zero network (every cluster mean is
+  exactly 0: candidates differ by their priors only), crp_alpha 1, transition_bias 0.9 (switching
+  preferred), so that "a new cluster" and "back to a cluster seen in one block" tie exactly.
+  Returns (params, sequence); `beam` is part of the spec only."""
+  del beam
+  from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel
+  params = weights.init_params(dim, hidden, 1, sigma2=0.5, transition_bias=0.9, seed=seed)
+  for key, value in list(params.items()):
+    if isinstance(value, np.ndarray) and value.dtype == np.float32 and key != 'sigma2':
+      params[key] = np.zeros_like(value)
+    if isinstance(value, list):
+      params[key] = [np.zeros_like(a) for a in value]
+  params['crp_alpha'] = 1.0
+  seq = np.random.default_rng(seed).standard_normal((n_frames, dim))
+  return params, seq

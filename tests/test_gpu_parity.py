@@ -248,6 +248,38 @@ def test_quirk7_zero_first_difference_on_the_device(oracle_lib):
   assert ref2['labels'][0].tolist()[1] != 0      # staying in cluster 0 was non-finite: a new one opens
 
 
+def test_exact_ties_on_the_device(oracle_lib):
+  """Exactly equal candidate scores (tests/golden/probes.json 'exact_ties', recorded from the
+  reference): the select kernels' lowest-flat-index rule gives the reference's labels, on the
+  one-launch path (no: these tiny shapes run launch-per-step), the fast and the general select."""
+  import json
+  import os
+  with open(os.path.join(golden_util.GOLDEN_DIR, 'probes.json')) as f:
+    probes = json.load(f)
+  for probe in probes['exact_ties']:
+    dim, hidden, beam, n_frames, seed, look = probe['spec']
+    params, seq = golden_util.tie_probe_case(dim, hidden, beam, n_frames, seed)
+    dec = _capi.Decoder(params)
+    frames, offsets = oracle_lib.pack([seq])
+    ref = oracle_lib.decode(params, [seq], beam, look, 1)
+    for flags in (0, _capi.UIS_FLAG_GENERIC_SELECT):
+      out = dec.decode(frames, offsets, beam, look, 1, want_beam_scores=True, flags=flags)
+      assert out['status'] == 0
+      assert out['labels'].tolist() == probe['labels'], (probe['spec'], flags)
+      assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  for probe in probes['exact_ties_unstable']:   # (the reference's unstable argsort chose differently: equal scores)
+    dim, hidden, beam, n_frames, seed, look = probe['spec']
+    params, seq = golden_util.tie_probe_case(dim, hidden, beam, n_frames, seed)
+    params['crp_alpha'] = probe['crp_alpha']
+    dec = _capi.Decoder(params)
+    frames, offsets = oracle_lib.pack([seq])
+    ref = oracle_lib.decode(params, [seq], beam, look, 1)
+    out = dec.decode(frames, offsets, beam, look, 1, max_clusters=32, want_beam_scores=True)
+    assert out['status'] == 0
+    assert out['labels'].tolist() == probe['decoder_labels'], probe['spec']
+    assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+
+
 def test_level_capacity_is_reported_not_retried(oracle_lib):
   """look_ahead >= 2: when a window has more live prefixes than an intermediate level holds the
   call fails with UIS_ERR_UNSUPPORTED and says so (doubling max_clusters could not help)."""

@@ -165,6 +165,37 @@ def test_trained_toy4_accuracy_is_one(oracle_lib):
   assert acc == 1.0
 
 
+def test_exact_ties_are_broken_like_the_reference_does(oracle_lib):
+  """probes.json 'exact_ties': candidates with EXACTLY equal scores (an all-zero network, priors
+  only; quirk 8, uisrnn.py:549 np.argsort).  The reference's choice on this stack equals the
+  decoder's rule -- lowest flat index first -- for score arrays on both sides of numpy's
+  16-element insertion-sort threshold."""
+  import json
+  import os
+  with open(os.path.join(golden_util.GOLDEN_DIR, 'probes.json')) as f:
+    probes = json.load(f)
+  assert len(probes['exact_ties']) >= 4
+  for probe in probes['exact_ties']:
+    dim, hidden, beam, n_frames, seed, look = probe['spec']
+    params, seq = golden_util.tie_probe_case(dim, hidden, beam, n_frames, seed)
+    out = oracle_lib.decode(params, [seq], beam, look, 1)
+    assert out['labels'][0].tolist() == probe['labels'], probe['spec']
+    assert len(set(probe['labels'])) > 1     # (not the trivial all-zeros answer)
+  # ... and where numpy's unstable argsort picks ANOTHER of the equally good candidates (more of
+  # them tie at once with crp_alpha 2 / 3): the decoder's labels differ from the reference's, and
+  # the reference's own scorer gives both sequences the same float32 (recorded by make_golden.py)
+  assert len(probes['exact_ties_unstable']) >= 3
+  for probe in probes['exact_ties_unstable']:
+    dim, hidden, beam, n_frames, seed, look = probe['spec']
+    params, seq = golden_util.tie_probe_case(dim, hidden, beam, n_frames, seed)
+    params['crp_alpha'] = probe['crp_alpha']
+    out = oracle_lib.decode(params, [seq], beam, look, 1)
+    assert out['labels'][0].tolist() == probe['decoder_labels'], probe['spec']
+    assert probe['decoder_labels'] != probe['reference_labels']
+    assert np.float32(probe['decoder_labels_rescored']) == np.float32(probe['reference_labels_rescored'])
+    assert abs(float(out['scores'][0]) - probe['reference_labels_rescored']) <= 1e-4 * abs(probe['reference_labels_rescored'])
+
+
 def test_reference_probes_at_the_edges(oracle_lib):
   """tests/golden/probes.json (make_golden.py --probes): what the reference does on a frame whose
   first component equals m0[0] (loss_func.py:36,41 -> the fresh-cluster candidate is inf) and on
