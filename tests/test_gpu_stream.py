@@ -203,6 +203,34 @@ def test_persistent_launch_leaves_when_idle_and_comes_back(oracle_lib, monkeypat
   assert np.array_equal(_bits(beam), _bits(off['beam_scores']))
 
 
+def test_persistent_launch_rows_that_change_hands_between_pushes(oracle_lib):
+  """Ragged counts (0 .. 16 frames per utterance and push, 64 utterances, back-to-back pushes
+  without label requests in between): which cluster a chunk row belongs to would change from push
+  to push if the clusters did not own fixed row ranges -- and a stale dirty line left in the
+  previous owner's XCD-private L2 would then be free to overwrite the new owner's data (this
+  test caught exactly that: rare score differences, never on uniform pushes)."""
+  params = synth.tracker_params(256, 512, 1, seed=33)
+  rng = np.random.default_rng(7)
+  lens = [int(x) for x in rng.integers(40, 160, size=64)]
+  seqs, _ = synth.make_utterances(12_700, len(lens), lens, 256)
+  dec = _capi.Decoder(params)
+  off, offsets = _offline(dec, seqs, 10)
+  for rep in range(3):
+    left = list(lens)
+    schedule = []
+    while any(left):
+      top = int(rng.choice([1, 5, 16]))
+      counts = [int(min(n, rng.integers(0, top + 1))) for n in left]
+      left = [n - c for n, c in zip(left, counts)]
+      if any(counts):
+        schedule.append(counts)
+    labels, scores, overflow, status, beam = _stream(dec, seqs, 10, schedule, max(lens), flags=_capi.UIS_FLAG_PERSISTENT)
+    assert status == 0 and not overflow.any()
+    for u in range(len(seqs)):
+      assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]]), (rep, u)
+    assert np.array_equal(_bits(beam), _bits(off['beam_scores'])), rep
+
+
 def test_persistent_flag_is_refused_where_it_cannot_work():
   params = weights.init_params(20, 24, 1, sigma2=0.08, transition_bias=0.2, seed=4)
   dec = _capi.Decoder(params)

@@ -127,6 +127,7 @@ struct uis_handle {
     size_t h_stage_cap = 0;
     DecodeState st{};
     int32_t* d_avail = nullptr;
+    int32_t* d_have = nullptr;        // frames received per utterance, refreshed for every back-trace
     int64_t* d_foff = nullptr;
     int64_t* d_lab_off = nullptr;
     float* d_beam_scores = nullptr;
@@ -142,7 +143,8 @@ struct uis_handle {
     bool pm_running = false;          // the launch is on the device
     unsigned char* pm_block = nullptr;
     uint32_t pm_seq = 0;              // commands issued to the running launch
-    int64_t pm_cap_frames = 0;        // frames one push can carry through the mailbox
+    int64_t pm_cap_frames = 0;        // rows of the mailbox's frame area = ncl * pm_cluster_rows
+    int64_t pm_cluster_rows = 0;      // each cluster's FIXED share of the chunk buffers (rows), see uis_stream_begin
     size_t pm_o_foff = 0, pm_o_avail = 0, pm_o_laboff = 0, pm_o_frames = 0, pm_o_labels = 0, pm_o_scores = 0,
            pm_o_bscores = 0, pm_o_overflow = 0;
     unsigned long long* d_go = nullptr;
@@ -177,12 +179,14 @@ namespace {
 inline volatile uint32_t* pm_ctl(uis_handle::Stream& ss) { return reinterpret_cast<volatile uint32_t*>(ss.pm_block); }
 
 // every cluster's doorbell: command words first, then the sequence numbers
-void pm_ring(uis_handle::Stream& ss, uint32_t seq, uint32_t type, uint32_t frames, const uint32_t* row0) {
+void pm_ring(uis_handle::Stream& ss, uint32_t seq, uint32_t type, uint32_t frames, const uint32_t* row0 = nullptr,
+             const uint32_t* nrow = nullptr) {
   volatile uint32_t* ctl = pm_ctl(ss);
   const int ncl = ss.st.ncl;
   for (int c = 0; c < ncl; ++c) {
     ctl[UIS_PM_BELL_WORD + 16 * c + 1] = type | (frames << 8);
-    ctl[UIS_PM_BELL_WORD + 16 * c + 2] = row0 ? (row0[c] | ((row0[c + 1] - row0[c]) << 16)) : 0u;
+    ctl[UIS_PM_BELL_WORD + 16 * c + 2] = row0 ? (row0[c] | (nrow[c] << 16)) : 0u;
+    ctl[UIS_PM_BELL_WORD + 16 * c + 3] = seq;
   }
   std::atomic_thread_fence(std::memory_order_release);
   for (int c = 0; c < ncl; ++c) ctl[UIS_PM_BELL_WORD + 16 * c] = seq;
@@ -906,7 +910,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream_state.pm_running) {  // tell the resident launch to leave before waiting for the stream
-    pm_ring(h->stream_state, h->stream_state.pm_seq + 1, UIS_PM_QUIT, 0, nullptr);
+    pm_ring(h->stream_state, h->stream_state.pm_seq + 1, UIS_PM_QUIT, 0);
     h->stream_state.pm_running = false;
   }
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1211,7 +1215,8 @@ int pm_launch(uis_handle* h) {
 // launch that left while the command was on its way is reaped and the command issued again to a
 // new one -- harmless: a cluster that did take a push has nothing left to do for it.
 // Returns UIS_OK, an error, or 1 = not running and may_launch was false.
-int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, const uint32_t* row0 = nullptr) {
+int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, const uint32_t* row0 = nullptr,
+               const uint32_t* nrow = nullptr) {
   uis_handle::Stream& ss = h->stream_state;
   volatile uint32_t* ctl = pm_ctl(ss);
   const int ncl = ss.st.ncl;
@@ -1221,11 +1226,11 @@ int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, c
       if (!may_launch) return 1;
       for (int i = 0; i < UIS_PM_CTL_WORDS; ++i) ctl[i] = 0;
       ss.pm_seq = 1;
-      pm_ring(ss, 1, type, frames, row0);
+      pm_ring(ss, 1, type, frames, row0, nrow);
       if ((rc = pm_launch(h))) return rc;
     } else {
       ss.pm_seq += 1;
-      pm_ring(ss, ss.pm_seq, type, frames, row0);
+      pm_ring(ss, ss.pm_seq, type, frames, row0, nrow);
     }
     ss.pm_commands += 1;
     const double t0 = pm_now_s();
@@ -1243,7 +1248,7 @@ int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, c
     // a cluster left before (or instead of) completing the command: tell the others to leave too
     // (they complete this command first if they had not seen it yet), then look at what happened
     ss.pm_seq += 1;
-    pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0, nullptr);
+    pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0);
     if ((rc = pm_reap(h))) return rc;
     if (!left) return fail(UIS_ERR_HIP, "the persistent streaming launch did not answer within 10 s");
   }
@@ -1254,7 +1259,7 @@ int pm_quit(uis_handle* h) {
   uis_handle::Stream& ss = h->stream_state;
   if (!ss.pm_running) return UIS_OK;
   ss.pm_seq += 1;
-  pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0, nullptr);
+  pm_ring(ss, ss.pm_seq, UIS_PM_QUIT, 0);
   return pm_reap(h);
 }
 
@@ -1303,6 +1308,7 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   SALLOC(st.utt_step, U, false);
   SALLOC(st.overflow, U, false);
   SALLOC(ss.d_avail, U, true);
+  SALLOC(ss.d_have, U, true);
   SALLOC(ss.d_foff, U, true);
   SALLOC(ss.d_lab_off, U, true);
   SALLOC(d_logblk, max_frames + 2, false);
@@ -1345,7 +1351,13 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
                                        "observation_dim 256 / 512 or 256 with 256, unpadded), at most one utterance per compute "
                                        "unit and n_utt * max_frames <= 64 M labels");
     }
-    ss.pm_cap_frames = std::min<int64_t>((int64_t)U * 16, (int64_t)UIS_RES_HEAD_TILES * 16 * 6);
+    // Every cluster gets a FIXED row range of the chunk buffers (x, gi0, mse0) and of the mailbox's
+    // frame area: room for 16 frames of each of its utterances.  Fixed, because the launch never
+    // ends between pushes: a row that changed hands from one push to the next would leave a stale
+    // dirty line in the previous owner's XCD-private L2, free to be written back over the new
+    // owner's data at any time (seen as rare score differences before the ranges were fixed).
+    ss.pm_cluster_rows = std::min<int64_t>(round_up(((U + ncl - 1) / ncl) * 16, 32), (int64_t)UIS_RES_HEAD_TILES * 16 * 6);
+    ss.pm_cap_frames = ss.pm_cluster_rows * ncl;
     size_t o = (size_t)UIS_PM_CTL_WORDS * 4;
     auto take = [&](size_t bytes) { o = (o + 127) & ~(size_t)127; const size_t r = o; o += bytes; return r; };
     ss.pm_o_foff = take((size_t)U * 8);
@@ -1415,7 +1427,16 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
 #if defined(UIS_PM_TIMING)
   const double t_enter = pm_now_s();
 #endif
-  if (ss.persist && !h->resident_off && F <= ss.pm_cap_frames) {
+  bool pm_fits = ss.persist && !h->resident_off;
+  if (pm_fits) {  // every cluster's new frames must fit its fixed row range
+    const int ncl = ss.st.ncl;
+    for (int c = 0; c < ncl && pm_fits; ++c) {
+      int64_t rows = 0;
+      for (int u = c; u < U; u += ncl) rows += counts[u];
+      pm_fits = rows <= ss.pm_cluster_rows;
+    }
+  }
+  if (pm_fits) {
     // ---- the launch that stays on the device: tables and frames into the mailbox, ring, wait
     int64_t* p_foff = reinterpret_cast<int64_t*>(ss.pm_block + ss.pm_o_foff);
     int32_t* p_avail = reinterpret_cast<int32_t*>(ss.pm_block + ss.pm_o_avail);
@@ -1425,9 +1446,10 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
     uint32_t row0[UIS_PM_MAX_CLUSTERS + 1];
     std::vector<int64_t> src(U + 1, 0);  // where utterance u's frames start in the caller's buffer
     for (int u = 0; u < U; ++u) src[u + 1] = src[u] + counts[u];
-    int64_t pos = 0;
+    uint32_t nrow[UIS_PM_MAX_CLUSTERS];
     float* dst = reinterpret_cast<float*>(ss.pm_block + ss.pm_o_frames);
     for (int c = 0; c < ncl; ++c) {
+      int64_t pos = (int64_t)c * ss.pm_cluster_rows;  // the cluster's fixed range
       row0[c] = (uint32_t)pos;
       for (int u = c; u < U; u += ncl) {
         p_foff[u] = pos - ss.have[u];
@@ -1435,15 +1457,15 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
         if (counts[u]) memcpy(dst + (size_t)pos * m.D, frames + (size_t)src[u] * m.D, (size_t)counts[u] * m.D * 4);
         pos += counts[u];
       }
+      nrow[c] = (uint32_t)(pos - (int64_t)c * ss.pm_cluster_rows);
     }
-    row0[ncl] = (uint32_t)pos;
     h->inlaunch_failed = false;
 #if defined(UIS_PM_TIMING)
     static double fill_s = 0.0, wait_s = 0.0; static long n_push = 0;
     const double t_mid = pm_now_s();
     fill_s += t_mid - t_enter;
 #endif
-    rc = pm_command(h, UIS_PM_PUSH, (uint32_t)F, true, row0);
+    rc = pm_command(h, UIS_PM_PUSH, (uint32_t)std::min<int64_t>(F, 4095), true, row0, nrow);
 #if defined(UIS_PM_TIMING)
     wait_s += pm_now_s() - t_mid;
     if (++n_push % 100 == 0) {
@@ -1605,7 +1627,12 @@ UIS_EXPORT int32_t uis_stream_labels(uis_handle* h, int32_t* labels_out, float* 
   if ((rc = ss.labels.ensure((size_t)std::max<int64_t>(F, 1) * 4))) return rc;
   if ((rc = ss.scores.ensure((size_t)U * 4))) return rc;
   HIPCHK(hipMemcpyAsync(ss.d_lab_off, lab_off.data(), (size_t)U * 8, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_backtrace, dim3(U), dim3(64), (size_t)64 * ss.B, h->stream, ss.st, ss.labels.as<int32_t>(),
+  // frames received = steps run, from the host's own count: the `avail` table of the last push may
+  // live in a chunk buffer this path did not fill (pushes taken by the persistent launch)
+  HIPCHK(hipMemcpyAsync(ss.d_have, ss.have.data(), (size_t)U * 4, hipMemcpyHostToDevice, h->stream));
+  DecodeState stl = ss.st;
+  stl.avail = ss.d_have;
+  hipLaunchKernelGGL(k_backtrace, dim3(U), dim3(64), (size_t)64 * ss.B, h->stream, stl, ss.labels.as<int32_t>(),
                      ss.scores.as<float>(), ss.d_beam_scores);
   HIPCHK(hipGetLastError());
   if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, ss.labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));

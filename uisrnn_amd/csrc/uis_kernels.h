@@ -35,7 +35,7 @@ struct RnnRow {
 #define UIS_PM_IDLE 4u          // (kernel-side only: nothing arrived for pm_idle_ticks)
 #define UIS_PM_MAX_CLUSTERS 16
 // the mailbox's control words (uint32 view of the block's first bytes), one 64-byte line each:
-#define UIS_PM_BELL_WORD 0      // + 16 c: cluster c's doorbell {sequence number, command | frames << 8, first row | rows << 16, 0}
+#define UIS_PM_BELL_WORD 0      // + 16 c: cluster c's doorbell {sequence number, command | frames << 8, first row | rows << 16, sequence number again}
 #define UIS_PM_DONE_WORD 256    // + 16 c: sequence number of the last command cluster c completed
 #define UIS_PM_LEFT_WORD 512    // + 16 c: non-zero once cluster c has left the kernel (1 told to, 2 idle)
 #define UIS_PM_TIMING_WORD 768  // 6 x uint64 of the -DUIS_PM_TIMING build
@@ -70,7 +70,7 @@ struct PersistArgs {
   float* scores;            // [U]
   float* beam_scores;       // [U][B]
   int32_t* overflow;        // [U]
-  unsigned long long* go;   // device, one 128-byte line per cluster: {sequence number, command | frames << 8, first row, rows}
+  unsigned long long* go;   // device, one 128-byte line per cluster, one 64-bit word: sequence number (16 bits) | command (4) | frames (12) | first row (16) | rows (16)
   unsigned char* hdr;       // device, per cluster: [foff U x 8][avail U x 4]; stride hdr_stride
   size_t hdr_stride;
   unsigned long long idle_ticks;  // 10 ns ticks without a command after which the launch ends by itself

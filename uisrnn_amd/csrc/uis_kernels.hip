@@ -1197,7 +1197,10 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const int C = sbase[nb];
 
   // ---- round trip 2: this thread's candidate (prior-table entries), then the cluster states
-  const float mse_new = st.mse0[frame];
+  // (resident decode: a streaming push's mse0 is written by this workgroup moments earlier, and a
+  // plain uniform load would go through the scalar cache, which neighbouring CUs may share and may
+  // have filled with this line before the write)
+  const float mse_new = RES ? __hip_atomic_load(st.mse0 + frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st.mse0[frame];
   int my_b = 0, my_c = 0;
   double my_lb = 0.0, my_ld = 0.0;
   if (tid < C) {
@@ -1847,7 +1850,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     // this cluster's new frames onto the device and passes the command on through pm_go (this
     // XCD's L2); everybody drops the CU's L1 -- chunk buffers and step counters were rewritten.
     ++pseq;
-    u32x4* go = reinterpret_cast<u32x4*>(pm.go + cluster * 16);
+    unsigned long long* go = pm.go + cluster * 16;
     if (rank == 0) {
       if (t == 0) {
         const unsigned long long t0 = wall_clock64();
@@ -1856,7 +1859,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           // this cluster's doorbell line in one 16-byte read (the host writes the sequence number last)
           u32x4 bell;
           asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(bell) : "v"(pm.ctl + UIS_PM_BELL_WORD + 16 * cluster) : "memory");
-          if (bell[0] != (uint32_t)s_ctl[6]) {
+          if (bell[0] != (uint32_t)s_ctl[6] && bell[3] == bell[0]) {  // (word 3 = the number again, written first: no torn line)
             ty = bell[1] & 0xffu; nf = bell[1] >> 8;
             s_ctl[6] = (int)bell[0]; s_ctl[7] = (int)(bell[2] & 0xffffu); s_ctl[8] = (int)(bell[2] >> 16);
 #if defined(UIS_PM_TIMING)
@@ -1890,20 +1893,23 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       PMSTAMP(0);  // tables and frames fetched from the host
-      if (t == 0) {  // one 16-byte store: {sequence number, command | frames << 8, first row, rows}
-        const u32x4 word = {pseq, ctype | ((uint32_t)push_F << 8), (uint32_t)prow0, (uint32_t)prows};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(go), "v"(word) : "memory");
+      if (t == 0) {  // ONE 64-bit atomic: sequence number (16 bits) | command (4) | frames (12) | first row (16) | rows (16)
+        const unsigned long long word = (unsigned long long)(pseq & 0xffffu) | ((unsigned long long)(ctype & 0xfu) << 16) |
+                                        ((unsigned long long)((uint32_t)push_F & 0xfffu) << 20) |
+                                        ((unsigned long long)((uint32_t)prow0 & 0xffffu) << 32) | ((unsigned long long)((uint32_t)prows & 0xffffu) << 48);
+        __hip_atomic_store(go, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_s_dcache_inv();  // (uniform addresses are read through the scalar cache: tables, step counters)
       }
       __syncthreads();
     } else {
       if (t == 0) {
         const unsigned long long t0 = wall_clock64();
-        u32x4 v = {0u, 0u, 0u, 0u};
+        unsigned long long v = 0;
         uint32_t ty = UIS_PM_QUIT;
         for (;;) {
-          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(go) : "memory");
-          if (v[0] == pseq) { ty = v[1] & 0xffu; break; }
+          v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(v & 0xffffu) == (pseq & 0xffffu)) { ty = (uint32_t)(v >> 16) & 0xfu; break; }
           if (wall_clock64() - t0 > 4 * pm.idle_ticks + 200000000ull) {  // rank 0 went missing: give up
             __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -1911,7 +1917,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_ctl[4] = (int)ty; s_ctl[5] = (int)(v[1] >> 8); s_ctl[7] = (int)v[2]; s_ctl[8] = (int)v[3];
+        __builtin_amdgcn_s_dcache_inv();  // (uniform addresses are read through the scalar cache: tables, step counters)
+        s_ctl[4] = (int)ty; s_ctl[5] = (int)((v >> 20) & 0xfffu); s_ctl[7] = (int)((v >> 32) & 0xffffu); s_ctl[8] = (int)(v >> 48);
       }
       __syncthreads();
       ctype = (uint32_t)s_ctl[4]; push_F = s_ctl[5]; prow0 = s_ctl[7]; prows = s_ctl[8];
