@@ -36,11 +36,18 @@ _RANK_SCRIPT = textwrap.dedent('''
 def test_timed_region_world_2_gloo(tmp_path):
   script = tmp_path / 'rank.py'
   script.write_text(_RANK_SCRIPT.format(root=ROOT))
-  port = 29500 + os.getpid() % 400
-  out = subprocess.run(
-      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-       '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
-      capture_output=True, text=True, timeout=300, cwd=ROOT)
+  import socket
+  out = None
+  for attempt in range(3):   # (a port the OS just handed out can still lose a race with another process)
+    with socket.socket() as sock:
+      sock.bind(('127.0.0.1', 0))
+      port = sock.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    if out.returncode == 0 or 'address already in use' not in out.stderr.lower():
+      break
   assert out.returncode == 0, out.stderr[-3000:]
   import json
   recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
