@@ -231,6 +231,24 @@ def test_persistent_launch_rows_that_change_hands_between_pushes(oracle_lib):
     assert np.array_equal(_bits(beam), _bits(off['beam_scores'])), rep
 
 
+def test_cluster_cap_in_a_session_is_reported_by_every_path(oracle_lib):
+  """A hypothesis that outgrows max_clusters: uis_stream_labels returns UIS_ERR_CLUSTER_CAP and the
+  per-utterance flags, from the per-step kernels, the one launch per push and the resident launch
+  (whose flags travel through the mailbox); the utterance that fits still has the oracle's labels."""
+  params = weights.init_params(256, 512, 1, sigma2=0.5, transition_bias=0.5, crp_alpha=50.0, seed=15)
+  rng = np.random.default_rng(16)
+  seqs = [rng.standard_normal((30, 256)), rng.standard_normal((2, 256)), rng.standard_normal((25, 256))]
+  ref = oracle_lib.decode(params, seqs, 8, 1, 1, n_threads=3)
+  assert ref['max_clusters'][0] > 8 and ref['max_clusters'][1] <= 8
+  dec = _capi.Decoder(params)
+  schedule = [[5, 2, 5]] + [[5, 0, 5]] * 4 + [[5, 0, 0]]
+  for flags in (_capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_RESIDENT, _capi.UIS_FLAG_PERSISTENT):
+    labels, scores, overflow, status, _ = _stream(dec, seqs, 8, schedule, 30, max_clusters=8, flags=flags)
+    assert status == _capi.UIS_ERR_CLUSTER_CAP, flags
+    assert overflow.tolist() == [1, 0, 1], flags
+    assert np.array_equal(labels[1], ref['labels'][1])
+
+
 def test_persistent_flag_is_refused_where_it_cannot_work():
   params = weights.init_params(20, 24, 1, sigma2=0.08, transition_bias=0.2, seed=4)
   dec = _capi.Decoder(params)
