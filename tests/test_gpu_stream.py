@@ -317,6 +317,11 @@ def test_python_online_session_matches_predict():
     assert session.labels() == offline
     with pytest.raises(TypeError):
       session.push([seqs[0].astype(np.float32), None, None])   # the reference's float64 rule
+  block = np.stack([s[:20] for s in seqs])            # [U, n, D]: every utterance gets the same count
+  with model.online(3, inference_args, max_frames=64) as session:
+    session.push(block[:, :7])
+    session.push(block[:, 7:])
+    assert session.labels() == [x[:20] for x in model.predict([s[:20] for s in seqs], inference_args)]
   with model.online(3, inference_args, max_frames=64, persistent=True) as session:
     assert session.persistent
     for lo in range(0, 50, 5):

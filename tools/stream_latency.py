@@ -21,15 +21,20 @@ for name, flags in (('persistent_launch', _capi.UIS_FLAG_PERSISTENT), ('one_laun
   dec.stream_begin(n_utt, 10, n_push + 64 * 16, flags=flags)
   for t in range(20):  # warm-up
     dec.stream_push([s[t:t + 1] for s in seqs])
-  lat, lat_c = [], []
+  lat, lat_c, lat_block = [], [], []
   import ctypes
   ones = np.ones(n_utt, dtype=np.int32)
   for t in range(20, n_push):
     chunks = [s[t:t + 1] for s in seqs]
-    if t % 2:   # through the Python host (packs the chunks with numpy)
+    if t % 4 == 1:   # through the Python host (packs the chunks with numpy)
       t0 = time.perf_counter()
       dec.stream_push(chunks)
       lat.append(time.perf_counter() - t0)
+    elif t % 4 == 3:  # through the Python host, one [U, 1, D] float64 array
+      block = np.stack(chunks)
+      t0 = time.perf_counter()
+      dec.stream_push(block)
+      lat_block.append(time.perf_counter() - t0)
     else:       # the C entry point alone, frames already packed
       flat = np.ascontiguousarray(np.concatenate(chunks), dtype=np.float32)
       t0 = time.perf_counter()
@@ -64,6 +69,7 @@ for name, flags in (('persistent_launch', _capi.UIS_FLAG_PERSISTENT), ('one_laun
   lat, chunk_lat, lat_c, chunk_lat_c = np.array(lat) * 1e6, np.array(chunk_lat) * 1e6, np.array(lat_c) * 1e6, np.array(chunk_lat_c) * 1e6
   out[name] = {'push_1_frame_us_median_c_abi': round(float(np.median(lat_c)), 1),
                'push_1_frame_us_median': round(float(np.median(lat)), 1),
+               'push_1_frame_us_median_python_block': round(float(np.median(lat_block)) * 1e6, 1),
                'push_1_frame_us_p90': round(float(np.percentile(lat, 90)), 1),
                'push_16_frames_us_median_c_abi': round(float(np.median(chunk_lat_c)), 1),
                'push_16_frames_us_median': round(float(np.median(chunk_lat)), 1),

@@ -382,10 +382,23 @@ class Decoder:
     self._stream_have = np.zeros(int(n_utt), dtype=np.int64)
 
   def stream_push(self, chunks):
-    """chunks: one [n_u, D] array (or None / empty) per utterance: its new frames."""
+    """chunks: one [n_u, D] array (or None / empty) per utterance: its new frames -- or ONE
+    [n_utt, n, D] array when every utterance has the same number of new frames (one cast, no
+    per-utterance Python work: the low-latency way to feed a live session)."""
     if len(chunks) != self._stream_n:
       raise ValueError('one chunk (or None) per utterance')
     dim = self.observation_dim
+    if isinstance(chunks, np.ndarray) and chunks.ndim == 3:
+      if chunks.shape[2] != dim:
+        raise ValueError('chunk does not match observation_dim')
+      frames = np.ascontiguousarray(chunks, dtype=np.float32)
+      counts = np.full(self._stream_n, chunks.shape[1], dtype=np.int32)
+      rc = self._lib.uis_stream_push(
+          self._handle, frames.ctypes.data_as(_fp) if frames.size else None,
+          counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+      self._check(rc, 'uis_stream_push')
+      self._stream_have += counts
+      return
     parts, counts = [], np.zeros(self._stream_n, dtype=np.int32)
     for u, chunk in enumerate(chunks):
       if chunk is None or len(chunk) == 0:

@@ -349,9 +349,15 @@ class OnlineSession:
     self._open = True
 
   def push(self, chunks):
-    for chunk in chunks:
-      if chunk is not None and len(chunk):
-        self._model._check_sequence(np.asarray(chunk))
+    """chunks: a list with one [n, D] float64 array (or None) per utterance, or one [U, n, D]
+    float64 array when every utterance received the same number of frames."""
+    if isinstance(chunks, np.ndarray) and chunks.ndim == 3:
+      if chunks.dtype != float:
+        raise TypeError('test_sequence should be a numpy array of float type.')
+    else:
+      for chunk in chunks:
+        if chunk is not None and len(chunk):
+          self._model._check_sequence(np.asarray(chunk))
     self._decoder.stream_push(chunks)
 
   def labels(self):
