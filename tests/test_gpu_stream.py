@@ -249,6 +249,24 @@ def test_cluster_cap_in_a_session_is_reported_by_every_path(oracle_lib):
     assert np.array_equal(labels[1], ref['labels'][1])
 
 
+def test_persistent_launch_that_fails_its_placement_check_is_reported():
+  """UIS_FLAG_TEST_MISPLACED makes one workgroup claim another XCD: the resident launch gives up
+  at its first in-launch barrier and ends; the push reports it (the session's state is gone),
+  and the handle goes on with ordinary launches."""
+  params = synth.tracker_params(256, 512, 1, seed=34)
+  seqs, _ = synth.make_utterances(12_800, 4, 12, 256)
+  dec = _capi.Decoder(params)
+  dec.stream_begin(4, 6, 16, flags=_capi.UIS_FLAG_PERSISTENT | _capi.UIS_FLAG_TEST_MISPLACED)
+  with pytest.raises(_capi.HipLibraryError):
+    dec.stream_push([s[:3] for s in seqs])
+  dec.stream_end()
+  off, offsets = _offline(dec, seqs, 6)
+  labels, scores, overflow, status, beam = _stream(dec, seqs, 6, [[5] * 4, [7] * 4], 16)
+  assert status == 0
+  for u in range(4):
+    assert np.array_equal(labels[u], off['labels'][offsets[u]:offsets[u + 1]])
+
+
 def test_persistent_flag_is_refused_where_it_cannot_work():
   params = weights.init_params(20, 24, 1, sigma2=0.08, transition_bias=0.2, seed=4)
   dec = _capi.Decoder(params)

@@ -1242,7 +1242,11 @@ int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, c
       if (all) return UIS_OK;
       for (int c = 0; c < ncl; ++c) left = left || ctl[UIS_PM_LEFT_WORD + 16 * c] != 0;
       if (left) break;
-      if ((++spins & 1023u) == 0 && pm_now_s() - t0 > 10.0) break;
+      if ((++spins & 4095u) == 0) {
+        if (pm_now_s() - t0 > 10.0) break;
+        // (a launch that ended without saying so -- an in-launch barrier gave up -- is noticed here)
+        if ((spins & 0xfffffu) == 0 && hipStreamQuery(h->stream) == hipSuccess) { left = true; break; }
+      }
       __builtin_ia32_pause();
     }
     // a cluster left before (or instead of) completing the command: tell the others to leave too

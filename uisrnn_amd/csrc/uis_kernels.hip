@@ -1868,7 +1868,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
             break;
           }
           if (wall_clock64() - t0 > pm.idle_ticks) break;
-          if ((++polls & 63u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ty = UIS_PM_QUIT; break; }
+          // a failed placement / barrier check anywhere on the device: leave (first poll and every 64th)
+          if ((polls++ & 63u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ty = UIS_PM_QUIT; break; }
           __builtin_amdgcn_s_sleep(8);
         }
         s_ctl[4] = (int)ty; s_ctl[5] = (int)nf;
@@ -2301,7 +2302,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #endif
   // (a push leaves nothing in host memory but this word: no system-scope fence, which would write
   // back the whole L2)
-  if (rank == 0 && t == 0)
+  // (... and nothing at all when a placement / barrier check has failed: the host finds the launch gone)
+  if (rank == 0 && t == 0 && !__hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     __hip_atomic_store(pm.ctl + UIS_PM_DONE_WORD + 16 * cluster, (uint32_t)s_ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }  // command loop
   if (PERSIST) {
