@@ -352,7 +352,10 @@ def main(argv=None):
       # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
       # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
       # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
-      kernel = 'k_decode_resident'
+      # (more utterances than workgroups -- 32 per XCD-sized cluster of CUs -- run the variant whose
+      # dense stages give a wave a whole row tile, unless flag 0x200 keeps the split-K passes)
+      n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+      kernel = 'k_decode_big' if n_utt > n_cu - n_cu % 32 and not args.flags & 0x200 else 'k_decode_resident'
       kclass = 'gru'
       per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
       flop_per_launch = per_row * prof['rnn_rows_nodedup']
@@ -377,7 +380,7 @@ def main(argv=None):
     executed = flop_exec / (avg_us * 1e-6) / 1e12 if flop_exec else 0.0
     roofline = {
         'bound': 'mfma', 'kernel': kernel,
-        'decode_path': 'one launch (k_decode_resident)' if resident else 'launch per step',
+        'decode_path': 'one launch ({})'.format(kernel) if resident else 'launch per step',
         'achieved': round(achieved, 3),
         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

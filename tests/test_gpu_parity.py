@@ -207,6 +207,33 @@ def test_resident_decode_is_bit_identical(oracle_lib):
     d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
 
 
+@pytest.mark.parametrize('dim,hidden', [(256, 512), (256, 256), (512, 512), (128, 256)])
+def test_one_launch_decode_with_more_utterances_than_workgroups(dim, hidden, oracle_lib):
+  """More than 256 utterances: k_decode_big (a wave per row tile, weights in LDS) against the
+  split-K passes of k_decode_resident (UIS_FLAG_SMALL_TILES) and the launch-per-step path, ragged
+  lengths, bit for bit; a sample against the oracle."""
+  import os
+  from uisrnn_amd import weights
+  trained = os.path.join(golden_util.GOLDEN_DIR, 'trained_d{}.uisrnn'.format(dim))
+  # (the closed-form tracker weights open clusters without end at observation_dim 512)
+  params = weights.load_checkpoint(trained) if hidden == 512 and os.path.exists(trained) else synth.tracker_params(dim, hidden, 1, seed=41)
+  lens = [5 + (7 * u) % 40 for u in range(300)]
+  seqs, _ = synth.make_utterances(13_000, len(lens), lens, dim)
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  big = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=_capi.UIS_FLAG_RESIDENT)
+  assert big['status'] == 0 and big['stats']['kernel_launches']['select'] == 0
+  for flags in (_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_STEPWISE):
+    other = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=flags)
+    assert np.array_equal(big['labels'], other['labels']), flags
+    assert np.array_equal(_bits(big['beam_scores']), _bits(other['beam_scores'])), flags
+  sample = [0, 37, 151, 299]
+  ref = oracle_lib.decode(params, [seqs[u] for u in sample], 10, 1, 2, n_threads=4)
+  for k, u in enumerate(sample):
+    assert np.array_equal(big['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
+    assert np.array_equal(_bits(big['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
+
+
 def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):
   """The one-launch decode verifies its own assumptions (XCD placement, barrier progress); a
   failed check must cost a re-run on the launch-per-step path, not an error or a wrong answer."""

@@ -728,13 +728,19 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     if (resident) {
       // h1 into the extra slot, then ONE launch for every step of every utterance
       HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
-      const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S), 96 * 1024);  // one workgroup per CU
+      // more utterances than workgroups: the variant whose dense stages give a wave a whole row tile
+      // (k_decode_big: +6 % at 288 utterances, +17 % at 768 / 1024; up to 256 the LDS-resident beam of
+      // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
+      const bool big = U > 32 * ncl && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
+                       big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+      const size_t shmem = std::max<size_t>(big ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
+                                            96 * 1024);  // one workgroup per CU
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
   if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
-    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV>, h->n_cu, dim3(32 * ncl), dim3(512),     \
-                                 shmem, m, gp.st)))                                                                  \
+    void (*kern)(DevModel, DecodeState) = big ? &k_decode_big<HPV, DPV> : &k_decode_resident<HPV, DPV>;             \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
       return rc;                                                                                                     \
   }
       UIS_RESIDENT_CASE(512, 256)

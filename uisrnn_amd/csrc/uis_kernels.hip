@@ -1836,6 +1836,9 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   int launch_step0 = 0, my_cur = 0;  // PERSIST: the owned utterance's step count at launch / now
   if (PERSIST && did_select) launch_step0 = my_cur = st.utt_step[cluster + ncl * rank];
   uint32_t ctype = UIS_PM_PUSH;
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt_prev = 0, ft_acc[4] = {0, 0, 0, 0}, rt_prev2 = 0;
+#endif
 #if defined(UIS_PM_TIMING)  // diagnostic: phases of a push as workgroup 0 sees them, 10 ns ticks, into the mailbox
   unsigned long long pm_t = 0, pm_acc[6] = {0, 0, 0, 0, 0, 0};
 #define PMSTAMP(k) do { if (PERSIST && blockIdx.x == 0 && t == 0) { const unsigned long long n_ = wall_clock64(); pm_acc[k] += n_ - pm_t; pm_t = n_; } } while (0)
@@ -2052,10 +2055,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     my_cur = my_step0 + (int)done;
   }
 #if defined(UIS_RESIDENT_TIMING)
-  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long rt_prev = wall_clock64();
-  unsigned long long ft_acc[4] = {0, 0, 0, 0};
-  unsigned long long rt_prev2 = rt_prev;
+  rt_prev = rt_prev2 = wall_clock64();
 #endif
 
   for (int s = 0; s < nsteps; ++s) {
@@ -2327,6 +2327,250 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (blockIdx.x == 248) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
     if (blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k];
   }
+#endif
+}
+
+// ------------------------------------------------------------ resident decode, many utterances
+//
+// k_decode_resident's stages walk the row tiles in passes of three, every pass split in K over
+// the eight waves and closed by two workgroup barriers (LDS combine, epilogue): right for the
+// three row tiles of 64 utterances, wasteful for the dozens of row tiles of a thousand (the passes
+// of a stage run at ~55 % of their MFMA time: operand fetch, combine and epilogue are exposed in
+// every pass).  k_decode_big is the same launch -- same clusters, same in-launch barriers, same
+// selects from the global beam tables -- with the dense stages turned around: the workgroup's
+// W_hh slice (3 gates x all k-blocks, 96 KB at hidden size 512) and linear_mean1 slice live in
+// LDS, and a WAVE owns a row tile: it walks the full K of its tile (the segment chains of
+// uis_numerics.h combined on the fly, as in the big-tile per-step kernels) with A operands from
+// LDS and B operands (its 16 rows) streamed from L2 one segment ahead, then runs the epilogue on
+// its own accumulators.  No split-K partials, no workgroup barrier inside a stage, eight row
+// tiles in flight per CU.  The two mean-head weight slices share one LDS slot, refilled from L2
+// at the start of their stage.  Used for
+// ordinary decodes with more utterances than workgroups (U > 32 x clusters).
+
+// NA weight streams from `wbase` (LDS or global; stream a at wbase + a * wstride, [k block][lane])
+// against one row tile whose row for this lane starts at byte `boff` of `rsrc` (16 bytes per k
+// block at + kb * 64 + q * 16): total[a] = this lane's 4 features x its row.
+// GS = segments per operand group: the rows of group g + 1 are requested while group g is
+// multiplied (two register sets in turn; everything unrolled, scheduling fenced per segment so
+// that the weight reads of later segments are not hoisted into spills).
+// KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
+// k-block-major staging layout, where a wave's load is one contiguous KiB).
+template <int NA, int NKB, int GS, int KBS>
+__device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
+                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA]) {
+  constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
+  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT, "k-blocks divide into segments, segments into groups");
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  f32x4 b[2][GB];
+#pragma unroll
+  for (int k = 0; k < GB; ++k) b[0][k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+#pragma unroll
+  for (int grp = 0; grp < NGRP; ++grp) {
+    if (grp + 1 < NGRP) {
+#pragma unroll
+      for (int k = 0; k < GB; ++k) b[(grp + 1) & 1][k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+    }
+#pragma unroll
+    for (int sg = 0; sg < GS; ++sg) {
+      const int sgm = grp * GS + sg;
+      f32x4 acc[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        acc[a] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias[a] + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kb = 0; kb < PER; ++kb) {
+        f32x4 wa[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) wa[a] = wbase[(size_t)a * wstride + (size_t)(sgm * PER + kb) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[grp & 1][sg * PER + kb][e], acc[a], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (sgm == 0) total[a] = acc[a];
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) total[a][i] = total[a][i] + acc[a][i];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+__host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+
+template <int HP, int DP>
+__global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
+  constexpr int NKB = HP / 16;
+  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
+  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32, "hidden size 256 / 512, observation_dim 128 / 256 / 512 (padded)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int ncl = st.ncl;
+  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
+  const int U = st.U, S = st.S;
+  const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
+  f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((L.total + 255) & ~255));  // [3][NKB][64]
+  f32x4* s_wm = s_whh + 3 * NKB * 64;                                          // [NKB][64] linear_mean1's slice, then linear_mean2's
+  int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                         // [0] abort [1] steps [2] arrived
+
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
+  }
+  __syncthreads();
+  {  // decode steps of this cluster = the longest of its utterances
+    int myT = 0;
+    for (int i = t; cluster + ncl * i < U; i += 512) {
+      const int u = cluster + ncl * i;
+      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      myT = T > myT ? (int)T : myT;
+    }
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  const int ft1 = rank / SH1, tpar1 = rank % SH1;  // ranks sharing a feature tile take alternate row tiles
+  const int ft2 = rank / SH2, tpar2 = rank % SH2;
+  for (int e = t; e < NKB * 64; e += 512) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      s_whh[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[0])[(size_t)(g * NFT1 + ft1) * NKB * 64 + e];
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+  const f32x4* w1g = reinterpret_cast<const f32x4*>(m.w1) + (size_t)ft1 * NKB * 64;
+  const f32x4* w2g = reinterpret_cast<const f32x4*>(m.w2) + (size_t)ft2 * NKB * 64;
+
+  const __amdgpu_buffer_rsrc_t rs_rows =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  float* const hst = st.gi_up;                // hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major
+  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
+  const int rbase = cluster * st.rx_stride;   // this cluster's rows of `rows`
+  const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
+  RowSink sink{st.rows + rbase, nullptr};
+  uint32_t bar = 0;
+  const float* bias_hh[3] = {m.bhh[0] + ft1 * 16, m.bhh[0] + HP + ft1 * 16, m.bhh[0] + 2 * HP + ft1 * 16};
+  const float* bias_1[1] = {m.b1 + ft1 * 16};
+  const float* bias_2[1] = {m.b2 + ft2 * 16};
+
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rt_prev = wall_clock64();
+#endif
+  for (int s = 0; s < nsteps; ++s) {
+    const int par = s & 1;
+    sink.count = st.rx_nrows + cluster * 32 + par;
+    for (int i = rank; cluster + ncl * i < U; i += 32) {
+      select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
+      __syncthreads();
+    }
+    RSTAMP(0);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(1);
+    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
+    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+    const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rank == 0 && t == 0)
+      __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nrt = (nrows + 15) >> 4;
+
+    // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot; wave w of this rank takes the
+    // row tiles tpar1 + SH1 * (w, w + 8, ...)
+    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));  // (a tile's first row always exists)
+      const long frame = load_row_frame(rs_rows, rbase + (valid ? row : 16 * tile));
+      const uint32_t hoff = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
+      const int j4 = ft1 * 16 + 4 * q;
+      const float* gi = st.gi0 + (size_t)frame * m.G;
+      const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
+      const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
+      const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
+      const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
+      f32x4 gh[3];
+      fullk_rows_sc1<3, NKB, 2, 64>(s_whh, NKB * 64, bias_hh, rs_hid, hoff, gh);
+      if (valid) {
+        f32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+        *reinterpret_cast<f32x4*>(st.pool_hid + ((size_t)rh.utt * S + rh.dst) * HP + j4) = out;
+        // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
+        // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
+        // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
+        *reinterpret_cast<f32x4*>(hst + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = out;
+      }
+    }
+    RSTAMP(2);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(3);
+
+    // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice
+    // takes the LDS slot first (32 KB from L2: one round trip per stage)
+    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];
+    __syncthreads();
+    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      f32x4 v[1];
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_hst, (uint32_t)((((tile0 + tile) * NFT1) * 256 + (lane & 15) * 16) * 4), v);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
+        *reinterpret_cast<f32x4*>(st.a1 + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = v[0];
+      }
+    }
+    RSTAMP(4);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(5);
+
+    // ---- linear_mean2 + running mean -> dst slot (every wave is past the barrier: the slot is free)
+    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w2g[e];
+    __syncthreads();
+    for (int tile = tpar2 + SH2 * w; tile < nrt; tile += SH2 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
+      const int f4 = ft2 * 16 + 4 * q;
+      f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)((((size_t)rh.utt * S + rh.src) * m.Dp + f4) * 4));
+      f32x4 v[1];
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, (uint32_t)((((tile0 + tile) * NFT1) * 256 + (lane & 15) * 16) * 4), v);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
+          if (f4 + i >= m.D) v[0][i] = 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)rh.utt * S + rh.dst) * m.Dp + f4) = v[0];
+      }
+    }
+    RSTAMP(6);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(7);
+  }
+#if defined(UIS_RESIDENT_TIMING)
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
+    for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
 #endif
 }
 
