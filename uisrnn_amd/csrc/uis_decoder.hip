@@ -1168,7 +1168,10 @@ int pm_launch(uis_handle* h) {
   uis_handle::Stream& ss = h->stream_state;
   const DevModel& m = h->m;
   DecodeState st = ss.st;
-  unsigned char* blk = ss.pm_block;
+  // the mailbox as the device sees it (the same address under unified addressing; asked for anyway)
+  void* blk_dev = nullptr;
+  HIPCHK(hipHostGetDevicePointer(&blk_dev, ss.pm_block, 0));
+  unsigned char* blk = static_cast<unsigned char*>(blk_dev);
   st.x = reinterpret_cast<const float*>(ss.chunk_x.as<char>());
   st.gi0 = ss.chunk_gi0.as<float>();
   st.mse0 = ss.chunk_mse0.as<float>();
