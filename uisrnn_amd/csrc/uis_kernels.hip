@@ -2355,20 +2355,40 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 // that the weight reads of later segments are not hoisted into spills).
 // KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
 // k-block-major staging layout, where a wave's load is one contiguous KiB).
+// The first group arrives preloaded in `bfirst` (rows_first_group); while the LAST group is
+// multiplied the first group of the wave's NEXT row tile (at next_boff, if has_next) is requested
+// into `bfirst` again, so that a tile's dependent start-up (row descriptor -> address -> rows)
+// hides behind its predecessor's chain.
+template <int GB, int KBS>
+__device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&bfirst)[GB]) {
+  const int q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+}
 template <int NA, int NKB, int GS, int KBS>
 __device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
-                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA]) {
+                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA],
+                                               f32x4 (&bfirst)[GS * (NKB / UIS_KSPLIT)], uint32_t next_boff, bool has_next) {
   constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
-  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT, "k-blocks divide into segments, segments into groups");
+  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT && NGRP % 2 == 0,
+                "k-blocks divide into segments, segments into an even number of groups (the last one uses the second register set)");
   const int lane = threadIdx.x & 63, q = lane >> 4;
-  f32x4 b[2][GB];
-#pragma unroll
-  for (int k = 0; k < GB; ++k) b[0][k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+  f32x4 bsec[GB];  // the second register set; groups alternate bfirst / bsec
 #pragma unroll
   for (int grp = 0; grp < NGRP; ++grp) {
     if (grp + 1 < NGRP) {
+      if ((grp + 1) & 1) {
 #pragma unroll
-      for (int k = 0; k < GB; ++k) b[(grp + 1) & 1][k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+        for (int k = 0; k < GB; ++k) bsec[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+      } else {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+      }
+    }
+    const f32x4 (&b)[GB] = (grp & 1) ? bsec : bfirst;  // this group's operands
+    if (grp + 1 == NGRP && has_next) {  // (the last group reads bsec) bfirst is free: the next tile's first group
+#pragma unroll
+      for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, next_boff + (uint32_t)(k * KBS + q * 16));
     }
 #pragma unroll
     for (int sg = 0; sg < GS; ++sg) {
@@ -2386,7 +2406,7 @@ __device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, 
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int a = 0; a < NA; ++a)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[grp & 1][sg * PER + kb][e], acc[a], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[sg * PER + kb][e], acc[a], 0, 0, 0);
       }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
@@ -2493,31 +2513,54 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     const int nrt = (nrows + 15) >> 4;
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot; wave w of this rank takes the
-    // row tiles tpar1 + SH1 * (w, w + 8, ...)
-    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
-      const int row = 16 * tile + (lane & 15);
-      const bool valid = row < nrows;
-      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));  // (a tile's first row always exists)
-      const long frame = load_row_frame(rs_rows, rbase + (valid ? row : 16 * tile));
-      const uint32_t hoff = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
-      const int j4 = ft1 * 16 + 4 * q;
-      const float* gi = st.gi0 + (size_t)frame * m.G;
-      const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
-      const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
-      const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
-      const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
-      f32x4 gh[3];
-      fullk_rows_sc1<3, NKB, 2, 64>(s_whh, NKB * 64, bias_hh, rs_hid, hoff, gh);
-      if (valid) {
-        f32x4 out;
+    // row tiles tpar1 + SH1 * (w, w + 8, ...); the next tile's descriptor and first rows are
+    // requested while the current tile's chain runs
+    {
+      constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
+      int tile = tpar1 + SH1 * w;
+      RowHead rh{0, 0, 0, 0};
+      long frame = 0;
+      uint32_t hoff = h1_off;
+      f32x4 bfirst[GBG];
+      auto fetch_head = [&](int tl, RowHead& h_, long& f_, uint32_t& o_) {
+        const int row = 16 * tl + (lane & 15);
+        const int use = rbase + (row < nrows ? row : 16 * tl);  // (a tile's first row always exists)
+        h_ = load_row_head(rs_rows, use);
+        f_ = load_row_frame(rs_rows, use);
+        o_ = h_.src >= 0 ? (uint32_t)((((size_t)h_.utt * S + h_.src) * HP) * 4) : h1_off;
+      };
+      if (tile < nrt) {
+        fetch_head(tile, rh, frame, hoff);
+        rows_first_group<GBG, 64>(rs_hid, hoff, bfirst);
+      }
+      while (tile < nrt) {
+        const int next = tile + SH1 * 8;
+        const bool has_next = next < nrt;
+        RowHead rh_n{0, 0, 0, 0};
+        long frame_n = 0;
+        uint32_t hoff_n = h1_off;
+        if (has_next) fetch_head(next, rh_n, frame_n, hoff_n);
+        const bool valid = 16 * tile + (lane & 15) < nrows;
+        const int j4 = ft1 * 16 + 4 * q;
+        const float* gi = st.gi0 + (size_t)frame * m.G;
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
+        const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
+        f32x4 gh[3];
+        fullk_rows_sc1<3, NKB, GSG, 64>(s_whh, NKB * 64, bias_hh, rs_hid, hoff, gh, bfirst, hoff_n, has_next);
+        if (valid) {
+          f32x4 out;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
-        *reinterpret_cast<f32x4*>(st.pool_hid + ((size_t)rh.utt * S + rh.dst) * HP + j4) = out;
-        // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
-        // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
-        // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
-        *reinterpret_cast<f32x4*>(hst + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = out;
+          for (int i = 0; i < 4; ++i)
+            out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+          *reinterpret_cast<f32x4*>(st.pool_hid + ((size_t)rh.utt * S + rh.dst) * HP + j4) = out;
+          // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
+          // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
+          // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
+          *reinterpret_cast<f32x4*>(hst + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = out;
+        }
+        tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
       }
     }
     RSTAMP(2);
@@ -2528,11 +2571,14 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     // takes the LDS slot first (32 KB from L2: one round trip per stage)
     for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];
     __syncthreads();
+    constexpr int GBH = 4 * (NKB / UIS_KSPLIT);
+    auto stage_off = [&](int tl) { return (uint32_t)((((tile0 + tl) * NFT1) * 256 + (lane & 15) * 16) * 4); };
     for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
       const int row = 16 * tile + (lane & 15);
       const bool valid = row < nrows;
-      f32x4 v[1];
-      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_hst, (uint32_t)((((tile0 + tile) * NFT1) * 256 + (lane & 15) * 16) * 4), v);
+      f32x4 v[1], bfirst1[GBH];
+      rows_first_group<GBH, 1024>(rs_hst, stage_off(tile), bfirst1);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_hst, stage_off(tile), v, bfirst1, 0u, false);
       if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
@@ -2553,8 +2599,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       const int f4 = ft2 * 16 + 4 * q;
       f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
       if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)((((size_t)rh.utt * S + rh.src) * m.Dp + f4) * 4));
-      f32x4 v[1];
-      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, (uint32_t)((((tile0 + tile) * NFT1) * 256 + (lane & 15) * 16) * 4), v);
+      f32x4 v[1], bfirst2[GBH];
+      rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
       if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
