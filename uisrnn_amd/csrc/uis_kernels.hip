@@ -1060,7 +1060,8 @@ template <int NT, bool RES, bool KEEP, int DPT = 0, int PARTS = 7, typename Pub 
 __device__ __forceinline__ void select_fast_body(const DevModel& m, const DecodeState& st, int par, int u,
                                                  unsigned char* smem_raw, RowSink sink, int step_in = 0,
                                                  long off0_in = 0, long off1_in = 0, Pub published = Pub(),
-                                                 int first_step_in = 0) {
+                                                 int first_step_in = 0, unsigned char* keep_sets = nullptr,
+                                                 int* keep_pcnt = nullptr) {
   static_assert(PARTS == 7 || KEEP, "the split needs the beam in LDS");
   int tid_ = threadIdx.x;
   // inside the resident decode's step loop: keep the compiler from hoisting every tid-derived
@@ -1078,8 +1079,12 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const int nxt = tpar ^ 1;
   const FastLds L = fast_lds_layout(m.Dp, B, Kmax, S);
   float* swgt = reinterpret_cast<float*>(smem_raw + L.off_wgt);
-  unsigned char* const set_cur = smem_raw + (KEEP ? tpar * L.set_stride : 0);
-  unsigned char* const set_nxt = smem_raw + (KEEP ? nxt * L.set_stride : 0);
+  // KEEP with several utterances per workgroup (k_decode_big): the two table sets and the per-slot
+  // counts of utterance i live in a block of their own (keep_sets = block - L.off_slot: the set's
+  // fields keep their relative offsets), the scratch areas are shared
+  unsigned char* const sets0 = (KEEP && keep_sets) ? keep_sets : smem_raw;
+  unsigned char* const set_cur = sets0 + (KEEP ? tpar * L.set_stride : 0);
+  unsigned char* const set_nxt = sets0 + (KEEP ? nxt * L.set_stride : 0);
   int* sslot = reinterpret_cast<int*>(set_cur + L.off_slot);
   int* sblk = reinterpret_cast<int*>(set_cur + L.off_blk);
   int* sK = reinterpret_cast<int*>(set_cur + L.off_K);
@@ -1092,7 +1097,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   int* nlast = reinterpret_cast<int*>(set_nxt + L.off_last);
   int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
   float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
-  int* spcnt = reinterpret_cast<int*>(smem_raw + L.off_pcnt);
+  int* spcnt = (KEEP && keep_pcnt) ? keep_pcnt : reinterpret_cast<int*>(smem_raw + L.off_pcnt);
   unsigned* scand = reinterpret_cast<unsigned*>(smem_raw + L.off_cand);
   int* sbase = reinterpret_cast<int*>(smem_raw + L.off_base);
   int* slive = reinterpret_cast<int*>(smem_raw + L.off_live);
@@ -2421,8 +2426,20 @@ __device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, 
   }
 }
 
-__host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+// LDS of k_decode_big: select scratch | W_hh slice | mean-head slot | control words | beam store
+// (table sets + per-slot counts of as many of the rank's utterances as fit in what is left of 160 KB)
+__host__ __device__ inline size_t big_lds_fixed(int Hp, int Dp, int B, int Kmax, int S) {
   return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+__host__ __device__ inline size_t big_store_stride(int Dp, int B, int Kmax, int S) {
+  return (size_t)((2 * fast_lds_layout(Dp, B, Kmax, S).set_stride + S * 4 + 15) & ~15);
+}
+__host__ __device__ inline int big_store_slots(int Hp, int Dp, int B, int Kmax, int S) {
+  const size_t fixed = big_lds_fixed(Hp, Dp, B, Kmax, S);
+  return fixed >= 160 * 1024 ? 0 : (int)((160 * 1024 - fixed) / big_store_stride(Dp, B, Kmax, S));
+}
+__host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+  return big_lds_fixed(Hp, Dp, B, Kmax, S) + (size_t)big_store_slots(Hp, Dp, B, Kmax, S) * big_store_stride(Dp, B, Kmax, S);
 }
 
 template <int HP, int DP>
@@ -2440,6 +2457,11 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((L.total + 255) & ~255));  // [3][NKB][64]
   f32x4* s_wm = s_whh + 3 * NKB * 64;                                          // [NKB][64] linear_mean1's slice, then linear_mean2's
   int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                         // [0] abort [1] steps [2] arrived
+  // the beams of this rank's first `nstore` utterances stay in LDS from step to step (the rest, if
+  // the rank has more, goes through the global tables every step)
+  unsigned char* s_store = reinterpret_cast<unsigned char*>(s_ctl + 16);
+  const int store_stride = (int)big_store_stride(m.Dp, st.B, st.Kmax, S);
+  const int nstore = big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -2497,8 +2519,15 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
     sink.count = st.rx_nrows + cluster * 32 + par;
-    for (int i = rank; cluster + ncl * i < U; i += 32) {
-      select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
+    for (int i = rank, k = 0; cluster + ncl * i < U; i += 32, ++k) {
+      const int u = cluster + ncl * i;
+      if (k < nstore) {
+        unsigned char* blk = s_store + (size_t)k * store_stride;
+        select_fast_body<512, true, true, DP, 7>(m, st, par, u, smem_raw, sink, s, (long)st.off[u], (long)st.off[u + 1], SelectNoHook(), 0,
+                                                 blk - L.off_slot, reinterpret_cast<int*>(blk + 2 * L.set_stride));
+      } else {
+        select_fast_body<512, true, false, DP>(m, st, par, u, smem_raw, sink);
+      }
       __syncthreads();
     }
     RSTAMP(0);
