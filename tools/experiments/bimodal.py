@@ -1,0 +1,28 @@
+"""Does the 1.28 M / 1.33 M bimodality of the bench follow the physical placement of the decoder's
+buffers?  Several handles in one process, each created after a different amount of filler
+allocations (kept alive), device-resident decodes timed by the library's own events."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np, torch
+import bench
+from uisrnn_amd import _capi, synth
+cfg = dict(bench.CONFIGS[1])
+params = bench.load_model(cfg, 'auto')[0]
+seqs, _ = synth.make_utterances(10_000, 64, 500, 256)
+frames = torch.from_numpy(np.concatenate(seqs).astype(np.float32)).cuda()
+offsets = (np.arange(65) * 500).astype(np.int64)
+labels = torch.empty(32000, dtype=torch.int32, device='cuda')
+scores = torch.empty(64, dtype=torch.float32, device='cuda')
+import os
+shifts = [int(v) for v in sys.argv[1].split(',')]
+print('arena base / shift -> decode ms')
+for rep in range(2):
+  for sh in shifts:
+    os.environ['UIS_ARENA_SHIFT'] = str(sh)
+    dec = _capi.Decoder(params)
+    ms = []
+    for i in range(4):
+      out = dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr())
+      ms.append(out['stats']['decode_ms'])
+    print('shift', sh, 'decode_ms', ' '.join('%.2f' % v for v in ms[1:]), flush=True)
+    dec.close()

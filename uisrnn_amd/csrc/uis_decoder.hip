@@ -591,8 +591,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     size_t total = 0;
     for (auto& w : want) total += (w.second + 4095) & ~(size_t)4095;
     if (use_arena) {
-      if ((rc = h->arena.ensure(total))) return rc;
-      size_t o = 0;
+      // (experiment knob, tools/experiments/bimodal.py: the one-launch decode runs in one of two modes
+      // 4 % apart depending on where its buffers land)
+      const size_t shift = getenv("UIS_ARENA_SHIFT") ? ((size_t)atol(getenv("UIS_ARENA_SHIFT")) & ~(size_t)4095) : 0;
+      if ((rc = h->arena.ensure(total + shift))) return rc;
+      size_t o = shift;
       for (auto& w : want) {
         if (w.first->p && !w.first->borrowed) (void)hipFree(w.first->p);
         w.first->p = static_cast<char*>(h->arena.p) + o;
