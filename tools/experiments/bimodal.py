@@ -14,6 +14,14 @@ offsets = (np.arange(65) * 500).astype(np.int64)
 labels = torch.empty(32000, dtype=torch.int32, device='cuda')
 scores = torch.empty(64, dtype=torch.float32, device='cuda')
 import os
+def run(tag):
+  dec = _capi.Decoder(params)
+  ms = []
+  for i in range(4):
+    out = dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr())
+    ms.append(out['stats']['decode_ms'])
+  print(tag, 'decode_ms %.2f' % (sum(ms[1:]) / 3), flush=True)
+  dec.close()
 shifts = [int(v) for v in sys.argv[1].split(',')]
 print('arena base / shift -> decode ms')
 for rep in range(2):
