@@ -22,6 +22,27 @@ def run(tag):
     ms.append(out['stats']['decode_ms'])
   print(tag, 'decode_ms %.2f' % (sum(ms[1:]) / 3), flush=True)
   dec.close()
+if sys.argv[1] == 'which':
+  os.environ['UIS_ARENA_SHIFT'] = '0'
+  for k in range(8):
+    dec = _capi.Decoder(params)
+    for i in range(2):
+      dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr())
+    out = dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr(), flags=_capi.UIS_FLAG_PROFILE)
+    st = out['stats']
+    print('handle', k, 'decode_ms %.2f' % st['decode_ms'], {n: round(v, 3) for n, v in st['kernel_ms'].items() if v}, flush=True)
+    dec.close()
+  sys.exit(0)
+if sys.argv[1] == 'streams':
+  # does the mode follow the hardware queue behind the handle's stream?  k dummy streams are
+  # created (and kept) before each handle
+  os.environ['UIS_ARENA_SHIFT'] = '0'
+  dummies = []
+  for k in (0, 0, 1, 0, 1, 1, 2, 0, 3, 0, 0, 1):
+    for _ in range(k):
+      dummies.append(torch.cuda.Stream())
+    run('after %d more dummy streams (total %d)' % (k, len(dummies)))
+  sys.exit(0)
 shifts = [int(v) for v in sys.argv[1].split(',')]
 print('arena base / shift -> decode ms')
 for rep in range(2):
