@@ -103,9 +103,11 @@ typedef struct uis_decode_opts {
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */
-#define UIS_FLAG_SMALL_TILES 0x200u /* launch-per-step path: keep the split-K dense kernels even where
-                                    the big-tile ones (thousands of rnn rows per step) apply; A/B
-                                    switch, results are bit-identical either way                */
+#define UIS_FLAG_SMALL_TILES 0x200u /* keep the split-K dense stages even where the wave-per-row-tile
+                                    ones apply: the big-tile kernels of the launch-per-step path
+                                    (thousands of rnn rows per step) and k_decode_big of the one-launch
+                                    path (more utterances than workgroups); A/B switch, results are
+                                    bit-identical either way                                     */
 #define UIS_FLAG_PERSISTENT 0x400u /* uis_stream_begin only: the one-launch decode kernel STAYS on the device
                                     between pushes and takes pushes / label requests from a mailbox in
                                     host-coherent pinned memory -- a push costs no launch and no copy
