@@ -1892,10 +1892,24 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
         float* xdev = const_cast<float*>(st.x);
         int64_t* foff_c = const_cast<int64_t*>(st.foff);
         int32_t* avail_c = const_cast<int32_t*>(st.avail);
-        for (int e = t; e < prows * q4; e += 512) {
-          const size_t row = (size_t)(prow0 + e / q4);
-          const int c4 = (e % q4) * 4;
-          *reinterpret_cast<f32x4*>(xdev + row * m.Dp + c4) = sys_load_f32x4(pm.frames + row * m.D + c4);
+        for (int e0 = t; e0 < prows * q4; e0 += 4 * 512) {  // four PCIe reads in flight per thread
+          f32x4 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * 512;
+            v[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (e < prows * q4) {  // (no request for what is past the end: a one-frame push is ONE read per thread)
+              const float* src = pm.frames + (size_t)(prow0 + e / q4) * m.D + (e % q4) * 4;
+              asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(v[k]) : "v"(src) : "memory");
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int e = e0 + k * 512;
+            asm volatile("" : "+v"(v[k]));  // (the values exist only after the wait above)
+            if (e < prows * q4) *reinterpret_cast<f32x4*>(xdev + (size_t)(prow0 + e / q4) * m.Dp + (e % q4) * 4) = v[k];
+          }
         }
         for (int u = t; u < U; u += 512) { foff_c[u] = sys_load_i64(pm.foff + u); avail_c[u] = sys_load_i32(pm.avail + u); }
       }
