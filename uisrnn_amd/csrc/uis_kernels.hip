@@ -2769,7 +2769,7 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
 }
 
 __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int par) {
-  __shared__ int lds4[4];
+  __shared__ int lds4[8];  // (4 for the scans, 8 for the two-word reductions of the prune)
   __shared__ int lds_misc[8];  // [0] nlive [1] nfinite
   const int u = blockIdx.x, tid = threadIdx.x;
   const int B = st.B, Kmax = st.Kmax, S = st.S, L = st.L, NC = st.NC;
@@ -2903,19 +2903,53 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
       // the keep-th smallest one, K*, is the largest T with #{key < T} <= keep - 1: found bit by
       // bit from the top, one workgroup-wide count per bit (64 counts over C keys instead of
       // the C^2 / 2 comparisons of ranking every candidate against every other).
-      unsigned long long kstar = 0ull;
-      for (int bit = 63; bit >= 0; --bit) {
-        const unsigned long long t2 = kstar | (1ull << bit);
+      // Done in two halves.  The score half (high 32 bits) first, starting below the prefix all
+      // finite keys share (scores of one step have the same sign and exponent: ~10 bits decide
+      // nothing); if the candidates at the threshold score are exactly as many as are still
+      // needed -- the usual case: ties are rare -- the index half needs no search at all.
+      // (64 workgroup-wide counts over up to 15 k keys -> about 22.)
+      auto count_wg = [&](auto pred) {  // workgroup-wide count of pred(key)
         int c = 0;
-        for (int i = tid; i < C; i += 256) c += key[i] < t2 ? 1 : 0;
+        for (int i = tid; i < C; i += 256) c += pred(key[i]) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        __syncthreads();  // (lds4 of the previous count has been read by everybody)
         if ((tid & 63) == 0) lds4[tid >> 6] = c;
         __syncthreads();
-        const int total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-        if (total <= keep - 1) kstar = t2;
-        __syncthreads();
+        return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+      };
+      unsigned hi_and = 0xffffffffu, hi_or = 0u;
+      for (int i = tid; i < C; i += 256) {
+        const unsigned long long k = key[i];
+        if (k != ~0ull) { hi_and &= (unsigned)(k >> 32); hi_or |= (unsigned)(k >> 32); }
       }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) { hi_and &= __shfl_xor(hi_and, off, 64); hi_or |= __shfl_xor(hi_or, off, 64); }
+      __syncthreads();
+      if ((tid & 63) == 0) { lds4[tid >> 6] = (int)hi_and; lds4[4 + (tid >> 6)] = (int)hi_or; }
+      __syncthreads();
+      hi_and = (unsigned)(lds4[0] & lds4[1] & lds4[2] & lds4[3]);
+      hi_or = (unsigned)(lds4[4] | lds4[5] | lds4[6] | lds4[7]);
+      const unsigned diff = hi_or & ~hi_and;                    // score bits in which the finite keys differ
+      const int top = diff ? 31 - __builtin_clz(diff) : -1;      // the highest of them
+      unsigned khi = top >= 31 ? 0u : (hi_and & ~((2u << top) - 1u));  // the common prefix above it
+      if (top < 0) khi = hi_and;
+      for (int bit = top; bit >= 0; --bit) {
+        const unsigned t2 = khi | (1u << bit);
+        if (count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) < t2; }) <= keep - 1) khi = t2;
+      }
+      const int n_lt = count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) < khi; });
+      const int n_eq = count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) == khi; });
+      const int need = keep - n_lt;                               // how many of the threshold score go on (>= 1)
+      unsigned klo = 0xffffffffu;
+      if (n_eq != need) {                                         // a tie at the threshold: lowest candidate indices first
+        klo = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+          const unsigned t2 = klo | (1u << bit);
+          if (count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) == khi && (unsigned)k < t2; }) <= need - 1) klo = t2;
+        }
+      }
+      const unsigned long long kstar = ((unsigned long long)khi << 32) | klo;
       // the winners (key <= K*) in candidate order, then each one's rank among them
       int* wl = ordv;  // (free until the leader bookkeeping below)
       block_scan(C, [&](int i) { return key[i] <= kstar ? 1 : 0; },
