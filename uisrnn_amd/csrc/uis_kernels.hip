@@ -2832,31 +2832,79 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   const float* xrow = st.x + (size_t)frame * m.Dp;
   {
     const int grp = tid >> 4, p = tid & 15;
-    for (int i0 = 0; i0 < nlive; i0 += 16) {
-      const int i = i0 + grp;
-      const bool act = i < nlive;
-      const int sl = livelist[act ? i : 0];
-      const float* mean = pmean + (size_t)sl * m.Dp;
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      float first_sq = 0.0f;
-      for (int q = 0; q < m.Dp; q += 256) {
+    if (m.Dp <= 256) {
+      // one 256-float chunk: the frame and the weights stay in registers and FOUR slots per 16-lane
+      // group are in flight (a level of a wide beam has hundreds of live states: the loop was one
+      // dependent L2 round trip per 16 slots, the largest phase of the kernel)
+      f32x4 xv[4], wv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int d = q + 4 * (p + 16 * k);
-          if (d < m.Dp) {
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + d);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + d);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(m.wgt + d);
+      for (int k = 0; k < 4; ++k) {
+        const int d = 4 * (p + 16 * k);
+        const bool in_ = d < m.Dp;
+        xv[k] = in_ ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        wv[k] = in_ ? *reinterpret_cast<const f32x4*>(m.wgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      for (int i0 = 0; i0 < nlive; i0 += 64) {
+        int sl[4]; bool act[4]; f32x4 mv[4][4];
 #pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[e2], xv[e2], wv[e2]);
-            if (q == 0 && k == 0) { const float d0 = mv[0] - xv[0]; first_sq = d0 * d0; }
+        for (int h2 = 0; h2 < 4; ++h2) {
+          const int i = i0 + 16 * h2 + grp;
+          act[h2] = i < nlive;
+          sl[h2] = livelist[act[h2] ? i : 0];
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 4; ++h2) {
+          const float* mean = pmean + (size_t)sl[h2] * m.Dp;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = 4 * (p + 16 * k);
+            mv[h2][k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
         }
-      }
-      float t = (v[0] + v[2]) + (v[1] + v[3]);
 #pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-      if (p == 0 && act) { mse[sl] = uis_mse_finish(t, first_sq, m.D); cntv[sl] = st.pool_cnt[(size_t)u * S + sl]; }
+        for (int h2 = 0; h2 < 4; ++h2) {
+          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (4 * (p + 16 * k) < m.Dp) {
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[h2][k][e2], xv[k][e2], wv[k][e2]);
+            }
+          }
+          const float d0 = mv[h2][0][0] - xv[0][0];
+          float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+          if (p == 0 && act[h2]) { mse[sl[h2]] = uis_mse_finish(t, d0 * d0, m.D); cntv[sl[h2]] = st.pool_cnt[(size_t)u * S + sl[h2]]; }
+        }
+      }
+    } else {
+      for (int i0 = 0; i0 < nlive; i0 += 16) {
+        const int i = i0 + grp;
+        const bool act = i < nlive;
+        const int sl = livelist[act ? i : 0];
+        const float* mean = pmean + (size_t)sl * m.Dp;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float first_sq = 0.0f;
+        for (int q = 0; q < m.Dp; q += 256) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = q + 4 * (p + 16 * k);
+            if (d < m.Dp) {
+              const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + d);
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + d);
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(m.wgt + d);
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[e2], xv[e2], wv[e2]);
+              if (q == 0 && k == 0) { const float d0 = mv[0] - xv[0]; first_sq = d0 * d0; }
+            }
+          }
+        }
+        float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+        if (p == 0 && act) { mse[sl] = uis_mse_finish(t, first_sq, m.D); cntv[sl] = st.pool_cnt[(size_t)u * S + sl]; }
+      }
     }
   }
   __syncthreads();
