@@ -156,9 +156,10 @@ def test_streams_and_graph_are_bit_identical(oracle_lib):
 
 
 def test_wide_tiles_bit_exact(oracle_lib):
-  """row capacity > 2048 switches the launch-per-step dense kernels to the big-tile ones (full-K
-  chains per wave); UIS_FLAG_SMALL_TILES keeps the split-K kernels in their 2x2 tile shape.  Also
-  a two-layer model (k_dense_upper_in feeds the big GRU kernel) and dims that fall back."""
+  """row capacity > 2048 switches the launch-per-step dense kernels to a wave per row tile: with
+  hidden size 256 / 512 the kernels that keep their weight slice in LDS (k_wt_*), else the big-tile
+  ones that stream it (k_big_*); UIS_FLAG_SMALL_TILES keeps the split-K kernels in their 2x2 tile
+  shape.  Also two-layer models (k_dense_upper_in feeds the GRU kernel of either kind)."""
   params = synth.tracker_params(256, 512, 1, seed=2)
   n_utt = 224
   lengths = [10 + (7 * u) % 23 for u in range(n_utt)]
@@ -169,6 +170,8 @@ def test_wide_tiles_bit_exact(oracle_lib):
   seqs2, _ = synth.make_utterances(6100, n_utt, [8 + (5 * u) % 11 for u in range(n_utt)], 128)
   _compare(deep, seqs2, 10, 1, 1, oracle_lib)
   _compare(deep, seqs2, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_SMALL_TILES)
+  deep2 = synth.tracker_params(128, 256, 2, seed=13)      # depth 2, hidden 256: k_wt_gru for both layers
+  _compare(deep2, seqs2, 10, 1, 1, oracle_lib)
 
 
 def test_generic_select_flag_is_bit_identical(oracle_lib):

@@ -325,6 +325,26 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
   const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
   // thousands of rows: the big-tile kernels (4 row tiles x several feature tiles per workgroup,
   // full-K chains per wave) where the feature-tile counts divide
+  // thousands of rows and hidden size 256 / 512: weights in LDS, a wave per row tile (k_wt_*)
+  if (wide && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64 &&
+      !getenv("UIS_NO_WT")) {
+    const int nft = m.Hp / 16, nft2 = m.Dp / 16;
+    const int ng1 = wt_groups(h->n_cu, nft), ng2 = wt_groups(h->n_cu, nft2);
+    const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
+    for (int l = 0; l < m.depth; ++l) {
+      if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
+      if (m.Hp == 512) LAUNCH(UIS_K_GRU, k_wt_gru<32>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
+      else LAUNCH(UIS_K_GRU, k_wt_gru<16>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
+    }
+    if (m.Hp == 512) {
+      LAUNCH(UIS_K_HEAD1, (k_wt_head<32, 1>), dim3(nft * ng1), dim3(512), kb_bytes, m, st, par, ng1);
+      LAUNCH(UIS_K_HEAD2, (k_wt_head<32, 2>), dim3(nft2 * ng2), dim3(512), kb_bytes, m, st, par, ng2);
+    } else {
+      LAUNCH(UIS_K_HEAD1, (k_wt_head<16, 1>), dim3(nft * ng1), dim3(512), kb_bytes, m, st, par, ng1);
+      LAUNCH(UIS_K_HEAD2, (k_wt_head<16, 2>), dim3(nft2 * ng2), dim3(512), kb_bytes, m, st, par, ng2);
+    }
+    return UIS_OK;
+  }
   if (wide && (m.Hp / 16) % 4 == 0 && (m.Dp / 16) % 4 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES)) {
     for (int l = 0; l < m.depth; ++l) {
       if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
@@ -1005,6 +1025,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, std::vector<float>(m.Dp, 0.0f), &m.m0))) return bail(rc);
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_gru<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return bail(fail(UIS_ERR_HIP, std::string("hipFuncSetAttribute(k_select): ") + hipGetErrorString(e)));

@@ -2384,6 +2384,150 @@ __device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, ui
 #pragma unroll
   for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
 }
+// the same schedule with plain loads from this lane's row (launch-per-step kernels: the rows were
+// written by earlier launches): NA weight streams in LDS against one row tile, the operands of the
+// next group of GS segments requested while the current one is multiplied
+template <int NA, int NKB, int GS>
+__device__ __forceinline__ void fullk_rows_plain(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
+                                                 const float* __restrict__ row, f32x4 (&total)[NA]) {
+  constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
+  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT, "k-blocks divide into segments, segments into groups");
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const f32x4* bp = reinterpret_cast<const f32x4*>(row) + q;
+  f32x4 b[2][GB];
+#pragma unroll
+  for (int k = 0; k < GB; ++k) b[0][k] = bp[(size_t)k * 4];
+#pragma unroll
+  for (int grp = 0; grp < NGRP; ++grp) {
+    if (grp + 1 < NGRP) {
+#pragma unroll
+      for (int k = 0; k < GB; ++k) b[(grp + 1) & 1][k] = bp[(size_t)((grp + 1) * GB + k) * 4];
+    }
+#pragma unroll
+    for (int sg = 0; sg < GS; ++sg) {
+      const int sgm = grp * GS + sg;
+      f32x4 acc[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        acc[a] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias[a] + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kb = 0; kb < PER; ++kb) {
+        f32x4 wa[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) wa[a] = wbase[(size_t)a * wstride + (size_t)(sgm * PER + kb) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[grp & 1][sg * PER + kb][e], acc[a], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (sgm == 0) total[a] = acc[a];
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) total[a][i] = total[a][i] + acc[a][i];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// ---------------------------------------------- launch-per-step dense kernels, weights in LDS
+//
+// Thousands of rnn rows per step (wide beams under look_ahead): the schedule of k_decode_big's
+// stages as ordinary kernels.  One 512-thread workgroup per CU-sized share of the work: workgroup
+// (feature tile ft, row group g) copies its weight slice into LDS once per launch (96 KB for the
+// GRU at hidden size 512) and its eight waves walk the row tiles g, g + NG, ... of the step, a
+// whole tile per wave.  The big-tile kernels above stream every weight fragment from L2 for every
+// four row tiles and wait ~1 us per four k-blocks for it (0.38 of the MFMA peak); here the A
+// operands come from LDS and only the rows are streamed, one operand group ahead.
+__host__ __device__ inline int wt_groups(int n_cu, int nft) {  // row groups: about one workgroup per CU, a multiple of 8 (XCDs)
+  int ng = n_cu / nft;
+  ng = ng < 8 ? 8 : ng - ng % 8;
+  return ng;
+}
+template <int NKB>
+__global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int par, int layer, int ng) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* s_w = reinterpret_cast<f32x4*>(smem_raw);  // [3][NKB][64]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int grp = blockIdx.x % ng, ft = blockIdx.x / ng;  // (a row group's workgroups share an XCD's L2: block b -> XCD b % 8)
+  const int nft = m.Hp / 16;
+  const int nrows = st.nrows[par];
+  const int nrt = (nrows + 15) >> 4;
+  if (grp >= nrt) return;  // nothing in this group
+  for (int e = t; e < NKB * 64; e += 512) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) s_w[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[layer])[(size_t)(g * nft + ft) * NKB * 64 + e];
+  }
+  __syncthreads();
+  const float* bias[3] = {m.bhh[layer] + ft * 16, m.bhh[layer] + m.Hp + ft * 16, m.bhh[layer] + 2 * m.Hp + ft * 16};
+  for (int tile = grp + ng * w; tile < nrt; tile += ng * 8) {
+    const int row = 16 * tile + (lane & 15);
+    const bool valid = row < nrows;
+    const RnnRow me = st.rows[valid ? row : 16 * tile];
+    const float* hs = me.src >= 0 ? hid_ptr(m, st, me, me.src, layer) : m.h1 + (size_t)layer * m.Hp;
+    const int j4 = ft * 16 + 4 * q;
+    const float* gi = layer == 0 ? st.gi0 + (size_t)me.frame * m.G : st.gi_up + (size_t)(valid ? row : 16 * tile) * m.G;
+    const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
+    const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j4);
+    const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j4);
+    const f32x4 hprev = *reinterpret_cast<const f32x4*>(hs + j4);
+    f32x4 gh[3];
+    fullk_rows_plain<3, NKB, 2>(s_w, NKB * 64, bias, hs, gh);
+    if (valid) {
+      f32x4 out;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+      *reinterpret_cast<f32x4*>(const_cast<float*>(hid_ptr(m, st, me, me.dst, layer)) + j4) = out;
+    }
+  }
+}
+// HEAD 1: a1[row] = relu(b1 + W1 h'_top); HEAD 2: mean = b2 + W2 a1, running-mean update -> dst slot
+template <int NKB, int HEAD>
+__global__ __launch_bounds__(512) void k_wt_head(DevModel m, DecodeState st, int par, int ng) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* s_w = reinterpret_cast<f32x4*>(smem_raw);  // [NKB][64]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int grp = blockIdx.x % ng, ft = blockIdx.x / ng;
+  const int nrows = st.nrows[par];
+  const int nrt = (nrows + 15) >> 4;
+  if (grp >= nrt) return;
+  const f32x4* wg = reinterpret_cast<const f32x4*>(HEAD == 1 ? m.w1 : m.w2) + (size_t)ft * NKB * 64;
+  for (int e = t; e < NKB * 64; e += 512) s_w[e] = wg[e];
+  __syncthreads();
+  const float* bias[1] = {(HEAD == 1 ? m.b1 : m.b2) + ft * 16};
+  for (int tile = grp + ng * w; tile < nrt; tile += ng * 8) {
+    const int row = 16 * tile + (lane & 15);
+    const bool valid = row < nrows;
+    const int use = valid ? row : 16 * tile;
+    const RnnRow me = st.rows[use];
+    const int f4 = ft * 16 + 4 * q;
+    const float* in = HEAD == 1 ? hid_ptr(m, st, me, me.dst, m.depth - 1) : st.a1 + (size_t)use * m.Hp;
+    f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (HEAD == 2 && valid && me.src >= 0)
+      old = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.src) * m.Dp + f4);
+    f32x4 v[1];
+    fullk_rows_plain<1, NKB, 4>(s_w, 0, bias, in, v);
+    if (!valid) continue;
+    if (HEAD == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
+      *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f4) = v[0];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (me.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], me.nprev);
+        if (f4 + i >= m.D) v[0][i] = 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v[0];
+    }
+  }
+}
+
 template <int NA, int NKB, int GS, int KBS>
 __device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
                                                __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA],
