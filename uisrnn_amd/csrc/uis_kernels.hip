@@ -2349,59 +2349,46 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #endif
 }
 
-// ------------------------------------------------------------ resident decode, many utterances
-//
-// k_decode_resident's stages walk the row tiles in passes of three, every pass split in K over
-// the eight waves and closed by two workgroup barriers (LDS combine, epilogue): right for the
-// three row tiles of 64 utterances, wasteful for the dozens of row tiles of a thousand (the passes
-// of a stage run at ~55 % of their MFMA time: operand fetch, combine and epilogue are exposed in
-// every pass).  k_decode_big is the same launch -- same clusters, same in-launch barriers, same
-// selects from the global beam tables -- with the dense stages turned around: the workgroup's
-// W_hh slice (3 gates x all k-blocks, 96 KB at hidden size 512) and linear_mean1 slice live in
-// LDS, and a WAVE owns a row tile: it walks the full K of its tile (the segment chains of
-// uis_numerics.h combined on the fly, as in the big-tile per-step kernels) with A operands from
-// LDS and B operands (its 16 rows) streamed from L2 one segment ahead, then runs the epilogue on
-// its own accumulators.  No split-K partials, no workgroup barrier inside a stage, eight row
-// tiles in flight per CU.  The two mean-head weight slices share one LDS slot, refilled from L2
-// at the start of their stage.  Used for
-// ordinary decodes with more utterances than workgroups (U > 32 x clusters).
-
-// NA weight streams from `wbase` (LDS or global; stream a at wbase + a * wstride, [k block][lane])
-// against one row tile whose row for this lane starts at byte `boff` of `rsrc` (16 bytes per k
-// block at + kb * 64 + q * 16): total[a] = this lane's 4 features x its row.
-// GS = segments per operand group: the rows of group g + 1 are requested while group g is
-// multiplied (two register sets in turn; everything unrolled, scheduling fenced per segment so
-// that the weight reads of later segments are not hoisted into spills).
-// KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
-// k-block-major staging layout, where a wave's load is one contiguous KiB).
-// The first group arrives preloaded in `bfirst` (rows_first_group); while the LAST group is
-// multiplied the first group of the wave's NEXT row tile (at next_boff, if has_next) is requested
-// into `bfirst` again, so that a tile's dependent start-up (row descriptor -> address -> rows)
-// hides behind its predecessor's chain.
-template <int GB, int KBS>
-__device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&bfirst)[GB]) {
-  const int q = (threadIdx.x & 63) >> 4;
+// The schedule of k_decode_big's stages with plain loads from this lane's row (launch-per-step
+// kernels: the rows were written by earlier launches): NA weight streams in LDS against one row
+// tile.  The first operand group arrives preloaded in `bfirst`; the groups alternate between bfirst
+// and a second register set, the next one requested while the current one is multiplied, and
+// during the LAST group the first group of the wave's NEXT row tile (next_row, if has_next) goes
+// into bfirst: a tile's dependent start-up (descriptor -> address -> rows) hides behind its
+// predecessor's chain.
+template <int GB>
+__device__ __forceinline__ void rows_first_group_plain(const float* __restrict__ row, f32x4 (&bfirst)[GB]) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(row) + ((threadIdx.x & 63) >> 4);
 #pragma unroll
-  for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+  for (int k = 0; k < GB; ++k) bfirst[k] = bp[(size_t)k * 4];
 }
-// the same schedule with plain loads from this lane's row (launch-per-step kernels: the rows were
-// written by earlier launches): NA weight streams in LDS against one row tile, the operands of the
-// next group of GS segments requested while the current one is multiplied
 template <int NA, int NKB, int GS>
 __device__ __forceinline__ void fullk_rows_plain(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
-                                                 const float* __restrict__ row, f32x4 (&total)[NA]) {
+                                                 const float* __restrict__ row, f32x4 (&total)[NA],
+                                                 f32x4 (&bfirst)[GS * (NKB / UIS_KSPLIT)], const float* __restrict__ next_row,
+                                                 bool has_next) {
   constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
-  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT, "k-blocks divide into segments, segments into groups");
+  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT && NGRP % 2 == 0,
+                "k-blocks divide into segments, segments into an even number of groups");
   const int lane = threadIdx.x & 63, q = lane >> 4;
   const f32x4* bp = reinterpret_cast<const f32x4*>(row) + q;
-  f32x4 b[2][GB];
-#pragma unroll
-  for (int k = 0; k < GB; ++k) b[0][k] = bp[(size_t)k * 4];
+  const f32x4* bn = reinterpret_cast<const f32x4*>(next_row) + q;
+  f32x4 bsec[GB];
 #pragma unroll
   for (int grp = 0; grp < NGRP; ++grp) {
     if (grp + 1 < NGRP) {
+      if ((grp + 1) & 1) {
 #pragma unroll
-      for (int k = 0; k < GB; ++k) b[(grp + 1) & 1][k] = bp[(size_t)((grp + 1) * GB + k) * 4];
+        for (int k = 0; k < GB; ++k) bsec[k] = bp[(size_t)((grp + 1) * GB + k) * 4];
+      } else {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) bfirst[k] = bp[(size_t)((grp + 1) * GB + k) * 4];
+      }
+    }
+    const f32x4 (&b)[GB] = (grp & 1) ? bsec : bfirst;
+    if (grp + 1 == NGRP && has_next) {  // (the last group reads bsec) bfirst is free: the next tile's first group
+#pragma unroll
+      for (int k = 0; k < GB; ++k) bfirst[k] = bn[(size_t)k * 4];
     }
 #pragma unroll
     for (int sg = 0; sg < GS; ++sg) {
@@ -2419,7 +2406,7 @@ __device__ __forceinline__ void fullk_rows_plain(const f32x4* wbase, int wstride
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int a = 0; a < NA; ++a)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[grp & 1][sg * PER + kb][e], acc[a], 0, 0, 0);
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[sg * PER + kb][e], acc[a], 0, 0, 0);
       }
 #pragma unroll
       for (int a = 0; a < NA; ++a) {
@@ -2464,11 +2451,25 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
   }
   __syncthreads();
   const float* bias[3] = {m.bhh[layer] + ft * 16, m.bhh[layer] + m.Hp + ft * 16, m.bhh[layer] + 2 * m.Hp + ft * 16};
-  for (int tile = grp + ng * w; tile < nrt; tile += ng * 8) {
+  constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
+  auto fetch = [&](int tl, RnnRow& r_, const float*& hs_) {
+    const int row = 16 * tl + (lane & 15);
+    r_ = st.rows[row < nrows ? row : 16 * tl];  // (a tile's first row always exists)
+    hs_ = r_.src >= 0 ? hid_ptr(m, st, r_, r_.src, layer) : m.h1 + (size_t)layer * m.Hp;
+  };
+  int tile = grp + ng * w;
+  RnnRow me{};
+  const float* hs = m.h1;
+  f32x4 bfirst[GBG];
+  if (tile < nrt) { fetch(tile, me, hs); rows_first_group_plain<GBG>(hs, bfirst); }
+  while (tile < nrt) {
+    const int next = tile + ng * 8;
+    const bool has_next = next < nrt;
+    RnnRow me_n{};
+    const float* hs_n = m.h1;
+    if (has_next) fetch(next, me_n, hs_n);  // requested now, needed when this tile's chain is almost done
     const int row = 16 * tile + (lane & 15);
     const bool valid = row < nrows;
-    const RnnRow me = st.rows[valid ? row : 16 * tile];
-    const float* hs = me.src >= 0 ? hid_ptr(m, st, me, me.src, layer) : m.h1 + (size_t)layer * m.Hp;
     const int j4 = ft * 16 + 4 * q;
     const float* gi = layer == 0 ? st.gi0 + (size_t)me.frame * m.G : st.gi_up + (size_t)(valid ? row : 16 * tile) * m.G;
     const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
@@ -2476,7 +2477,7 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
     const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j4);
     const f32x4 hprev = *reinterpret_cast<const f32x4*>(hs + j4);
     f32x4 gh[3];
-    fullk_rows_plain<3, NKB, 2>(s_w, NKB * 64, bias, hs, gh);
+    fullk_rows_plain<3, NKB, GSG>(s_w, NKB * 64, bias, hs, gh, bfirst, hs_n, has_next);
     if (valid) {
       f32x4 out;
 #pragma unroll
@@ -2484,6 +2485,7 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
         out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
       *reinterpret_cast<f32x4*>(const_cast<float*>(hid_ptr(m, st, me, me.dst, layer)) + j4) = out;
     }
+    tile = next; me = me_n; hs = hs_n;
   }
 }
 // HEAD 1: a1[row] = relu(b1 + W1 h'_top); HEAD 2: mean = b2 + W2 a1, running-mean update -> dst slot
@@ -2500,34 +2502,85 @@ __global__ __launch_bounds__(512) void k_wt_head(DevModel m, DecodeState st, int
   for (int e = t; e < NKB * 64; e += 512) s_w[e] = wg[e];
   __syncthreads();
   const float* bias[1] = {(HEAD == 1 ? m.b1 : m.b2) + ft * 16};
-  for (int tile = grp + ng * w; tile < nrt; tile += ng * 8) {
+  constexpr int GSH = 2, GBH = GSH * (NKB / UIS_KSPLIT);
+  auto fetch = [&](int tl, RnnRow& r_, const float*& in_) {
+    const int row = 16 * tl + (lane & 15);
+    const int use = row < nrows ? row : 16 * tl;
+    r_ = st.rows[use];
+    in_ = HEAD == 1 ? hid_ptr(m, st, r_, r_.dst, m.depth - 1) : st.a1 + (size_t)use * m.Hp;
+  };
+  int tile = grp + ng * w;
+  RnnRow me{};
+  const float* in = st.a1;
+  f32x4 bfirst[GBH];
+  if (tile < nrt) { fetch(tile, me, in); rows_first_group_plain<GBH>(in, bfirst); }
+  while (tile < nrt) {
+    const int next = tile + ng * 8;
+    const bool has_next = next < nrt;
+    RnnRow me_n{};
+    const float* in_n = st.a1;
+    if (has_next) fetch(next, me_n, in_n);
     const int row = 16 * tile + (lane & 15);
     const bool valid = row < nrows;
-    const int use = valid ? row : 16 * tile;
-    const RnnRow me = st.rows[use];
     const int f4 = ft * 16 + 4 * q;
-    const float* in = HEAD == 1 ? hid_ptr(m, st, me, me.dst, m.depth - 1) : st.a1 + (size_t)use * m.Hp;
     f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
     if (HEAD == 2 && valid && me.src >= 0)
       old = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.src) * m.Dp + f4);
     f32x4 v[1];
-    fullk_rows_plain<1, NKB, 4>(s_w, 0, bias, in, v);
-    if (!valid) continue;
-    if (HEAD == 1) {
+    fullk_rows_plain<1, NKB, GSH>(s_w, 0, bias, in, v, bfirst, in_n, has_next);
+    if (valid) {
+      if (HEAD == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
-      *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f4) = v[0];
-    } else {
+        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
+        *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f4) = v[0];
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (me.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], me.nprev);
-        if (f4 + i >= m.D) v[0][i] = 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          if (me.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], me.nprev);
+          if (f4 + i >= m.D) v[0][i] = 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v[0];
       }
-      *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v[0];
     }
+    tile = next; me = me_n; in = in_n;
   }
 }
 
+// ------------------------------------------------------------ resident decode, many utterances
+//
+// k_decode_resident's stages walk the row tiles in passes of three, every pass split in K over
+// the eight waves and closed by two workgroup barriers (LDS combine, epilogue): right for the
+// three row tiles of 64 utterances, wasteful for the dozens of row tiles of a thousand (the passes
+// of a stage run at ~55 % of their MFMA time: operand fetch, combine and epilogue are exposed in
+// every pass).  k_decode_big is the same launch -- same clusters, same in-launch barriers, same
+// selects from the global beam tables -- with the dense stages turned around: the workgroup's
+// W_hh slice (3 gates x all k-blocks, 96 KB at hidden size 512) and linear_mean1 slice live in
+// LDS, and a WAVE owns a row tile: it walks the full K of its tile (the segment chains of
+// uis_numerics.h combined on the fly, as in the big-tile per-step kernels) with A operands from
+// LDS and B operands (its 16 rows) streamed from L2 one segment ahead, then runs the epilogue on
+// its own accumulators.  No split-K partials, no workgroup barrier inside a stage, eight row
+// tiles in flight per CU.  The two mean-head weight slices share one LDS slot, refilled from L2
+// at the start of their stage.  Used for
+// ordinary decodes with more utterances than workgroups (U > 32 x clusters).
+
+// NA weight streams from `wbase` (LDS or global; stream a at wbase + a * wstride, [k block][lane])
+// against one row tile whose row for this lane starts at byte `boff` of `rsrc` (16 bytes per k
+// block at + kb * 64 + q * 16): total[a] = this lane's 4 features x its row.
+// GS = segments per operand group: the rows of group g + 1 are requested while group g is
+// multiplied (two register sets in turn; everything unrolled, scheduling fenced per segment so
+// that the weight reads of later segments are not hoisted into spills).
+// KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
+// k-block-major staging layout, where a wave's load is one contiguous KiB).
+// The first group arrives preloaded in `bfirst` (rows_first_group); while the LAST group is
+// multiplied the first group of the wave's NEXT row tile (at next_boff, if has_next) is requested
+// into `bfirst` again, so that a tile's dependent start-up (row descriptor -> address -> rows)
+// hides behind its predecessor's chain.
+template <int GB, int KBS>
+__device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&bfirst)[GB]) {
+  const int q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+}
 template <int NA, int NKB, int GS, int KBS>
 __device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
                                                __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA],
