@@ -84,6 +84,8 @@ struct Scratch {
 #define UIS_MAX_GROUPS 8
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
+#define UIS_WINDOW_WIDE_LEVEL 256  // level capacity (hypotheses) from which k_window runs with more threads per utterance
+#define UIS_WINDOW_WIDE_NT 512
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
 #define UIS_STREAM_RESIDENT_MIN_STEPS 4  // uis_stream_push: steps per push from which the one-launch kernel is used
 #define UIS_H2D_CHUNKS 4     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection
@@ -436,7 +438,9 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
     if (st.L == 1 && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
       LAUNCH(UIS_K_SELECT, k_select_fast, dim3(st.U), dim3(256), (size_t)fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).total, m, st, par);
     else if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
-    else LAUNCH(UIS_K_EXPAND, k_window, dim3(st.U), dim3(256), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
+    else if (st.NC >= UIS_WINDOW_WIDE_LEVEL && !getenv("UIS_WINDOW_256"))  // hundreds of hypotheses per level: more threads per utterance
+      LAUNCH(UIS_K_EXPAND, k_window<UIS_WINDOW_WIDE_NT>, dim3(st.U), dim3(UIS_WINDOW_WIDE_NT), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
+    else LAUNCH(UIS_K_EXPAND, k_window<256>, dim3(st.U), dim3(256), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
     int rc = launch_rnn(h, lch, st, par, max_rows);
     if (rc) return rc;
   }
@@ -1026,7 +1030,8 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_gru<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window<UIS_WINDOW_WIDE_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return bail(fail(UIS_ERR_HIP, std::string("hipFuncSetAttribute(k_select): ") + hipGetErrorString(e)));
   if ((rc = bootstrap_constants(h, d_hinit))) return bail(rc);

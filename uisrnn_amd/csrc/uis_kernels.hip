@@ -2938,12 +2938,12 @@ __host__ __device__ inline size_t window_lds_bytes(const WindowScratch& w) {
   return w.hot_total <= 150 * 1024 ? w.hot_total : 0;
 }
 
-// Exclusive prefix sums over i in [0, n) of val(i) by 256 threads (contiguous chunk each);
-// emit(i, prefix) is called for every i; returns the total.  lds4: 4 ints of LDS.
-template <typename V, typename E>
+// Exclusive prefix sums over i in [0, n) of val(i) by NT threads (contiguous chunk each);
+// emit(i, prefix) is called for every i; returns the total.  lds4: NT / 64 ints of LDS.
+template <int NT, typename V, typename E>
 __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = (n + 255) >> 8;
+  const int chunk = (n + NT - 1) / NT;
   const int lo = tid * chunk < n ? tid * chunk : n;
   const int hi = lo + chunk < n ? lo + chunk : n;
   int cnt = 0;
@@ -2958,15 +2958,19 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
   __syncthreads();
   int base = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) { const int c = lds4[w]; if (w < wave) base += c; total += c; }
+  for (int w = 0; w < NT / 64; ++w) { const int c = lds4[w]; if (w < wave) base += c; total += c; }
   int run = base + incl - cnt;
   for (int i = lo; i < hi; ++i) { emit(i, run); run += val(i); }
   __syncthreads();
   return total;
 }
 
-__global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int par) {
-  __shared__ int lds4[8];  // (4 for the scans, 8 for the two-word reductions of the prune)
+// NT threads per utterance: 256 for narrow beams, more when a level holds hundreds of hypotheses
+// (every phase is a scan or a count over the level's candidates)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int par) {
+  constexpr int NW = NT / 64;
+  __shared__ int lds4[2 * NW];  // (NW for the scans, 2 NW for the two-word reductions of the prune)
   __shared__ int lds_misc[8];  // [0] nlive [1] nfinite
   const int u = blockIdx.x, tid = threadIdx.x;
   const int B = st.B, Kmax = st.Kmax, S = st.S, L = st.L, NC = st.NC;
@@ -3010,16 +3014,16 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   int* freelist = reinterpret_cast<int*>(scr + W.freelist);
 
   // ---- live cluster states of the input level, candidate offsets
-  for (int sl = tid; sl <= S; sl += 256) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
+  for (int sl = tid; sl <= S; sl += NT) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
   if (tid < 8) lds_misc[tid] = 0;
   __syncthreads();
-  for (int e = tid; e < n_in * Kmax; e += 256) {
+  for (int e = tid; e < n_in * Kmax; e += NT) {
     const int i = e / Kmax, c = e - i * Kmax;
     if (c < in.K[i]) live[in.slot[(size_t)i * Kmax + c]] = 1;
   }
-  const int C = block_scan(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
+  const int C = block_scan<NT>(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
   if (tid == 0) cbase[n_in] = C;
-  for (int sl = tid; sl < S; sl += 256)
+  for (int sl = tid; sl < S; sl += NT)
     if (live[sl]) livelist[atomicAdd(&lds_misc[0], 1)] = sl;
   __syncthreads();
   const int nlive = lds_misc[0];
@@ -3041,11 +3045,11 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
         xv[k] = in_ ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         wv[k] = in_ ? *reinterpret_cast<const f32x4*>(m.wgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      for (int i0 = 0; i0 < nlive; i0 += 64) {
+      for (int i0 = 0; i0 < nlive; i0 += 4 * (NT / 16)) {
         int sl[4]; bool act[4]; f32x4 mv[4][4];
 #pragma unroll
         for (int h2 = 0; h2 < 4; ++h2) {
-          const int i = i0 + 16 * h2 + grp;
+          const int i = i0 + (NT / 16) * h2 + grp;
           act[h2] = i < nlive;
           sl[h2] = livelist[act[h2] ? i : 0];
         }
@@ -3076,7 +3080,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
         }
       }
     } else {
-      for (int i0 = 0; i0 < nlive; i0 += 16) {
+      for (int i0 = 0; i0 < nlive; i0 += NT / 16) {
         const int i = i0 + grp;
         const bool act = i < nlive;
         const int sl = livelist[act ? i : 0];
@@ -3113,7 +3117,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cbase[mid] <= i) lo = mid; else hi = mid; }
     return lo;
   };
-  for (int i = tid; i < C; i += 256) {
+  for (int i = tid; i < C; i += NT) {
     const int b = node_of(i);
     const int c = i - cbase[b];
     const int Kb = in.K[b];
@@ -3136,12 +3140,12 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
   // ---- which candidates go on: all finite ones in order (expand) or the B best (prune)
   int keep;
   if (!last) {
-    const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; },
+    const int nfin = block_scan<NT>(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; },
                                 [&](int i, int pre) { if (key[i] != ~0ull && pre < NC) winv[pre] = i; }, lds4);
     keep = nfin;
     if (keep > NC) { keep = NC; if (tid == 0) atomicOr(&st.overflow[u], 2); }  // level capacity (not the cluster cap): bit 1
   } else {
-    const int nfin = block_scan(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
+    const int nfin = block_scan<NT>(C, [&](int i) { return key[i] != ~0ull ? 1 : 0; }, [&](int, int) {}, lds4);
     keep = nfin < B ? nfin : B;
     if (keep > 0) {
       // The `keep` smallest keys, in order.  Keys are unique (score bits, candidate index), so
@@ -3155,26 +3159,30 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
       // (64 workgroup-wide counts over up to 15 k keys -> about 22.)
       auto count_wg = [&](auto pred) {  // workgroup-wide count of pred(key)
         int c = 0;
-        for (int i = tid; i < C; i += 256) c += pred(key[i]) ? 1 : 0;
+        for (int i = tid; i < C; i += NT) c += pred(key[i]) ? 1 : 0;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
         __syncthreads();  // (lds4 of the previous count has been read by everybody)
         if ((tid & 63) == 0) lds4[tid >> 6] = c;
         __syncthreads();
-        return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+        int tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) tot += lds4[w2];
+        return tot;
       };
       unsigned hi_and = 0xffffffffu, hi_or = 0u;
-      for (int i = tid; i < C; i += 256) {
+      for (int i = tid; i < C; i += NT) {
         const unsigned long long k = key[i];
         if (k != ~0ull) { hi_and &= (unsigned)(k >> 32); hi_or |= (unsigned)(k >> 32); }
       }
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) { hi_and &= __shfl_xor(hi_and, off, 64); hi_or |= __shfl_xor(hi_or, off, 64); }
       __syncthreads();
-      if ((tid & 63) == 0) { lds4[tid >> 6] = (int)hi_and; lds4[4 + (tid >> 6)] = (int)hi_or; }
+      if ((tid & 63) == 0) { lds4[tid >> 6] = (int)hi_and; lds4[NW + (tid >> 6)] = (int)hi_or; }
       __syncthreads();
-      hi_and = (unsigned)(lds4[0] & lds4[1] & lds4[2] & lds4[3]);
-      hi_or = (unsigned)(lds4[4] | lds4[5] | lds4[6] | lds4[7]);
+      hi_and = 0xffffffffu; hi_or = 0u;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) { hi_and &= (unsigned)lds4[w2]; hi_or |= (unsigned)lds4[NW + w2]; }
       const unsigned diff = hi_or & ~hi_and;                    // score bits in which the finite keys differ
       const int top = diff ? 31 - __builtin_clz(diff) : -1;      // the highest of them
       unsigned khi = top >= 31 ? 0u : (hi_and & ~((2u << top) - 1u));  // the common prefix above it
@@ -3197,9 +3205,9 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
       const unsigned long long kstar = ((unsigned long long)khi << 32) | klo;
       // the winners (key <= K*) in candidate order, then each one's rank among them
       int* wl = ordv;  // (free until the leader bookkeeping below)
-      block_scan(C, [&](int i) { return key[i] <= kstar ? 1 : 0; },
+      block_scan<NT>(C, [&](int i) { return key[i] <= kstar ? 1 : 0; },
                  [&](int i, int pre) { if (key[i] <= kstar) wl[pre] = i; }, lds4);
-      for (int a = tid; a < keep; a += 256) {
+      for (int a = tid; a < keep; a += NT) {
         const unsigned long long ka = key[wl[a]];
         int rank = 0;
         for (int b2 = 0; b2 < keep; ++b2) rank += key[wl[b2]] < ka ? 1 : 0;
@@ -3211,7 +3219,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
 
   // ---- source cluster state per survivor; one rnn row per distinct source (index S = fresh cluster)
   const bool nodedup = (st.flags & 1u) != 0;
-  for (int r = tid; r < keep; r += 256) {
+  for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
     const int b = node_of(i);
     const int c = i - cbase[b];
@@ -3220,19 +3228,19 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
     if (!nodedup) atomicMin(&first[src], r);
   }
   __syncthreads();
-  for (int r = tid; r < keep; r += 256) leadv[r] = nodedup ? r : first[srcv[r]];
+  for (int r = tid; r < keep; r += NT) leadv[r] = nodedup ? r : first[srcv[r]];
   __syncthreads();
-  const int nlead = block_scan(keep, [&](int r) { return leadv[r] == r ? 1 : 0; },
+  const int nlead = block_scan<NT>(keep, [&](int r) { return leadv[r] == r ? 1 : 0; },
                                [&](int r, int pre) { ordv[r] = pre; }, lds4);
-  block_scan(S, [&](int sl) { return live[sl] ? 0 : 1; },
+  block_scan<NT>(S, [&](int sl) { return live[sl] ? 0 : 1; },
              [&](int sl, int pre) { if (!live[sl] && pre < nlead) freelist[pre] = sl; }, lds4);
-  for (int r = tid; r < keep; r += 256) if (leadv[r] == r) dstv[r] = freelist[ordv[r]];
+  for (int r = tid; r < keep; r += NT) if (leadv[r] == r) dstv[r] = freelist[ordv[r]];
   __syncthreads();
-  for (int r = tid; r < keep; r += 256) if (leadv[r] != r) dstv[r] = dstv[leadv[r]];
+  for (int r = tid; r < keep; r += NT) if (leadv[r] != r) dstv[r] = dstv[leadv[r]];
   __syncthreads();
 
   // ---- write the next level / the next beam
-  for (long e = tid; e < (long)keep * Kmax; e += 256) {
+  for (long e = tid; e < (long)keep * Kmax; e += NT) {
     const int r = (int)(e / Kmax), c2 = (int)(e - (long)r * Kmax);
     const int i = winv[r];
     const int b = node_of(i);
@@ -3249,7 +3257,7 @@ __global__ __launch_bounds__(256) void k_window(DevModel m, DecodeState st, int 
     }
   }
   uint16_t* bp = st.bp16 + ((size_t)st.bp_base[u] + (size_t)win * B) * (L + 1);
-  for (int r = tid; r < keep; r += 256) {
+  for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
     const int b = node_of(i);
     const int c = i - cbase[b];
