@@ -85,7 +85,7 @@ struct Scratch {
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
 #define UIS_WINDOW_WIDE_LEVEL 256  // level capacity (hypotheses) from which k_window runs with more threads per utterance
-#define UIS_WINDOW_WIDE_NT 512
+#define UIS_WINDOW_WIDE_NT 512   // (1024 measured the same)
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
 #define UIS_STREAM_RESIDENT_MIN_STEPS 4  // uis_stream_push: steps per push from which the one-launch kernel is used
 #define UIS_H2D_CHUNKS 4     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection
@@ -328,8 +328,7 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
   // thousands of rows: the big-tile kernels (4 row tiles x several feature tiles per workgroup,
   // full-K chains per wave) where the feature-tile counts divide
   // thousands of rows and hidden size 256 / 512: weights in LDS, a wave per row tile (k_wt_*)
-  if (wide && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64 &&
-      !getenv("UIS_NO_WT")) {
+  if (wide && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64) {
     const int nft = m.Hp / 16, nft2 = m.Dp / 16;
     const int ng1 = wt_groups(h->n_cu, nft), ng2 = wt_groups(h->n_cu, nft2);
     const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
@@ -438,7 +437,7 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
     if (st.L == 1 && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
       LAUNCH(UIS_K_SELECT, k_select_fast, dim3(st.U), dim3(256), (size_t)fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).total, m, st, par);
     else if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
-    else if (st.NC >= UIS_WINDOW_WIDE_LEVEL && !getenv("UIS_WINDOW_256"))  // hundreds of hypotheses per level: more threads per utterance
+    else if (st.NC >= UIS_WINDOW_WIDE_LEVEL)  // hundreds of hypotheses per level: more threads per utterance
       LAUNCH(UIS_K_EXPAND, k_window<UIS_WINDOW_WIDE_NT>, dim3(st.U), dim3(UIS_WINDOW_WIDE_NT), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
     else LAUNCH(UIS_K_EXPAND, k_window<256>, dim3(st.U), dim3(256), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
     int rc = launch_rnn(h, lch, st, par, max_rows);
