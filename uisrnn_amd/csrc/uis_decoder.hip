@@ -81,6 +81,7 @@ struct Scratch {
 };
 
 #define UIS_WIDE_TILE_ROWS 2048   // row capacity (about twice the rows actually run, after dedup) above which the 2x2 tiles win
+#define UIS_WT_ROWS 1280          // row capacity above which the LDS-weight kernels (k_wt_*) take over at hidden size 256 / 512
 #define UIS_MAX_GROUPS 8
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
 #define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
@@ -328,7 +329,8 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
   // thousands of rows: the big-tile kernels (4 row tiles x several feature tiles per workgroup,
   // full-K chains per wave) where the feature-tile counts divide
   // thousands of rows and hidden size 256 / 512: weights in LDS, a wave per row tile (k_wt_*)
-  if (wide && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64) {
+  // (measured crossover against the 1x1 split-K tiles: row capacity 1280 about equal, 1920 +11 %)
+  if (max_rows > UIS_WT_ROWS && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64) {
     const int nft = m.Hp / 16, nft2 = m.Dp / 16;
     const int ng1 = wt_groups(h->n_cu, nft), ng2 = wt_groups(h->n_cu, nft2);
     const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
