@@ -366,13 +366,13 @@ def main(argv=None):
       # hidden-side matvecs (3H x H MACs per surviving hypothesis / prefix)
       kclass = max(('gru', 'head1', 'head2', 'select', 'expand', 'upper_in'),
                    key=lambda k: prof['kernel_ms'][k])
-      # which family of dense kernels the library picks (uis_decoder.hip, launch_rnn): a row
-      # capacity above 2048 = a wave per row tile, with the weight slice in LDS at hidden size 256 / 512
+      # which family of dense kernels the library picks (uis_decoder.hip, launch_rnn): a wave per row
+      # tile above a row capacity of 1280 (weight slice in LDS, hidden size 256 / 512) or 2048 (others)
       level = beam
       for j in range(1, look):
         level = min(level * (state['cap'] + j), 32768)
-      wide = n_utt * (beam if look == 1 else level) > 2048 and not args.flags & 0x200
-      fam = ('k_wt' if hid in (256, 512) else 'k_big') if wide else 'k_dense'
+      cap_rows = 0 if args.flags & 0x200 else n_utt * (beam if look == 1 else level)
+      fam = 'k_wt' if hid in (256, 512) and cap_rows > 1280 else ('k_big' if cap_rows > 2048 else 'k_dense')
       kernel = {'gru': fam + '_gru', 'head1': fam + '_head1' if fam != 'k_wt' else 'k_wt_head<1>',
                 'head2': fam + '_head2' if fam != 'k_wt' else 'k_wt_head<2>',
                 'select': 'k_select_fast', 'expand': 'k_window', 'upper_in': 'k_dense_upper_in'}[kclass]
