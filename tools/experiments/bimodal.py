@@ -22,6 +22,14 @@ def run(tag):
     ms.append(out['stats']['decode_ms'])
   print(tag, 'decode_ms %.2f' % (sum(ms[1:]) / 3), flush=True)
   dec.close()
+if sys.argv[1] == 'tune':
+  # the placement tuner of the control words: handles created one after the other, ten decodes each
+  for k in range(8):
+    dec = _capi.Decoder(params)
+    ms = [dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr())['stats']['decode_ms'] for i in range(10)]
+    print('handle', k, 'decode_ms', ' '.join('%.2f' % v for v in ms), flush=True)
+    dec.close()
+  sys.exit(0)
 if sys.argv[1] == 'which':
   os.environ['UIS_ARENA_SHIFT'] = '0'
   for k in range(8):
