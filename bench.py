@@ -246,7 +246,8 @@ def main(argv=None):
         cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'])
   big = cfg['utterances_per_gpu'] * cfg['frames'] > 200_000 or cfg['look_ahead'] > 1
   steps = args.steps if args.steps is not None else (3 if big else 10)
-  warmup = args.warmup if args.warmup is not None else (1 if big else 5)  # 5: past the control-word placement trials
+  # five warm-up passes: the decoder tries its control-word placements on passes 2-5 of a shape
+  warmup = args.warmup if args.warmup is not None else (5 if cfg['utterances_per_gpu'] * cfg['frames'] <= 2_000_000 else 1)
 
   n_dev = torch.cuda.device_count()
   if n_dev < 1:

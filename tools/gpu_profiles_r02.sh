@@ -20,7 +20,7 @@ timeout 600 python bench.py --model tracker --no_cpu_baseline --no_host_buffers 
 # the launch-per-step path, for comparison
 timeout 600 python bench.py --flags 128 --no_cpu_baseline --no_host_buffers > gpurun_out/r02_bench_c1_stepwise.json 2>/dev/null
 # kernel trace of the SAME default command
-BENCH_ARGS="--steps 10 --warmup 2 --no_cpu_baseline" ./tools/gpu_prof.sh > gpurun_out/r02_prof_stats.log 2>&1
+BENCH_ARGS="--steps 10 --warmup 5 --no_cpu_baseline" ./tools/gpu_prof.sh > gpurun_out/r02_prof_stats.log 2>&1
 cp gpurun_out/kernel_stats.csv gpurun_out/r02_kernel_stats_bench.csv
 grep '"metric"' gpurun_out/prof_bench.log > gpurun_out/r02_bench_line_under_rocprof.json
 # PMC passes (separate runs per counter group)
