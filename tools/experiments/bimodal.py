@@ -30,6 +30,16 @@ if sys.argv[1] == 'tune':
     print('handle', k, 'decode_ms', ' '.join('%.2f' % v for v in ms), flush=True)
     dec.close()
   sys.exit(0)
+if sys.argv[1] == 'offsets':
+  # one handle, the control words at every offset given (bytes): device time of decodes 2-4 at each
+  dec = _capi.Decoder(params)
+  offs = [int(v) for v in sys.argv[2].split(',')]
+  for rep in range(2):
+    for off in offs:
+      os.environ['UIS_CTL_OFFSET'] = str(off)
+      ms = [dec.decode_device(frames.data_ptr(), offsets, 10, 1, 2, labels.data_ptr(), scores.data_ptr())['stats']['decode_ms'] for i in range(4)]
+      print('offset', off, 'decode_ms %.2f' % min(ms[1:]), flush=True)
+  sys.exit(0)
 if sys.argv[1] == 'which':
   os.environ['UIS_ARENA_SHIFT'] = '0'
   for k in range(8):

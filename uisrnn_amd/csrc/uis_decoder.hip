@@ -654,7 +654,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     if (tn.sig != sig) { tn = uis_handle::CtlTune{}; tn.sig = sig; }
     ctl_cand = (tn.phase >= 1 && tn.phase <= 4) ? tn.phase - 1 : tn.best;
   }
-  uint32_t* const ctl = reinterpret_cast<uint32_t*>(h->cluster_ctl.as<char>() + ctl_place[ctl_cand]);
+  size_t ctl_off = ctl_place[ctl_cand];
+  if (const char* e = getenv("UIS_CTL_OFFSET")) ctl_off = std::min<size_t>((size_t)atol(e) & ~(size_t)127, ctl_place[3]);  // experiments
+  uint32_t* const ctl = reinterpret_cast<uint32_t*>(h->cluster_ctl.as<char>() + ctl_off);
 
   // ---- per-decode tables
   std::vector<double> logblk(maxT + 2), logden(maxT + 2);
