@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UIS_ABI_VERSION 3
+#define UIS_ABI_VERSION 4
 
 typedef enum uis_status {
   UIS_OK = 0,
@@ -188,6 +188,23 @@ void uis_destroy(uis_handle* h);
 int32_t uis_decode(uis_handle* h, const float* frames, const int64_t* offsets,
                    int32_t n_utt, const uis_decode_opts* opts,
                    int32_t* labels_out, float* scores_out, uis_stats* stats);
+
+/*
+ * Same, taking the utterances the way the reference's predict() receives them
+ * (uisrnn/uisrnn.py:564-590: a list of [N_u, D] float64 arrays, dtype checked at
+ * :511-513) -- no packed float32 copy on the caller's side:
+ *   utterances : host, [n_utt] pointers, utterances[u] -> float64 [n_frames[u], D]
+ *                row-major, contiguous (may be NULL where n_frames[u] == 0)
+ *   n_frames   : host, int64, [n_utt]
+ * The cast to float32 (round to nearest even, what torch's .float() does at
+ * :524-526) is done by the library: a few host threads fill a pinned staging
+ * buffer chunk by chunk, each chunk's copy to the device and input projection
+ * running while the next chunk is cast.  labels_out covers sum(n_frames) frames
+ * in utterance order.
+ */
+int32_t uis_decode_f64(uis_handle* h, const double* const* utterances, const int64_t* n_frames,
+                       int32_t n_utt, const uis_decode_opts* opts,
+                       int32_t* labels_out, float* scores_out, uis_stats* stats);
 
 /*
  * Same, with frames / labels_out / scores_out resident on the handle's device

@@ -431,6 +431,34 @@ def test_cluster_cap_on_the_one_launch_decode(oracle_lib):
   assert model.predict(seqs, inference_args) == [x.tolist() for x in ref['labels']]
 
 
+@pytest.mark.parametrize('dim,hidden,threads', [(256, 512, '3'), (20, 24, '5'), (256, 512, '')])
+def test_float64_utterances_through_uis_decode_f64(dim, hidden, threads, oracle_lib, monkeypatch):
+  """uis_decode_f64 (the list of float64 arrays predict() receives, cast by the library's own
+  threads chunk by chunk) gives bit for bit what uis_decode gives on the caller-cast float32
+  frames: ragged lengths, empty utterances, several copy chunks, values that round in the cast."""
+  if threads:
+    monkeypatch.setenv('UIS_CAST_THREADS', threads)
+  params = synth.tracker_params(dim, hidden, 1, seed=0)
+  lengths = [300, 0, 431, 257, 1, 0, 390, 300] * 6   # 9474 frames: two copy chunks
+  seqs, _ = synth.make_utterances(9461, len(lengths), [max(n, 1) for n in lengths], dim)
+  rng = np.random.default_rng(5)
+  seqs = [(s[:n] + 1e-9 * rng.standard_normal((n, dim))) for s, n in zip(seqs, lengths)]  # not exactly representable in f32
+  frames = np.concatenate(seqs).astype(np.float32)
+  offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+  dec = _capi.Decoder(params)
+  want = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True)
+  got = dec.decode_f64(seqs, 10, 1, 2, want_beam_scores=True)
+  assert got['status'] == want['status'] == 0
+  assert np.array_equal(got['labels'], want['labels'])
+  assert np.array_equal(_bits(got['beam_scores']), _bits(want['beam_scores']))
+  # a second call with fewer frames reuses the staging buffer; nothing of the first call leaks in
+  got2 = dec.decode_f64(seqs[:8], 10, 1, 2)
+  want2 = dec.decode(frames[:offsets[8]], offsets[:9], 10, 1, 2)
+  assert np.array_equal(got2['labels'], want2['labels'])
+  assert np.array_equal(_bits(got2['scores']), _bits(want2['scores']))
+  assert dec.decode_f64([], 10, 1, 2)['labels'].size == 0
+
+
 def test_python_surface_and_demo_flow(tmp_path, oracle_lib):
   """uisrnn_amd.UISRNN.predict / parallel_predict / save+load, as the reference's demo uses them."""
   import subprocess

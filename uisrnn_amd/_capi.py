@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuisrnn_hip.so')
 
 UIS_OK = 0
-UIS_ABI_VERSION = 3   # include/uisrnn_hip.h
+UIS_ABI_VERSION = 4   # include/uisrnn_hip.h
 UIS_ERR_INVALID_ARG = -1
 UIS_ERR_DIM_MISMATCH = -2
 UIS_ERR_NO_DEVICE = -3
@@ -225,6 +225,10 @@ def load_library(path=None):
   lib.uis_decode_device.argtypes = [
       ctypes.c_void_p, ctypes.c_void_p, i64p, i32, ctypes.POINTER(DecodeOpts),
       ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Stats)]
+  lib.uis_decode_f64.restype = i32
+  lib.uis_decode_f64.argtypes = [
+      ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), i64p, i32, ctypes.POINTER(DecodeOpts),
+      i32p, _fp, ctypes.POINTER(Stats)]
   lib.uis_last_decode_info.restype = i32
   lib.uis_last_decode_info.argtypes = [ctypes.c_void_p, i32p, _fp]
   lib.uis_model_constants.restype = i32
@@ -257,7 +261,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
-    'uis_decode', 'uis_decode_device', 'uis_last_decode_info',
+    'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info',
     'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',
     'uis_stream_labels', 'uis_stream_end', 'uis_eval_accuracy', 'uis_eval_accuracy_device',
     'uis_eval_last_decode', 'uis_host_alloc', 'uis_host_free', 'uis_last_error')
@@ -360,6 +364,43 @@ class Decoder:
     rc = self._check(rc, 'uis_decode')
     out = {'labels': labels, 'scores': scores, 'stats': stats.as_dict(),
            'status': rc}
+    overflow = np.zeros(n_utt, dtype=np.int32)
+    beam_scores = (np.empty((n_utt, int(beam_size)), dtype=np.float32)
+                   if want_beam_scores else None)
+    rc2 = self._lib.uis_last_decode_info(
+        self._handle, overflow.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        beam_scores.ctypes.data_as(_fp) if want_beam_scores else None)
+    self._check(rc2, 'uis_last_decode_info')
+    out['overflow'] = overflow
+    if want_beam_scores:
+      out['beam_scores'] = beam_scores
+    return out
+
+  def decode_f64(self, sequences, beam_size, look_ahead, test_iteration,
+                 max_clusters=0, flags=0, want_beam_scores=False, n_streams=0):
+    """Decode a list of [N_u, D] float64 arrays as predict() receives them (uis_decode_f64:
+    the library casts to float32 on its own threads while earlier chunks travel to the device).
+
+    Returns the dict of decode(); labels are packed in utterance order.
+    """
+    seqs = [np.ascontiguousarray(s, dtype=np.float64) for s in sequences]  # (no copy when already so)
+    n_utt = len(seqs)
+    for s in seqs:
+      if s.ndim != 2 or (s.shape[0] and s.shape[1] != self.observation_dim):
+        raise ValueError('frames do not match observation_dim')
+    lens = np.array([s.shape[0] for s in seqs], dtype=np.int64)
+    total = int(lens.sum())
+    ptrs = (ctypes.c_void_p * max(n_utt, 1))(*[s.ctypes.data if s.shape[0] else None for s in seqs])
+    labels = np.empty(total, dtype=np.int32)
+    scores = np.empty(n_utt, dtype=np.float32)
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags, n_streams)
+    stats = Stats()
+    rc = self._lib.uis_decode_f64(
+        self._handle, ptrs, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,
+        ctypes.byref(opts), labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        scores.ctypes.data_as(_fp), ctypes.byref(stats))
+    rc = self._check(rc, 'uis_decode_f64')
+    out = {'labels': labels, 'scores': scores, 'stats': stats.as_dict(), 'status': rc}
     overflow = np.zeros(n_utt, dtype=np.int32)
     beam_scores = (np.empty((n_utt, int(beam_size)), dtype=np.float32)
                    if want_beam_scores else None)

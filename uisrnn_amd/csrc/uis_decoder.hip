@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "uis_kernels.hip"
@@ -174,6 +175,11 @@ struct uis_handle {
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
+  // uis_decode_f64: the caller's float64 utterances (set for the duration of that call) and the
+  // pinned float32 staging buffer they are cast into, chunk by chunk, ahead of each H2D copy
+  const double* const* src64 = nullptr;
+  float* h_cast = nullptr;
+  size_t h_cast_cap = 0;
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -459,6 +465,33 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
   return UIS_OK;
 }
 
+// float64 -> float32 of rows [f0, f1) of the packed frame matrix, read from the caller's
+// per-utterance arrays (the reference casts once with torch's .float(), round to nearest even,
+// uisrnn/uisrnn.py:524-526; so does a C++ double -> float conversion), by a few host threads.
+void cast_rows(const double* const* utt, const int64_t* offsets, int n_utt, int D, int64_t f0, int64_t f1, float* dst) {
+  auto work = [&](int64_t r0, int64_t r1) {
+    int u = (int)(std::upper_bound(offsets, offsets + n_utt + 1, r0) - offsets) - 1;  // the utterance holding row r0
+    for (int64_t r = r0; r < r1;) {
+      while (offsets[u + 1] <= r) ++u;  // (empty utterances)
+      const int64_t e = std::min(r1, offsets[u + 1]);
+      const double* src = utt[u] + (size_t)(r - offsets[u]) * D;
+      float* d = dst + (size_t)r * D;
+      const int64_t n = (e - r) * D;
+      for (int64_t i = 0; i < n; ++i) d[i] = (float)src[i];
+      r = e;
+    }
+  };
+  const int64_t rows = f1 - f0;
+  unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+  nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(1, rows * D / (1 << 17)));  // >= 1 MB of input per thread
+  if (nt <= 1) { work(f0, f1); return; }
+  std::vector<std::thread> pool;
+  for (unsigned k = 1; k < nt; ++k) pool.emplace_back(work, f0 + rows * k / nt, f0 + rows * (k + 1) / nt);
+  work(f0, f0 + rows / nt);
+  for (auto& th : pool) th.join();
+}
+
 int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats,
                 const float* h_frames = nullptr) {
@@ -702,6 +735,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
     for (int c = 0; c < n_chunks; ++c) {
       const int64_t f0 = F * c / n_chunks, f1 = F * (c + 1) / n_chunks;
+      if (h->src64) cast_rows(h->src64, offsets, n_utt, m.D, f0, f1, h->h_cast);  // (while chunk c-1 copies / projects)
       HIPCHK(hipMemcpyAsync(const_cast<float*>(d_frames) + (size_t)f0 * m.D, h_frames + (size_t)f0 * m.D,
                             (size_t)(f1 - f0) * m.D * 4, hipMemcpyHostToDevice, h->copy_stream));
       HIPCHK(hipEventRecord(h->h2d_done[c], h->copy_stream));
@@ -1000,6 +1034,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t sg : h->gstreams) { (void)hipStreamSynchronize(sg); (void)hipStreamDestroy(sg); }
   for (hipEvent_t e : h->h2d_done) (void)hipEventDestroy(e);
+  if (h->h_cast) (void)hipHostFree(h->h_cast);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1100,6 +1135,32 @@ UIS_EXPORT int32_t uis_decode(uis_handle* h, const float* frames, const int64_t*
   if (scores_out && n_utt > 0)
     HIPCHK(hipMemcpyAsync(scores_out, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return rc;
+}
+
+UIS_EXPORT int32_t uis_decode_f64(uis_handle* h, const double* const* utterances, const int64_t* n_frames, int32_t n_utt,
+                                  const uis_decode_opts* opts, int32_t* labels_out, float* scores_out, uis_stats* stats) {
+  if (!h || n_utt < 0 || (n_utt > 0 && (!utterances || !n_frames)))
+    return fail(UIS_ERR_INVALID_ARG, "null handle/utterances/n_frames or negative n_utt");
+  std::vector<int64_t> offsets((size_t)n_utt + 1, 0);
+  for (int u = 0; u < n_utt; ++u) {
+    if (n_frames[u] < 0 || (n_frames[u] > 0 && !utterances[u])) return fail(UIS_ERR_INVALID_ARG, "negative n_frames or null utterance");
+    offsets[u + 1] = offsets[u] + n_frames[u];
+  }
+  const int64_t F = offsets[n_utt];
+  const size_t need = (size_t)std::max<int64_t>(F, 1) * h->m.D * 4;
+  HIPCHK(hipSetDevice(h->device));
+  if (need > h->h_cast_cap) {  // grow only, like the device workspace
+    if (h->h_cast) { (void)hipHostFree(h->h_cast); h->h_cast = nullptr; h->h_cast_cap = 0; }
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(UIS_ERR_OOM, std::string("hipHostMalloc (float32 staging): ") + hipGetErrorString(e));
+    h->h_cast = static_cast<float*>(p);
+    h->h_cast_cap = need;
+  }
+  h->src64 = utterances;
+  const int rc = uis_decode(h, h->h_cast, offsets.data(), n_utt, opts, labels_out, scores_out, stats);
+  h->src64 = nullptr;
   return rc;
 }
 

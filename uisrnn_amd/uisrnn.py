@@ -173,28 +173,19 @@ class UISRNN:
     """
     decoder = decoder or self._get_decoder(device)
     n_utt = len(sequences)
-    lens = np.array([s.shape[0] for s in sequences], dtype=np.int64)
-    offsets = np.zeros(n_utt + 1, dtype=np.int64)
-    offsets[1:] = np.cumsum(lens)
-    frames = np.empty((int(offsets[-1]), self.observation_dim), dtype=np.float32)
-    for seq, start in zip(sequences, offsets[:-1]):
-      # float64 -> float32 once, like torch.from_numpy(seq).float() (uisrnn.py:525)
-      frames[start:start + seq.shape[0]] = seq
     results = [None] * n_utt
     pending = list(range(n_utt))
     cap = _initial_cluster_cap(args)
     stats = None
     while pending:
-      sub_lens = lens[pending]
+      # the float64 arrays go to the library as they are (uis_decode_f64): it casts to float32
+      # once, like torch.from_numpy(seq).float() (uisrnn.py:525), on its own threads while the
+      # earlier chunks are already travelling to the device
+      sub = [sequences[u] for u in pending]
       sub_off = np.zeros(len(pending) + 1, dtype=np.int64)
-      sub_off[1:] = np.cumsum(sub_lens)
-      if len(pending) == n_utt:
-        sub_frames = frames
-      else:
-        sub_frames = np.concatenate(
-            [frames[offsets[u]:offsets[u + 1]] for u in pending], axis=0)
-      out = decoder.decode(sub_frames, sub_off, args.beam_size, args.look_ahead,
-                           args.test_iteration, max_clusters=cap, flags=flags)
+      sub_off[1:] = np.cumsum([s.shape[0] for s in sub])
+      out = decoder.decode_f64(sub, args.beam_size, args.look_ahead,
+                               args.test_iteration, max_clusters=cap, flags=flags)
       if stats is None:
         stats = out['stats']
       still = []
