@@ -487,8 +487,14 @@ void cast_rows(const double* const* utt, const int64_t* offsets, int n_utt, int 
   nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(1, rows * D / (1 << 17)));  // >= 1 MB of input per thread
   if (nt <= 1) { work(f0, f1); return; }
   std::vector<std::thread> pool;
-  for (unsigned k = 1; k < nt; ++k) pool.emplace_back(work, f0 + rows * k / nt, f0 + rows * (k + 1) / nt);
+  unsigned started = 1;  // share 0 is this thread's
+  try {
+    pool.reserve(nt);
+    for (; started < nt; ++started) pool.emplace_back(work, f0 + rows * started / nt, f0 + rows * (started + 1) / nt);
+  } catch (...) {  // no more threads to be had: the shares that did not start are done here
+  }
   work(f0, f0 + rows / nt);
+  for (unsigned k = started; k < nt; ++k) work(f0 + rows * k / nt, f0 + rows * (k + 1) / nt);
   for (auto& th : pool) th.join();
 }
 
