@@ -456,9 +456,19 @@ def main(argv=None):
         'n_streams': stats.get('n_streams', 0),
         'roofline': roofline, 'cpu_baseline': cpu,
     }
-    print(json.dumps(result), flush=True)
+  # the JSON line is the last thing on stdout: whatever native libraries buffered there (RCCL's
+  # banner goes through C stdio) is flushed by every rank before rank 0 prints
+  sys.stdout.flush()
+  try:
+    import ctypes  # pylint: disable=import-outside-toplevel
+    ctypes.CDLL(None).fflush(None)
+  except OSError:
+    pass
   if use_dist:
     dist.barrier()
+  if result is not None:
+    print(json.dumps(result), flush=True)
+  if use_dist:
     dist.destroy_process_group()
   return result
 

@@ -27,7 +27,8 @@ _RANK_SCRIPT = textwrap.dedent('''
                                  reduce_device=torch.device('cpu'))
     assert len(calls) == 5
     assert gathered.view(world, 5)[1].tolist() == [1] * 5
-    print(json.dumps({{'rank': rank, 'elapsed': elapsed}}), flush=True)
+    sys.stdout.write(json.dumps({{'rank': rank, 'elapsed': elapsed}}) + chr(10))  # one write per record
+    sys.stdout.flush()
     dist.barrier()
     dist.destroy_process_group()
 ''')
@@ -50,7 +51,9 @@ def test_timed_region_world_2_gloo(tmp_path):
       break
   assert out.returncode == 0, out.stderr[-3000:]
   import json
-  recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith('{')]
+  import re
+  # (the two ranks share the pipe: records may end up on one line)
+  recs = [json.loads(r) for r in re.findall(r'\{[^{}]*\}', out.stdout)]
   assert sorted(r['rank'] for r in recs) == [0, 1]
   # every rank reports the SAME number: the slowest rank's (3 steps x 40 ms)
   assert abs(recs[0]['elapsed'] - recs[1]['elapsed']) < 1e-9

@@ -78,6 +78,10 @@ def main():
         assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), ('labels', fl, u, tag)
       assert np.array_equal(bits(out['beam_scores']), bits(ref['beam_scores'])), ('scores', fl, tag)
       n_decode += 1
+    out = dec.decode_f64(seqs, beam, look, tau, max_clusters=cap, want_beam_scores=True)  # predict()'s own input type
+    assert out['status'] == 0 and np.array_equal(bits(out['beam_scores']), bits(ref['beam_scores'])), ('f64', tag)
+    assert np.array_equal(out['labels'], np.concatenate([ref['labels'][u] for u in range(len(seqs))])), ('f64 labels', tag)
+    n_decode += 1
     if look == 1 and tau == 1:  # online decoding = predict_single with test_iteration 1
       for fl in (0, _capi.UIS_FLAG_PERSISTENT, _capi.UIS_FLAG_STEPWISE):
         try:
