@@ -251,6 +251,7 @@ int upload(uis_handle* h, const std::vector<float>& v, const float** dst) {
   return UIS_OK;
 }
 
+#define UIS_PROJ_WIDE_ROWS 2048  // frames from which the input projection runs its 2 x 4-tile-per-wave kernel
 inline dim3 dense_grid(long rows, int tiles) { return dim3((unsigned)((rows + 15) / 16), (unsigned)((tiles + 3) / 4), 1); }
 // 1-D, XCD-aware grid of the per-step dense kernels (dense_block_map in uis_kernels.hip)
 inline dim3 dense_grid_xcd(long rows, int tiles) {
@@ -725,8 +726,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                          d_frames + (size_t)f0 * m.D, h->xpad.as<float>() + (size_t)f0 * m.Dp, n, m.D, m.Dp);
       HIPCHK(hipGetLastError());
     }
-    LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
-           h->gi0.as<float>() + (size_t)f0 * m.G, n);
+    if (n >= UIS_PROJ_WIDE_ROWS)  // enough rows to fill the device with 32-row x 16-tile workgroups
+      LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_wide, dim3((unsigned)((n + 31) / 32), (unsigned)((m.G / 16 + 15) / 16)), dim3(256), 0, m,
+             d_x + (size_t)f0 * m.Dp, h->gi0.as<float>() + (size_t)f0 * m.G, n);
+    else
+      LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
+             h->gi0.as<float>() + (size_t)f0 * m.G, n);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m,
            d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n);
     return UIS_OK;

@@ -221,6 +221,70 @@ __global__ __launch_bounds__(256) void k_dense_input_proj(DevModel m, const floa
   if (valid) *reinterpret_cast<f32x4*>(gi0 + (size_t)row * m.G + f) = v;
 }
 
+// The same arithmetic for many frames (a whole decode's input): a wave owns 2 row tiles x 4 feature
+// tiles, so the rows are fetched once for four feature tiles and the weights once for two row
+// tiles -- the one-tile kernel above asks L2 for 32 KB per 16 x 16 outputs and is bound by that.
+__global__ __launch_bounds__(256) void k_dense_input_proj_wide(DevModel m, const float* __restrict__ x,
+                                                               float* __restrict__ gi0, long nframes) {
+  constexpr int NA = 4, NB = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
+  const int ntiles = m.G / 16, nKb = m.Dp / 16;
+  const int tile0 = (blockIdx.y * 4 + wave) * NA;
+  if (tile0 >= ntiles) return;
+  const long row0 = (long)blockIdx.x * (16 * NB);
+  if (row0 >= nframes) return;
+  long rows[NB];
+  bool valid[NB];
+  const f32x4* bp[NB];
+  const f32x4* wp[NA];
+  int tiles[NA];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    rows[r] = row0 + 16 * r + (lane & 15);
+    valid[r] = rows[r] < nframes;
+    if (!valid[r]) rows[r] = nframes - 1;
+    bp[r] = reinterpret_cast<const f32x4*>(x + (size_t)rows[r] * m.Dp) + q;
+  }
+#pragma unroll
+  for (int g = 0; g < NA; ++g) {
+    tiles[g] = tile0 + g < ntiles ? tile0 + g : ntiles - 1;  // (a tail group recomputes its last tile, not stored twice)
+    wp[g] = reinterpret_cast<const f32x4*>(m.wih[0]) + ((size_t)tiles[g] * nKb) * 64 + lane;
+  }
+  const int per = uis_kseg_blocks(nKb);
+  f32x4 total[NB][NA];
+#pragma unroll 1
+  for (int sgm = 0; sgm < UIS_KSPLIT; ++sgm) {
+    const int kb0 = sgm * per;
+    const int kb1 = kb0 + per < nKb ? kb0 + per : nKb;
+    f32x4 acc[NB][NA];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+#pragma unroll
+      for (int g = 0; g < NA; ++g)
+        acc[r][g] = sgm == 0 ? *reinterpret_cast<const f32x4*>(m.bih[0] + tiles[g] * 16 + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    if (kb0 < kb1) chain_blocks<NA, NB>(wp, bp, kb0, kb1, acc);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+#pragma unroll
+      for (int g = 0; g < NA; ++g) {
+        if (sgm == 0) total[r][g] = acc[r][g];
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) total[r][g][i] = total[r][g][i] + acc[r][g][i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+#pragma unroll
+    for (int g = 0; g < NA; ++g)
+      if (valid[r] && tile0 + g < ntiles)
+        *reinterpret_cast<f32x4*>(gi0 + (size_t)rows[r] * m.G + (tile0 + g) * 16 + q * 4) = total[r][g];
+  }
+}
+
 // Common prologue of the per-step kernels.  A workgroup owns RT consecutive row tiles and CT
 // consecutive feature tiles; which ones follows from blockIdx alone.  The row count (written
 // by this step's select) and the row descriptors are fetched together, so only ONE global
