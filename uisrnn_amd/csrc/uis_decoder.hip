@@ -726,10 +726,16 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                          d_frames + (size_t)f0 * m.D, h->xpad.as<float>() + (size_t)f0 * m.Dp, n, m.D, m.Dp);
       HIPCHK(hipGetLastError());
     }
-    if (n >= UIS_PROJ_WIDE_ROWS)  // enough rows to fill the device with 32-row x 16-tile workgroups
-      LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_wide, dim3((unsigned)((n + 31) / 32), (unsigned)((m.G / 16 + 15) / 16)), dim3(256), 0, m,
-             d_x + (size_t)f0 * m.Dp, h->gi0.as<float>() + (size_t)f0 * m.G, n);
-    else
+    if (n >= UIS_PROJ_WIDE_ROWS) {  // enough rows to fill the device with 32-row x 16-tile workgroups
+      const dim3 wgrid((unsigned)((n + 31) / 32), (unsigned)((m.G / 16 + 15) / 16));
+      const float* xin = d_x + (size_t)f0 * m.Dp;
+      float* gout = h->gi0.as<float>() + (size_t)f0 * m.G;
+      const bool pipe = !(opts->flags & UIS_FLAG_SMALL_TILES);  // (the flag keeps the plain walk for A/B runs)
+      if (pipe && m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n);
+      else if (pipe && m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n);
+      else if (pipe && m.Dp == 512) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n);
+      else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_wide, wgrid, dim3(256), 0, m, xin, gout, n);
+    } else
       LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
              h->gi0.as<float>() + (size_t)f0 * m.G, n);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m,

@@ -285,6 +285,108 @@ __global__ __launch_bounds__(256) void k_dense_input_proj_wide(DevModel m, const
   }
 }
 
+// The same tiles with the K walk software-pipelined, for observation_dim 128 * PER (PER k-blocks per
+// K segment, PER = 1, 2, 4): the operands of the next stage (two k-blocks; one when PER = 1) are
+// requested before the MFMAs of the current one, everything unrolled, two register sets in turn.
+// Without it a segment's loads wait for the previous segment's MFMAs and the MFMAs for the loads.
+// Same order of operations per accumulator as chain_blocks (k-blocks ascending, e = 0..3).
+template <int PER>
+__global__ __launch_bounds__(256) void k_dense_input_proj_pipe(DevModel m, const float* __restrict__ x,
+                                                               float* __restrict__ gi0, long nframes) {
+  constexpr int NA = 4, NB = 2;
+  constexpr int STG = PER >= 2 ? 2 : 1, SPS = PER / STG, NS = UIS_KSPLIT * SPS, NKB = UIS_KSPLIT * PER;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
+  const int ntiles = m.G / 16;
+  const int tile0 = (blockIdx.y * 4 + wave) * NA;
+  if (tile0 >= ntiles) return;
+  const long row0 = (long)blockIdx.x * (16 * NB);
+  if (row0 >= nframes) return;
+  long rows[NB];
+  bool valid[NB];
+  const f32x4* bp[NB];
+  const f32x4* wp[NA];
+  int tiles[NA];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    rows[r] = row0 + 16 * r + (lane & 15);
+    valid[r] = rows[r] < nframes;
+    if (!valid[r]) rows[r] = nframes - 1;
+    bp[r] = reinterpret_cast<const f32x4*>(x + (size_t)rows[r] * (NKB * 16)) + q;
+  }
+#pragma unroll
+  for (int g = 0; g < NA; ++g) {
+    tiles[g] = tile0 + g < ntiles ? tile0 + g : ntiles - 1;
+    wp[g] = reinterpret_cast<const f32x4*>(m.wih[0]) + ((size_t)tiles[g] * NKB) * 64 + lane;
+  }
+  f32x4 a[2][STG][NA], b[2][STG][NB], acc[NB][NA], total[NB][NA];
+#pragma unroll
+  for (int u = 0; u < STG; ++u) {
+#pragma unroll
+    for (int g = 0; g < NA; ++g) a[0][u][g] = wp[g][(size_t)u * 64];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) b[0][u][r] = bp[r][(size_t)u * 4];
+  }
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const int cur = st & 1, nxt = cur ^ 1;
+    if (st + 1 < NS) {
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int kk = (st + 1) * STG + u;
+#pragma unroll
+        for (int g = 0; g < NA; ++g) a[nxt][u][g] = wp[g][(size_t)kk * 64];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) b[nxt][u][r] = bp[r][(size_t)kk * 4];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the requests go out before this stage's MFMAs, not in the middle of them
+    if (st % SPS == 0) {  // a K segment starts: bias in front of the first, zeros otherwise
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+#pragma unroll
+        for (int g = 0; g < NA; ++g)
+          acc[r][g] = st == 0 ? *reinterpret_cast<const f32x4*>(m.bih[0] + tiles[g] * 16 + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < STG; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+#pragma unroll
+          for (int g = 0; g < NA; ++g)
+            acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][u][g][e], b[cur][u][r][e], acc[r][g], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (or the compiler hoists every load to the top: 256 AGPRs, one wave per SIMD)
+    if (st % SPS == SPS - 1) {  // the segment is complete: segments are combined left to right
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+#pragma unroll
+        for (int g = 0; g < NA; ++g) {
+          if (st == SPS - 1) total[r][g] = acc[r][g];
+          else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) total[r][g][i] = total[r][g][i] + acc[r][g][i];
+          }
+          // the sum is wanted HERE: left alone the compiler sinks all seven additions to the end
+          // of the kernel and keeps every segment's accumulators alive until then (396 registers)
+          asm volatile("" : "+v"(total[r][g]));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+#pragma unroll
+    for (int g = 0; g < NA; ++g)
+      if (valid[r] && tile0 + g < ntiles)
+        *reinterpret_cast<f32x4*>(gi0 + (size_t)rows[r] * m.G + (tile0 + g) * 16 + q * 4) = total[r][g];
+  }
+}
+
 // Common prologue of the per-step kernels.  A workgroup owns RT consecutive row tiles and CT
 // consecutive feature tiles; which ones follows from blockIdx alone.  The row count (written
 // by this step's select) and the row descriptors are fetched together, so only ONE global
