@@ -350,20 +350,27 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
   // (measured crossover against the 1x1 split-K tiles: row capacity 1280 about equal, 1920 +11 %)
   if (max_rows > UIS_WT_ROWS && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64) {
     const int nft = m.Hp / 16, nft2 = m.Dp / 16;
-    const int ng1 = wt_groups(h->n_cu, nft), ng2 = wt_groups(h->n_cu, nft2);
+    const int ng1 = wt_groups(h->n_cu, nft);
     const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
     for (int l = 0; l < m.depth; ++l) {
       if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
       if (m.Hp == 512) LAUNCH(UIS_K_GRU, k_wt_gru<32>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
       else LAUNCH(UIS_K_GRU, k_wt_gru<16>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
     }
+    // two feature tiles per workgroup of the heads where the tile count is even (measured on
+    // configs[2]: one 66.4 / 36.7 ms per pass for the two heads, two 49.0 / 30.9, four 55.1 / 39.4)
+    const int na1 = nft % 2 == 0 ? 2 : 1, na2 = nft2 % 2 == 0 ? 2 : 1;
+    const int nh1 = wt_groups(h->n_cu, nft / na1), nh2 = wt_groups(h->n_cu, nft2 / na2);
+#define UIS_WT_HEAD(NKB_, HEAD_, NA_, tiles_, ng_) \
+  LAUNCH(HEAD_ == 1 ? UIS_K_HEAD1 : UIS_K_HEAD2, (k_wt_head<NKB_, HEAD_, NA_>), dim3((tiles_) / NA_ * (ng_)), dim3(512), NA_ * kb_bytes, m, st, par, ng_)
     if (m.Hp == 512) {
-      LAUNCH(UIS_K_HEAD1, (k_wt_head<32, 1>), dim3(nft * ng1), dim3(512), kb_bytes, m, st, par, ng1);
-      LAUNCH(UIS_K_HEAD2, (k_wt_head<32, 2>), dim3(nft2 * ng2), dim3(512), kb_bytes, m, st, par, ng2);
+      if (na1 == 2) UIS_WT_HEAD(32, 1, 2, nft, nh1); else UIS_WT_HEAD(32, 1, 1, nft, nh1);
+      if (na2 == 2) UIS_WT_HEAD(32, 2, 2, nft2, nh2); else UIS_WT_HEAD(32, 2, 1, nft2, nh2);
     } else {
-      LAUNCH(UIS_K_HEAD1, (k_wt_head<16, 1>), dim3(nft * ng1), dim3(512), kb_bytes, m, st, par, ng1);
-      LAUNCH(UIS_K_HEAD2, (k_wt_head<16, 2>), dim3(nft2 * ng2), dim3(512), kb_bytes, m, st, par, ng2);
+      if (na1 == 2) UIS_WT_HEAD(16, 1, 2, nft, nh1); else UIS_WT_HEAD(16, 1, 1, nft, nh1);
+      if (na2 == 2) UIS_WT_HEAD(16, 2, 2, nft2, nh2); else UIS_WT_HEAD(16, 2, 1, nft2, nh2);
     }
+#undef UIS_WT_HEAD
     return UIS_OK;
   }
   if (wide && (m.Hp / 16) % 4 == 0 && (m.Dp / 16) % 4 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES)) {
@@ -1117,6 +1124,8 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_gru<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_head<32, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_head<32, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window<UIS_WINDOW_WIDE_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -2654,20 +2654,26 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
     tile = next; me = me_n; hs = hs_n;
   }
 }
-// HEAD 1: a1[row] = relu(b1 + W1 h'_top); HEAD 2: mean = b2 + W2 a1, running-mean update -> dst slot
-template <int NKB, int HEAD>
+// HEAD 1: a1[row] = relu(b1 + W1 h'_top); HEAD 2: mean = b2 + W2 a1, running-mean update -> dst slot.
+// NA feature tiles per workgroup (their weight slices side by side in LDS, 32 KB each at hidden size
+// 512): with one, a wave's 16 rows feed 4 MFMAs per k-block and eight waves ask L2 for the CU's full
+// 64 bytes per clock (the heads ran at 0.36-0.38 of the MFMA peak next to the three-gate GRU's 0.60);
+// every further tile divides that stream.
+template <int NKB, int HEAD, int NA>
 __global__ __launch_bounds__(512) void k_wt_head(DevModel m, DecodeState st, int par, int ng) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  f32x4* s_w = reinterpret_cast<f32x4*>(smem_raw);  // [NKB][64]
+  f32x4* s_w = reinterpret_cast<f32x4*>(smem_raw);  // [NA][NKB][64]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
-  const int grp = blockIdx.x % ng, ft = blockIdx.x / ng;
+  const int grp = blockIdx.x % ng, ft0 = (blockIdx.x / ng) * NA;
   const int nrows = st.nrows[par];
   const int nrt = (nrows + 15) >> 4;
   if (grp >= nrt) return;
-  const f32x4* wg = reinterpret_cast<const f32x4*>(HEAD == 1 ? m.w1 : m.w2) + (size_t)ft * NKB * 64;
-  for (int e = t; e < NKB * 64; e += 512) s_w[e] = wg[e];
+  const f32x4* wg = reinterpret_cast<const f32x4*>(HEAD == 1 ? m.w1 : m.w2) + (size_t)ft0 * NKB * 64;
+  for (int e = t; e < NA * NKB * 64; e += 512) s_w[e] = wg[e];  // (consecutive feature tiles are consecutive in memory)
   __syncthreads();
-  const float* bias[1] = {(HEAD == 1 ? m.b1 : m.b2) + ft * 16};
+  const float* bias[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) bias[a] = (HEAD == 1 ? m.b1 : m.b2) + (ft0 + a) * 16;
   constexpr int GSH = 2, GBH = GSH * (NKB / UIS_KSPLIT);
   auto fetch = [&](int tl, RnnRow& r_, const float*& in_) {
     const int row = 16 * tl + (lane & 15);
@@ -2688,24 +2694,31 @@ __global__ __launch_bounds__(512) void k_wt_head(DevModel m, DecodeState st, int
     if (has_next) fetch(next, me_n, in_n);
     const int row = 16 * tile + (lane & 15);
     const bool valid = row < nrows;
-    const int f4 = ft * 16 + 4 * q;
-    f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (HEAD == 2 && valid && me.src >= 0)
-      old = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.src) * m.Dp + f4);
-    f32x4 v[1];
-    fullk_rows_plain<1, NKB, GSH>(s_w, 0, bias, in, v, bfirst, in_n, has_next);
+    f32x4 old[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      old[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (HEAD == 2 && valid && me.src >= 0)
+        old[a] = *reinterpret_cast<const f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.src) * m.Dp + (ft0 + a) * 16 + 4 * q);
+    }
+    f32x4 v[NA];
+    fullk_rows_plain<NA, NKB, GSH>(s_w, NKB * 64, bias, in, v, bfirst, in_n, has_next);
     if (valid) {
-      if (HEAD == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
-        *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f4) = v[0];
-      } else {
+      for (int a = 0; a < NA; ++a) {
+        const int f4 = (ft0 + a) * 16 + 4 * q;
+        if (HEAD == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (me.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], me.nprev);
-          if (f4 + i >= m.D) v[0][i] = 0.0f;
+          for (int i = 0; i < 4; ++i) v[a][i] = v[a][i] > 0.0f ? v[a][i] : 0.0f;
+          *reinterpret_cast<f32x4*>(st.a1 + (size_t)row * m.Hp + f4) = v[a];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (me.src >= 0) v[a][i] = uis_mean_update(old[a][i], v[a][i], me.nprev);
+            if (f4 + i >= m.D) v[a][i] = 0.0f;
+          }
+          *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v[a];
         }
-        *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)me.utt * st.S + me.dst) * m.Dp + f4) = v[0];
       }
     }
     tile = next; me = me_n; in = in_n;
