@@ -951,7 +951,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     if (++tn.phase == 5) {
       tn.best = 0;
       for (int k = 1; k < 4; ++k)
-        if (tn.ms[k] < 0.99f * tn.ms[tn.best]) tn.best = k;  // (another placement has to win by 1 %)
+        if (tn.ms[k] < 0.995f * tn.ms[tn.best]) tn.best = k;  // (another placement has to win by 0.5 %: repeats agree to 0.1 %)
     }
   }
   int n_over = 0, n_level = 0;
