@@ -10,6 +10,7 @@ Nothing here is used by the product; the files it writes under tests/golden/ are
   python tests/golden/make_trained.py predict_d256 100 # reference predict() on 100-frame utterances
   python tests/golden/make_trained.py predict_d256 500
   python tests/golden/make_trained.py predict_d256 1000
+  python tests/golden/make_trained.py predict_d512 100 # the configs[4] shape: observation_dim 512, beam 20
   python tests/golden/make_trained.py wholebox         # reference whole-box CPU rate (8 x 1 thread)
 
 Outputs
@@ -53,6 +54,8 @@ import make_golden  # noqa: E402  pylint: disable=wrong-import-position
 D256_TRAIN_SEED = 5000
 D256_TEST_SEED = {100: 6100, 500: 6500, 1000: 7000}
 D256_TEST_COUNT = {100: 4, 500: 2, 1000: 2}
+D512_TEST_SEED = {100: 8100}   # BASELINE configs[4]: observation_dim 512, beam 20
+D512_TEST_COUNT = {100: 4}
 
 
 def _seed_all():
@@ -252,31 +255,35 @@ def train_d256(dim=256):
 
 def _predict_d256_one(job):
   """Worker: one utterance through the reference (one torch thread)."""
-  n_frames, u = job
+  n_frames, u, dim, beam = job
   import torch  # pylint: disable=import-outside-toplevel
   torch.set_num_threads(1)
   from uisrnn_amd import synth  # pylint: disable=import-outside-toplevel
   uisrnn = make_golden.import_reference()
-  model_args, _, inference_args = _d256_args(uisrnn)
-  path = os.path.join(HERE, 'trained_d256.uisrnn')
+  model_args, _, inference_args = _d256_args(uisrnn, dim)
+  path = os.path.join(HERE, 'trained_d{}.uisrnn'.format(dim))
   model = _load_reference_model(uisrnn, model_args, path)
-  seq, truth = synth.make_utterance(D256_TEST_SEED[n_frames] + u, n_frames, 256)
-  run = dict(beam_size=10, look_ahead=1, test_iteration=2)
+  seeds = D256_TEST_SEED if dim == 256 else D512_TEST_SEED
+  seq, truth = synth.make_utterance(seeds[n_frames] + u, n_frames, dim)
+  run = dict(beam_size=beam, look_ahead=1, test_iteration=2)
   out = _record(model, inference_args, _params_of(path), [seq], run)
   acc = uisrnn.compute_sequence_match_accuracy(out['labels_0'].tolist(),
                                                [str(i) for i in truth])
-  print('n={} u={} secs {:.0f} accuracy {:.3f} best {}'.format(
-      n_frames, u, out['secs'][0], acc, out['best'][0]), flush=True)
+  print('d={} n={} u={} secs {:.0f} accuracy {:.3f} best {}'.format(
+      dim, n_frames, u, out['secs'][0], acc, out['best'][0]), flush=True)
   out['accuracy'] = np.float64(acc)
   return out
 
 
-def predict_d256(n_frames):
-  count = D256_TEST_COUNT[n_frames]
+def predict_d256(n_frames, dim=256, beam=10):
+  """predict() of the reference on the trained model of that dim (256: beam 10; 512: the
+  BASELINE configs[4] shape, beam 20), utterances regenerated from their seeds by the tests."""
+  seeds, counts = (D256_TEST_SEED, D256_TEST_COUNT) if dim == 256 else (D512_TEST_SEED, D512_TEST_COUNT)
+  count = counts[n_frames]
   with multiprocessing.get_context('spawn').Pool(min(count, 4)) as pool:
-    parts = pool.map(_predict_d256_one, [(n_frames, u) for u in range(count)])
-  out = {'n_utt': np.int64(count), 'cfg': parts[0]['cfg'],
-         'utt_seed': np.int64(D256_TEST_SEED[n_frames]), 'n_frames': np.int64(n_frames),
+    parts = pool.map(_predict_d256_one, [(n_frames, u, dim, beam) for u in range(count)])
+  out = {'n_utt': np.int64(count), 'cfg': parts[0]['cfg'], 'dim': np.int64(dim),
+         'utt_seed': np.int64(seeds[n_frames]), 'n_frames': np.int64(n_frames),
          'best': np.concatenate([p['best'] for p in parts]),
          'beam': np.concatenate([p['beam'] for p in parts]),
          'secs': np.concatenate([p['secs'] for p in parts]),
@@ -287,8 +294,8 @@ def predict_d256(n_frames):
     for key in ('alt_labels', 'alt_rescored', 'alt_margin'):
       if key + '_0' in p:
         out['{}_{}'.format(key, u)] = p[key + '_0']
-  np.savez_compressed(os.path.join(HERE, 'trained_d256_n{}.npz'.format(n_frames)), **out)
-  print('wrote trained_d256_n{}'.format(n_frames))
+  np.savez_compressed(os.path.join(HERE, 'trained_d{}_n{}.npz'.format(dim, n_frames)), **out)
+  print('wrote trained_d{}_n{}'.format(dim, n_frames))
 
 
 def _wholebox_worker(job):
@@ -354,6 +361,8 @@ def main():
     train_d256(512)
   elif cmd == 'predict_d256':
     predict_d256(int(sys.argv[2]))
+  elif cmd == 'predict_d512':
+    predict_d256(int(sys.argv[2]), dim=512, beam=20)
   elif cmd == 'wholebox':
     wholebox()
   else:

@@ -28,6 +28,7 @@ TRAINED_CASES = {
     'trained_d256_n100': 'trained_d256.uisrnn',
     'trained_d256_n500': 'trained_d256.uisrnn',
     'trained_d256_n1000': 'trained_d256.uisrnn',
+    'trained_d512_n100': 'trained_d512.uisrnn',
 }
 
 
@@ -48,8 +49,9 @@ def load_trained(name):
   n_utt = int(data['n_utt'])
   if 'seq_0' in data.files:
     seqs = [data['seq_{}'.format(u)] for u in range(n_utt)]
-  else:  # D=256 utterances are regenerated from their seeds (uisrnn_amd.synth)
-    seqs = [synth.make_utterance(int(data['utt_seed']) + u, int(data['n_frames']), 256)[0]
+  else:  # D=256 / 512 utterances are regenerated from their seeds (uisrnn_amd.synth)
+    dim = int(data['dim']) if 'dim' in data.files else 256
+    seqs = [synth.make_utterance(int(data['utt_seed']) + u, int(data['n_frames']), dim)[0]
             for u in range(n_utt)]
   alt = {}
   for u in range(n_utt):

@@ -72,8 +72,8 @@ def test_four_cluster_toy_accuracy_is_one(tmp_path):
   assert loaded.transition_bias == model.transition_bias
 
 
-@pytest.mark.parametrize('name', [n for n in golden_util.trained_names() if n.startswith('trained_d256')])
-def test_trained_d256_against_reference_and_oracle(name, oracle_lib):
+@pytest.mark.parametrize('name', [n for n in golden_util.trained_names() if n.startswith(('trained_d256', 'trained_d512'))])
+def test_trained_d256_d512_against_reference_and_oracle(name, oracle_lib):
   case = golden_util.load_trained(name)
   beam, look, tau = case['cfg']
   dec = _capi.Decoder(case['params'])
