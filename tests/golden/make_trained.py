@@ -11,6 +11,7 @@ Nothing here is used by the product; the files it writes under tests/golden/ are
   python tests/golden/make_trained.py predict_d256 500
   python tests/golden/make_trained.py predict_d256 1000
   python tests/golden/make_trained.py predict_d512 100 # the configs[4] shape: observation_dim 512, beam 20
+  python tests/golden/make_trained.py predict_d256_l2 40 # the configs[2] shape: beam 50, look_ahead 2
   python tests/golden/make_trained.py wholebox         # reference whole-box CPU rate (8 x 1 thread)
 
 Outputs
@@ -52,8 +53,8 @@ sys.path.insert(0, HERE)
 import make_golden  # noqa: E402  pylint: disable=wrong-import-position
 
 D256_TRAIN_SEED = 5000
-D256_TEST_SEED = {100: 6100, 500: 6500, 1000: 7000}
-D256_TEST_COUNT = {100: 4, 500: 2, 1000: 2}
+D256_TEST_SEED = {100: 6100, 500: 6500, 1000: 7000, 40: 6040}   # 40: the look_ahead-2 fixture (configs[2] shape)
+D256_TEST_COUNT = {100: 4, 500: 2, 1000: 2, 40: 4}
 D512_TEST_SEED = {100: 8100}   # BASELINE configs[4]: observation_dim 512, beam 20
 D512_TEST_COUNT = {100: 4}
 
@@ -255,7 +256,7 @@ def train_d256(dim=256):
 
 def _predict_d256_one(job):
   """Worker: one utterance through the reference (one torch thread)."""
-  n_frames, u, dim, beam = job
+  n_frames, u, dim, beam, look = job
   import torch  # pylint: disable=import-outside-toplevel
   torch.set_num_threads(1)
   from uisrnn_amd import synth  # pylint: disable=import-outside-toplevel
@@ -265,7 +266,7 @@ def _predict_d256_one(job):
   model = _load_reference_model(uisrnn, model_args, path)
   seeds = D256_TEST_SEED if dim == 256 else D512_TEST_SEED
   seq, truth = synth.make_utterance(seeds[n_frames] + u, n_frames, dim)
-  run = dict(beam_size=beam, look_ahead=1, test_iteration=2)
+  run = dict(beam_size=beam, look_ahead=look, test_iteration=2)
   out = _record(model, inference_args, _params_of(path), [seq], run)
   acc = uisrnn.compute_sequence_match_accuracy(out['labels_0'].tolist(),
                                                [str(i) for i in truth])
@@ -275,13 +276,13 @@ def _predict_d256_one(job):
   return out
 
 
-def predict_d256(n_frames, dim=256, beam=10):
+def predict_d256(n_frames, dim=256, beam=10, look=1, tag=''):
   """predict() of the reference on the trained model of that dim (256: beam 10; 512: the
   BASELINE configs[4] shape, beam 20), utterances regenerated from their seeds by the tests."""
   seeds, counts = (D256_TEST_SEED, D256_TEST_COUNT) if dim == 256 else (D512_TEST_SEED, D512_TEST_COUNT)
   count = counts[n_frames]
   with multiprocessing.get_context('spawn').Pool(min(count, 4)) as pool:
-    parts = pool.map(_predict_d256_one, [(n_frames, u, dim, beam) for u in range(count)])
+    parts = pool.map(_predict_d256_one, [(n_frames, u, dim, beam, look) for u in range(count)])
   out = {'n_utt': np.int64(count), 'cfg': parts[0]['cfg'], 'dim': np.int64(dim),
          'utt_seed': np.int64(seeds[n_frames]), 'n_frames': np.int64(n_frames),
          'best': np.concatenate([p['best'] for p in parts]),
@@ -294,8 +295,8 @@ def predict_d256(n_frames, dim=256, beam=10):
     for key in ('alt_labels', 'alt_rescored', 'alt_margin'):
       if key + '_0' in p:
         out['{}_{}'.format(key, u)] = p[key + '_0']
-  np.savez_compressed(os.path.join(HERE, 'trained_d{}_n{}.npz'.format(dim, n_frames)), **out)
-  print('wrote trained_d{}_n{}'.format(dim, n_frames))
+  np.savez_compressed(os.path.join(HERE, 'trained_d{}{}_n{}.npz'.format(dim, tag, n_frames)), **out)
+  print('wrote trained_d{}{}_n{}'.format(dim, tag, n_frames))
 
 
 def _wholebox_worker(job):
@@ -361,6 +362,8 @@ def main():
     train_d256(512)
   elif cmd == 'predict_d256':
     predict_d256(int(sys.argv[2]))
+  elif cmd == 'predict_d256_l2':  # the configs[2] shape: beam 50, look_ahead 2
+    predict_d256(int(sys.argv[2]), beam=50, look=2, tag='_l2')
   elif cmd == 'predict_d512':
     predict_d256(int(sys.argv[2]), dim=512, beam=20)
   elif cmd == 'wholebox':

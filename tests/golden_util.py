@@ -29,6 +29,7 @@ TRAINED_CASES = {
     'trained_d256_n500': 'trained_d256.uisrnn',
     'trained_d256_n1000': 'trained_d256.uisrnn',
     'trained_d512_n100': 'trained_d512.uisrnn',
+    'trained_d256_l2_n40': 'trained_d256.uisrnn',
 }
 
 
