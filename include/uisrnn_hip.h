@@ -117,6 +117,14 @@ typedef struct uis_decode_opts {
                                     the next push starts a new one).  Needs the one-launch shape, at
                                     most one utterance per compute unit, unpadded observation_dim;
                                     pushes of more than 16 frames per utterance go the ordinary way */
+#define UIS_FLAG_OWNER_SELECT 0x800u /* one-launch decode: keep the select of an utterance on ONE
+                                    workgroup (k_decode_resident) even where the replicated select
+                                    applies (k_decode_rs: at most 8 utterances per XCD, every
+                                    workgroup of the XCD decides all of them, one wave each -- one
+                                    in-launch hand-off less per step and a select short enough for a
+                                    single wave); A/B switch, results are bit-identical either way */
+#define UIS_FLAG_REPLICATED_SELECT 0x1000u /* one-launch decode: REQUIRE-if-applicable the replicated select
+                                    (k_decode_rs) where it is not the default (A/B switch)         */
 #define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
                                     a wrong XCD, as if the (observed, not promised) workgroup
                                     placement had changed.  The call must then fall back to the

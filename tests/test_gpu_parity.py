@@ -38,6 +38,10 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
   variants = [flags]
   if not flags & _PATH_FLAGS and look_ahead == 1 and n_streams in (0, 1):
     variants.append(flags | _capi.UIS_FLAG_STEPWISE)
+    # ... and, where the replicated select (k_decode_rs) is the default, with the select of an
+    # utterance on one workgroup (k_decode_resident) as well
+    variants.append(flags | _capi.UIS_FLAG_OWNER_SELECT)
+    variants.append(flags | _capi.UIS_FLAG_REPLICATED_SELECT)
   for fl in variants:
     # intermediate look-ahead levels hold hypotheses with up to look_ahead - 1 more clusters
     # than any survivor

@@ -34,6 +34,8 @@ UIS_FLAG_STEPWISE = 0x80
 UIS_FLAG_TEST_MISPLACED = 0x100
 UIS_FLAG_SMALL_TILES = 0x200
 UIS_FLAG_PERSISTENT = 0x400
+UIS_FLAG_OWNER_SELECT = 0x800
+UIS_FLAG_REPLICATED_SELECT = 0x1000
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',

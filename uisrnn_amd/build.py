@@ -16,6 +16,7 @@ SOURCES = [os.path.join(_HERE, 'csrc', 'uis_decoder.hip')]
 DEPENDS = SOURCES + [
     os.path.join(_HERE, 'csrc', 'uis_kernels.hip'),
     os.path.join(_HERE, 'csrc', 'uis_kernels.h'),
+    os.path.join(_HERE, 'csrc', 'uis_select_rs.hip'),
     os.path.join(_HERE, 'csrc', 'uis_eval.hip'),
     os.path.join(_ROOT, 'include', 'uis_numerics.h'),
     os.path.join(_ROOT, 'include', 'uisrnn_hip.h'),

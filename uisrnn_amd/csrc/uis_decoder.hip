@@ -172,7 +172,7 @@ struct uis_handle {
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
-  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores;
+  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab;
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
   // uis_decode_f64: the caller's float64 utterances (set for the duration of that call) and the
@@ -655,6 +655,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const size_t ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
   static const size_t ctl_place[4] = {0, 8192, (size_t)1 << 20, ((size_t)1 << 20) + 8192};
   ENSURE(cluster_ctl, ctl_place[3] + ((ctl_words * 4 + 4095) & ~(size_t)4095));
+  // the one-launch decode with the REPLICATED select (k_decode_rs, uis_select_rs.hip): at most 8
+  // utterances per cluster, one per wave in every workgroup; the default where it applies
+  const bool rs = resident && !(opts->flags & UIS_FLAG_OWNER_SELECT) &&
+                  (UIS_RS_DEFAULT || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) && m.Dp <= 256 &&
+                  rs_select_ok(B, Kmax, S, U, ncl, (long)maxT) &&
+                  resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+  if (rs) ENSURE(mse_tab, (size_t)2 * U * S * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -808,6 +815,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       st.rx_stride = rx_stride;
       st.rx_nrows = reinterpret_cast<int32_t*>(ctl) + 32;
       st.rx_bar = ctl + 32 + UIS_MAX_CLUSTERS * 32;
+      if (rs) st.mse_tab = h->mse_tab.as<float>() + 0;  // (one group: resident_ok)
     }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;
@@ -843,10 +851,25 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
       const bool big = U > 32 * ncl && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
                        big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
-      const size_t shmem = std::max<size_t>(big ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
+      const size_t shmem = std::max<size_t>(rs    ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
+                                            : big ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
+                                                  : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
+#define UIS_RS_CASE(HPV, DPV)                                                                                         \
+  if (m.Hp == HPV && m.Dp == DPV && rs) {                                                                            \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_rs<HPV, DPV>),                               \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_rs<HPV, DPV>, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m,   \
+                                 gp.st)))                                                                            \
+      return rc;                                                                                                     \
+  }
+      UIS_RS_CASE(512, 256)
+      UIS_RS_CASE(512, 128)
+      UIS_RS_CASE(256, 256)
+      UIS_RS_CASE(256, 128)
+#undef UIS_RS_CASE
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
-  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+  if (m.Hp == HPV && m.Dp == DPV && !rs) {                                                                           \
     void (*kern)(DevModel, DecodeState) = big ? &k_decode_big<HPV, DPV> : &k_decode_resident<HPV, DPV>;             \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \
@@ -1045,7 +1068,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};

@@ -127,6 +127,10 @@ struct DecodeState {
   int rx_stride;
   int32_t* rx_nrows;
   uint32_t* rx_bar;
+  // k_decode_rs (replicated select): mse_tab[((step parity) * U + u) * S + slot] = weighted MSE of
+  // that step's frame against the cluster mean in `slot`, published one step ahead by the
+  // utterance's owner rank for the clusters the step in between does not rewrite
+  float* mse_tab;
   // streaming (uis_stream_*): utterances are NOT in lock-step.  avail[u] = frames received so far
   // (= decode steps that may run; test_iteration is 1), foff[u] + step = row of step `step`'s
   // frame in the current chunk's x / gi0 / mse0, lab_off[u] = where the utterance's labels go.

@@ -3040,6 +3040,8 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 #endif
 }
 
+#include "uis_select_rs.hip"
+
 // ------------------------------------------------------------------ window
 //
 // look_ahead >= 2 (uisrnn.py:469-477,529-559): a window of Lw <= L frames is scored jointly.

@@ -1,0 +1,832 @@
+// uis_select_rs.hip -- the one-launch decode with the select REPLICATED (k_decode_rs).
+// (Included by uis_kernels.hip: uses its dense-stage helpers.)
+//
+// Reference behaviour: _calculate_score + the prune + the bookkeeping half of
+// _update_beam_state, uisrnn/uisrnn.py:388-453,455-477,534-559 -- the same decisions, keys, leader
+// and arithmetic rules as select_fast_body; results are bit-identical (tests/test_gpu_parity.py
+// runs this path, the owner-select path and the launch-per-step path against the oracle).
+//
+// Why.  A decode step is a latency chain, not a throughput problem: with one workgroup per
+// utterance running the select (k_decode_resident) a step crosses the XCD four times -- select ->
+// GRU -> linear_mean1 -> linear_mean2 -> select -- and the first crossing alone (row descriptors
+// published, barrier, descriptors staged) costs ~2.4 us on top of a 6 us select that 24 of the 32
+// CUs sit out.  Here EVERY workgroup of an XCD keeps the beam tables of all of the cluster's (at
+// most 8) utterances in LDS and wave w decides utterance w, so the step's row list exists in every
+// workgroup without being exchanged: three hand-offs per step, no row reservation, no descriptor
+// staging.  What makes that affordable is a select whose critical path is short enough for one
+// wave:
+//   * its only heavy input -- the weighted MSE of the frame against every live cluster mean --
+//     arrives as one float per cluster for the clusters the previous step did not rewrite (the
+//     utterance's owner rank computes them one step ahead, inside the barrier after the GRU stage:
+//     mse_tab, double buffered by step parity) and is computed by the wave itself only for the at
+//     most beam_size clusters the previous step DID rewrite; everything is requested in one round
+//     trip;
+//   * the prior terms come from LDS (log tables; per-hypothesis log denominators are stored with
+//     the tables when a hypothesis is created);
+//   * candidates sit on a (hypothesis, cluster) grid -- no prefix sums, no candidate table;
+//   * the prune is `keep` rounds of a wave-wide minimum over 32-bit order-preserving score keys
+//     (DPP row reduction + four readlanes), ties to the lowest grid position = the lowest
+//     (hypothesis, cluster) -- the order of the 64-bit keys of select_fast_body;
+//   * everything nobody waits for -- the next step's tables, live masks, back-pointers -- runs
+//     AFTER the GRU stage's operand loads are in flight (rs_back, called from the dense stage's
+//     after-issue hook).
+#pragma once
+
+// 1: k_decode_rs is the default wherever it applies (UIS_FLAG_OWNER_SELECT keeps k_decode_resident);
+// 0: it runs only with UIS_FLAG_REPLICATED_SELECT
+#ifndef UIS_RS_DEFAULT
+#define UIS_RS_DEFAULT 0
+#endif
+#define UIS_RS_UTT 8        // utterances per cluster (one per wave)
+#define UIS_RS_MAXB 16      // beam_size
+#define UIS_RS_MAXS 256     // slots per utterance (four 64-bit masks)
+#define UIS_RS_MAXC 192     // grid positions: beam_size * (max_clusters + 1) (three per lane)
+#define UIS_RS_LOGTAB 128   // entries of the LDS copies of the log tables (larger counts: global)
+#define UIS_RS_NOKEY 0xffffffffu
+
+struct RsLds {
+  // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
+  int off_slot, off_blk;                     // uint16 [B][Kmax]
+  int off_K, off_last, off_sum, off_score;   // int32 / float [B]
+  int off_ld;                                // double [B]   log(sum(block_counts) + alpha) of the hypothesis
+  int off_hdr;                               // int32 [4]    {hypotheses, grid stride, its magic, 0}
+  int set_stride;
+  int off_pcnt;                              // uint16 [S]   frames assigned to the cluster state in slot s
+  int off_live;                              // u64 [4]      slots referenced by the CURRENT beam
+  int off_new;                               // u64 [4]      of those, written by the previous step
+  int off_newlist;                           // int32 [1 + B] count, slots written by the previous step
+  int off_stats;                             // u64 [4]      decode statistics (the owner flushes them at the end)
+  int persist_stride;
+  // per wave, scratch (lives in the split-K area: the select's front part and the dense stages
+  // never overlap; rs_back, which runs inside the GRU stage, only touches the persistent blocks)
+  int sc_mse;                                // float [S]
+  int sc_dst;                                // int32 [B]    the ord-th free slot
+  int scratch_stride;
+};
+
+__host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
+  RsLds l;
+  int o = 0;
+  auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+  l.off_slot = take(B * Kmax * 2);
+  l.off_blk = take(B * Kmax * 2);
+  l.off_K = take(B * 4);
+  l.off_last = take(B * 4);
+  l.off_sum = take(B * 4);
+  l.off_score = take(B * 4);
+  l.off_ld = take(B * 8);
+  l.off_hdr = take(16);
+  l.set_stride = o;
+  o += l.set_stride;
+  l.off_pcnt = take(S * 2);
+  l.off_live = take(4 * 8);
+  l.off_new = take(4 * 8);
+  l.off_newlist = take((1 + B) * 4);
+  l.off_stats = take(4 * 8);
+  l.persist_stride = o;
+  o = 0;
+  l.sc_mse = take(S * 4);
+  l.sc_dst = take(B * 4);
+  l.scratch_stride = o;
+  return l;
+}
+
+__host__ __device__ inline bool rs_select_ok(int B, int Kmax, int S, int U, int ncl, long max_steps) {
+  return B <= UIS_RS_MAXB && B * (Kmax + 1) <= UIS_RS_MAXC && S <= UIS_RS_MAXS && U <= UIS_RS_UTT * ncl &&
+         max_steps < 65535;
+}
+
+// row-tile descriptors built locally: enough tiles for every utterance's beam_size rows
+__host__ __device__ inline int rs_head_tiles(int B) { return (UIS_RS_UTT * B + 15) / 16; }
+
+// LDS of k_decode_rs: 1 / (2 sigma^2) | log tables | the utterances' persistent blocks | split-K
+// partial tiles (the waves' select scratch lives in the same bytes) | control words | the rank's
+// linear_mean1 / linear_mean2 weight tiles | this step's row descriptors (built locally)
+__host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+  const RsLds L = rs_lds_layout(B, Kmax, S);
+  const size_t spart = (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4;
+  const size_t scratch = (size_t)UIS_RS_UTT * L.scratch_stride;
+  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)UIS_RS_UTT * L.persist_stride +
+         (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 24;
+}
+
+// minimum of a row of 16 lanes in its lane 15 (DPP row shifts; lanes shifted in from outside the
+// row contribute the identity)
+__device__ __forceinline__ uint32_t rs_row_min_u32(uint32_t v) {
+  uint32_t o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;  // row_shr:1
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;  // row_shr:2
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;  // row_shr:4
+  o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;  // row_shr:8
+  return v;
+}
+__device__ __forceinline__ uint32_t rs_wave_min_u32(uint32_t v) {  // wave-uniform result
+  v = rs_row_min_u32(v);
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ int rs_wave_max_i32(int v) {  // small non-negative values
+  return (int)~rs_wave_min_u32(~(uint32_t)v);
+}
+
+// Weighted MSE of the frame (xv: this lane's four float4 chunks) against the mean whose chunks are
+// in mv, by the 16 lanes of a quarter wave in the canonical tree (include/uis_numerics.h): lane p
+// holds d = 4 * (p + 16 k), k = 0..3.  All 16 lanes return the value.  DP <= 256.
+template <int DP>
+__device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&mv)[4], const f32x4 (&xv)[4], const float* swgt,
+                                               int p) {
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = 4 * (p + 16 * k);
+    if (d < DP) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
+    }
+  }
+  const float d0 = mv[0][0] - xv[0][0];  // meaningful on lane p == 0 (d = 0)
+  float t = (v[0] + v[2]) + (v[1] + v[3]);
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+  const float d0b = __shfl(d0, (threadIdx.x & 63) & ~15, 64);
+  return uis_mse_finish(t, d0b * d0b, m.D);
+}
+template <int DP>
+__device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, size_t slot_index, int p, f32x4 (&mv)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = 4 * (p + 16 * k);
+    mv[k] = d < DP ? load_sc1(rs_mean, (uint32_t)((slot_index * DP + d) * 4)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+}
+
+// What the front part of a wave's select leaves in registers: lane r = winner r.
+struct RsWin {
+  int keep, C, nlead;          // wave-uniform: winners, candidates, rnn rows of this utterance
+  bool isw, is_lead;
+  int wb, wc, Kb, src, dst, ord, nprev;
+  float score;
+};
+
+__device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); }  // lanes of ONE wave talk through LDS: program order is enough
+
+// FRONT: scores, prune, winners, rows.  One wave (all 64 lanes), utterance u, decode step `step`
+// whose frame is row `frame` of the stream.  pers = the utterance's persistent block, scr = this
+// wave's scratch.
+template <int DP>
+__device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
+                                          unsigned char* pers, unsigned char* scr, const float* swgt, const double* s_lblk,
+                                          unsigned long long* ph) {
+  // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
+  // it would have to stay live -- spilled -- across the dense stages)
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long ph_prev = wall_clock64();
+#define PSTAMP(k) do { if (ph) { const unsigned long long n_ = wall_clock64(); ph[k] += n_ - ph_prev; ph_prev = n_; } } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
+  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int par = step & 1;
+  const unsigned char* const set_cur = pers + par * L.set_stride;
+  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
+  const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
+  const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
+  const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
+  const float* sscore = reinterpret_cast<const float*>(set_cur + L.off_score);
+  const double* sld = reinterpret_cast<const double*>(set_cur + L.off_ld);
+  const int* shdr = reinterpret_cast<const int*>(set_cur + L.off_hdr);
+  const unsigned short* spcnt = reinterpret_cast<const unsigned short*>(pers + L.off_pcnt);
+  const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
+  const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
+  const int* snewlist = reinterpret_cast<const int*>(pers + L.off_newlist);
+  float* smse = reinterpret_cast<float*>(scr + L.sc_mse);
+  int* sdst = reinterpret_cast<int*>(scr + L.sc_dst);
+
+  const int nb = shdr[0], Kcur = shdr[1], kmagic = shdr[2];
+  // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
+  // step left alone, the means of the ones it rewrote, the frame
+  const float mse_new = st.mse0[frame];
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  unsigned long long lv[4], nw[4];
+  float vold[4];
+  {
+    const float* tab = st.mse_tab + ((size_t)par * U + u) * S;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lv[k] = 64 * k < S ? slive[k] : 0ull;
+      nw[k] = 64 * k < S ? snew[k] : 0ull;
+      vold[k] = 0.0f;
+      if (((lv[k] & ~nw[k]) >> lane) & 1ull) vold[k] = load_f32_sc1(tab + lane + 64 * k);
+    }
+  }
+  const int nn = snewlist[0];
+  const int grp = lane >> 4, p = lane & 15;
+  f32x4 xv[4], mv[4][4];
+  int nsl[4];
+  if (nn > 0) {
+    const float* xrow = st.x + (size_t)frame * DP;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = 4 * (p + 16 * k);
+      xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      if (4 * ps < nn) {
+        const int i = 4 * ps + grp;
+        nsl[ps] = snewlist[1 + (i < nn ? i : 0)];
+        rs_load_mean16<DP>(rs_mean, (size_t)u * S + nsl[ps], p, mv[ps]);
+      }
+    }
+  }
+  // the published values first (they arrive first), then the rewritten clusters
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (((lv[k] & ~nw[k]) >> lane) & 1ull) smse[lane + 64 * k] = vold[k];
+  if (nn > 0) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      if (4 * ps < nn) {
+        const float v = rs_mse16_regs<DP>(m, mv[ps], xv, swgt, p);
+        if (p == 0 && 4 * ps + grp < nn) smse[nsl[ps]] = v;
+      }
+    }
+  }
+  rs_lds_fence();
+  PSTAMP(0);
+
+  // ---- candidate scores on the (hypothesis, cluster) grid: position e = b * Kcur + c
+  uint32_t key0 = UIS_RS_NOKEY, key1 = UIS_RS_NOKEY, key2 = UIS_RS_NOKEY;
+  float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;
+  int nfin = 0, C = 0;
+  const int nch = (nb * Kcur + 63) >> 6;
+  auto score_at = [&](int e, uint32_t& key, float& sc) {
+    const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
+    bool valid = false;
+    if (b < nb) {
+      const int Kb = sK[b];
+      if (c <= Kb) {
+        valid = true;
+        const double ld = sld[b];
+        float mse;
+        double prior;
+        if (c < Kb) {
+          mse = smse[sslot[b * Kmax + c]];
+          if (c == slast[b]) prior = m.lp_stay;
+          else {
+            const int blk = (int)sblk[b * Kmax + c];
+            const double lb = blk < UIS_RS_LOGTAB ? s_lblk[blk] : st.logblk[blk];
+            prior = (m.lp_sw + lb) - ld;
+          }
+        } else {
+          mse = mse_new;
+          prior = (m.lp_sw + m.l_alpha) - ld;
+        }
+        sc = sscore[b] + uis_step_loss(mse, prior);
+        if (uis_isfinite(sc)) key = uis_score_key(sc);
+      }
+    }
+    C += __popcll(__ballot(valid));
+    nfin += __popcll(__ballot(key != UIS_RS_NOKEY));
+  };
+  score_at(lane, key0, sc0);
+  if (nch > 1) score_at(lane + 64, key1, sc1);
+  if (nch > 2) score_at(lane + 128, key2, sc2);
+  const int keep = nfin < B ? nfin : B;
+  PSTAMP(1);
+
+  // ---- prune: `keep` rounds of the wave-wide minimum; ties to the lowest grid position
+  int win_e = 0;
+  float win_sc = 0.0f;
+  for (int r = 0; r < keep; ++r) {
+    uint32_t loc = key0 < key1 ? key0 : key1;
+    loc = loc < key2 ? loc : key2;
+    const uint32_t mn = rs_wave_min_u32(loc);
+    unsigned long long mk = __ballot(key0 == mn);
+    int l, e;
+    float s;
+    if (mk) {
+      l = __ffsll((long long)mk) - 1;
+      e = l;
+      s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc0), l));
+      if (lane == l) key0 = UIS_RS_NOKEY;
+    } else {
+      mk = __ballot(key1 == mn);
+      if (mk) {
+        l = __ffsll((long long)mk) - 1;
+        e = l + 64;
+        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc1), l));
+        if (lane == l) key1 = UIS_RS_NOKEY;
+      } else {
+        mk = __ballot(key2 == mn);
+        l = __ffsll((long long)mk) - 1;
+        e = l + 128;
+        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc2), l));
+        if (lane == l) key2 = UIS_RS_NOKEY;
+      }
+    }
+    if (lane == r) { win_e = e; win_sc = s; }
+  }
+  PSTAMP(2);
+
+  // ---- winners: lane r = winner r
+  RsWin out;
+  out.keep = keep;
+  out.C = C;
+  const bool nodedup = (st.flags & 1u) != 0;
+  const int r = lane;
+  const bool isw = r < keep;
+  int wb = 0, wc = 0, src = -2, Kb = 0;
+  if (isw) {
+    wb = (int)(((unsigned)win_e * (unsigned)kmagic) >> 20);
+    wc = win_e - wb * Kcur;
+    Kb = sK[wb];
+    src = wc < Kb ? (int)sslot[wb * Kmax + wc] : -1;
+  }
+  int lead = r;
+  if (!nodedup) {
+    for (int r2 = keep - 1; r2 >= 0; --r2) {  // lowest rank with the same source wins
+      const int s2 = __builtin_amdgcn_readlane(src, r2);
+      if (isw && s2 == src) lead = r2;
+    }
+  }
+  const bool is_lead = isw && lead == r;
+  const unsigned long long lmask = __ballot(is_lead);
+  const int nlead = __popcll(lmask);
+  const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
+  // the ord-th free slot (not referenced by the current beam), in slot order: slot-lane l + 64 k
+  // knows its own rank among the free ones
+  {
+    int before = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (64 * k < S && before < nlead) {
+        unsigned long long fm = ~lv[k];
+        if (S - 64 * k < 64) fm &= (1ull << (S - 64 * k)) - 1ull;
+        const int rk = before + __popcll(fm & ((1ull << lane) - 1ull));
+        if (((fm >> lane) & 1ull) && rk < nlead) sdst[rk] = lane + 64 * k;
+        before += __popcll(fm);
+      }
+    }
+  }
+  rs_lds_fence();
+  int dst = -1, nprev = 0;
+  if (is_lead) {
+    dst = sdst[ord];
+    nprev = src >= 0 ? (int)spcnt[src] : 0;
+  }
+  {
+    const int dl = __shfl(dst, lead, 64);
+    if (isw && !is_lead) dst = dl;
+  }
+  PSTAMP(3);
+  out.nlead = nlead;
+  out.isw = isw;
+  out.is_lead = is_lead;
+  out.wb = wb; out.wc = wc; out.Kb = Kb; out.src = src; out.dst = dst; out.ord = ord; out.nprev = nprev;
+  out.score = win_sc;
+  return out;
+}
+
+// BACK: the next step's tables, masks and counts, the back-pointers -- nothing anybody waits for.
+// `owner`: this workgroup writes what outlives the step to memory.
+__device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long off0,
+                                        unsigned char* pers, unsigned char* scr, const double* s_lden, bool owner,
+                                        const RsWin& w) {
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
+  const int B = st.B, Kmax = st.Kmax, U = st.U;
+  const int par = step & 1, nxt = par ^ 1;
+  const unsigned char* const set_cur = pers + par * L.set_stride;
+  unsigned char* const set_nxt = pers + nxt * L.set_stride;
+  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
+  const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
+  const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
+  const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
+  unsigned short* nslot = reinterpret_cast<unsigned short*>(set_nxt + L.off_slot);
+  unsigned short* nblk = reinterpret_cast<unsigned short*>(set_nxt + L.off_blk);
+  int* nK = reinterpret_cast<int*>(set_nxt + L.off_K);
+  int* nlast = reinterpret_cast<int*>(set_nxt + L.off_last);
+  int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
+  float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
+  double* nld = reinterpret_cast<double*>(set_nxt + L.off_ld);
+  int* nhdr = reinterpret_cast<int*>(set_nxt + L.off_hdr);
+  unsigned short* spcnt = reinterpret_cast<unsigned short*>(pers + L.off_pcnt);
+  unsigned long long* slive = reinterpret_cast<unsigned long long*>(pers + L.off_live);
+  unsigned long long* snew = reinterpret_cast<unsigned long long*>(pers + L.off_new);
+  int* snewlist = reinterpret_cast<int*>(pers + L.off_newlist);
+
+  const int r = lane;
+  int Knew_w = 0;
+  unsigned info_a = 0u, info_b = 0u;  // per winner, for the table copy below
+  if (w.isw) {
+    const bool is_new = w.wc == w.Kb;
+    const int lastb = slast[w.wb];
+    Knew_w = w.Kb + (is_new ? 1 : 0);
+    const int blk_new = is_new ? 1 : (int)sblk[w.wb * Kmax + w.wc] + (w.wc != lastb ? 1 : 0);
+    if (Knew_w > Kmax) { Knew_w = Kmax; if (owner) st.overflow[u] = 1; }
+    const int sum_new = ssum[w.wb] + ((is_new || w.wc != lastb) ? 1 : 0);
+    nK[r] = Knew_w;
+    nlast[r] = w.wc;
+    nsum[r] = sum_new;
+    nscore[r] = w.score;
+    nld[r] = sum_new < UIS_RS_LOGTAB ? s_lden[sum_new] : st.logden[sum_new];
+    info_a = (unsigned)w.wb | ((unsigned)w.wc << 8) | ((unsigned)Knew_w << 20);  // B <= 16, clusters <= 191
+    info_b = ((unsigned)w.dst & 0xffffu) | ((unsigned)blk_new << 16);
+    if (owner) {
+      st.beam_score[((size_t)nxt * U + u) * B + r] = w.score;  // (the final beam's scores are read back by k_backtrace)
+      st.bp[((size_t)st.tau * off0 + step) * B + r] = ((unsigned)w.wb << 16) | (unsigned)w.wc;
+    }
+  }
+  if (lane < 4) { slive[lane] = 0ull; snew[lane] = 0ull; }
+  rs_lds_fence();
+  {
+    // every entry of every winner in one pass: the changed entry from the winner's record, the
+    // unchanged ones from the parent's row (BeamState(source), uisrnn.py:66-69)
+    const unsigned kmagicK = ((1u << 20) + (unsigned)Kmax - 1u) / (unsigned)Kmax;  // e / Kmax = (e * magic) >> 20, exact for e < 2048
+    for (int e0 = 0; e0 < w.keep * Kmax; e0 += 64) {
+      const int e = e0 + lane;
+      const int rr = (int)(((unsigned)e * kmagicK) >> 20), c2 = e - rr * Kmax;
+      const unsigned ia = (unsigned)__shfl((int)info_a, rr < 64 ? rr : 0, 64), ib = (unsigned)__shfl((int)info_b, rr < 64 ? rr : 0, 64);
+      if (e < w.keep * Kmax) {
+        const int rb = (int)(ia & 0xffu), rc = (int)((ia >> 8) & 0xfffu), Knew = (int)(ia >> 20);
+        if (c2 < Knew) {
+          int slot, blk;
+          if (c2 == rc) { slot = (int)(ib & 0xffffu); blk = (int)(ib >> 16); }
+          else { slot = (int)sslot[rb * Kmax + c2]; blk = (int)sblk[rb * Kmax + c2]; }
+          nslot[e] = (unsigned short)slot;
+          nblk[e] = (unsigned short)blk;
+          atomicOr(&slive[slot >> 6], 1ull << (slot & 63));
+        }
+      }
+    }
+  }
+  const int Kmaxseen = rs_wave_max_i32(Knew_w);
+  if (w.is_lead) {
+    spcnt[w.dst] = (unsigned short)(w.nprev + 1);
+    atomicOr(&snew[w.dst >> 6], 1ull << (w.dst & 63));
+    snewlist[1 + w.ord] = w.dst;
+  }
+  if (lane == 0) {
+    snewlist[0] = w.nlead;
+    const int Kc = Kmaxseen + 1;  // grid stride of the next step: clusters 0 .. K of every hypothesis
+    nhdr[0] = w.keep;
+    nhdr[1] = Kc;
+    nhdr[2] = (int)(((1u << 20) + (unsigned)Kc - 1u) / (unsigned)Kc);  // e / Kc = (e * magic) >> 20, exact for e < 2048
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(pers + L.off_stats);
+    acc[0] += (unsigned long long)w.nlead;
+    acc[1] += (unsigned long long)w.keep;
+    acc[2] += (unsigned long long)w.C;
+    if ((unsigned long long)Kmaxseen > acc[3]) acc[3] = (unsigned long long)Kmaxseen;
+    if (owner) st.beam_n[(size_t)nxt * U + u] = w.keep;
+  }
+}
+
+// The owner's early MSE: for utterance u, every slot the NEXT beam references that this step does
+// not rewrite, against the next step's frame (row `frame_next`); one float per slot into
+// mse_tab[(step + 1) parity].  Called by all 512 threads of the owner workgroup between the arrival
+// at a barrier and the wait (it needs nobody else's data of this step: those means were final a
+// step ago).
+template <int DP>
+__device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step,
+                                             long frame_next, const unsigned char* pers, int* s_list, const float* swgt) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int S = st.S, U = st.U;
+  const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
+  const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
+  // list of old live slots (wave 0 compacts, 64 slots at a time)
+  if (w == 0) {
+    int n = 0;
+    for (int base = 0; base < S; base += 64) {
+      const unsigned long long mask = slive[base >> 6] & ~snew[base >> 6];
+      const bool on = (mask >> lane) & 1ull;
+      if (on) s_list[1 + n + __popcll(mask & ((1ull << lane) - 1ull))] = base + lane;
+      n += __popcll(mask);
+    }
+    if (lane == 0) s_list[0] = n;
+  }
+  __syncthreads();
+  const int n = s_list[0];
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  const int grp = t >> 4, p = t & 15;
+  if (grp < n) {
+    const float* xrow = st.x + (size_t)frame_next * DP;
+    f32x4 xv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = 4 * (p + 16 * k);
+      xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    float* tab = st.mse_tab + ((size_t)((step + 1) & 1) * U + u) * S;
+    for (int i = grp; i < n; i += 32) {
+      const int sl = s_list[1 + i];
+      f32x4 mv[4];
+      rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
+      const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
+      if (p == 0) tab[sl] = v;
+    }
+  }
+}
+
+// The one-launch decode with the replicated select (see the top of this file).  Same grid, same
+// weight residency, same dense stages and arithmetic as k_decode_resident; three in-launch
+// barriers per step instead of four, no row reservation, no descriptor staging.
+template <int HP, int DP>
+__global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
+  constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
+  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;
+  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;
+  constexpr int EPT = (RC + 1) / 2;
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32 && PER * UIS_KSPLIT == NKB && DP <= 256, "shapes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // the wave's number, known to be uniform (scalar addresses)
+  const int ncl = st.ncl;
+  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
+  const int U = st.U, S = st.S, B = st.B;
+  const RsLds L = rs_lds_layout(B, st.Kmax, S);
+  float* swgt = reinterpret_cast<float*>(smem_raw);
+  double* s_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
+  double* s_lden = s_lblk + UIS_RS_LOGTAB;
+  unsigned char* s_pers = reinterpret_cast<unsigned char*>(s_lden + UIS_RS_LOGTAB);
+  float* spart = reinterpret_cast<float*>(s_pers + (size_t)UIS_RS_UTT * L.persist_stride);
+  unsigned char* s_scr = reinterpret_cast<unsigned char*>(spart);
+  const size_t spart_bytes = (size_t)UIS_KSPLIT * RC * 3 * 256 * 4 > (size_t)UIS_RS_UTT * L.scratch_stride
+                                 ? (size_t)UIS_KSPLIT * RC * 3 * 256 * 4 : (size_t)UIS_RS_UTT * L.scratch_stride;
+  int* s_ctl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(spart) + spart_bytes);  // [0] abort [1] steps [2] arrived [8..15] rows per wave
+  f32x4* s_w1 = reinterpret_cast<f32x4*>(s_ctl + 32);
+  f32x4* s_w2 = s_w1 + NKB * 64;
+  const int head_tiles = rs_head_tiles(B);
+  u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);
+  long* s_frame = reinterpret_cast<long*>(s_head + head_tiles * 16);
+
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 32; ++k) s_ctl[k] = 0;
+  }
+  for (int i = t; i < DP; i += 512) swgt[i] = m.wgt[i];
+  for (int i = t; i < UIS_RS_LOGTAB; i += 512) { s_lblk[i] = st.logblk[i]; s_lden[i] = st.logden[i]; }
+  for (int i = t; i < head_tiles * 16; i += 512) { s_head[i] = u32x4{0u, 0u, 0u, 0u}; s_frame[i] = 0; }
+  // ---- this wave's utterance: slot w of the cluster
+  const int u_w = cluster + ncl * w;
+  const bool has_u = w < UIS_RS_UTT && u_w < U;
+  unsigned char* const pers_w = s_pers + (size_t)(w < UIS_RS_UTT ? w : 0) * L.persist_stride;
+  unsigned char* const scr_w = s_scr + (size_t)(w < UIS_RS_UTT ? w : 0) * L.scratch_stride;
+  long off0_w = 0, N_w = 0;
+  if (has_u) { off0_w = (long)st.off[u_w]; N_w = (long)st.off[u_w + 1] - off0_w; }
+  const long T_w = (long)st.tau * N_w;
+  // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
+  for (int i = lane; i < L.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    int* hdr = reinterpret_cast<int*>(pers_w + L.off_hdr);
+    hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
+    reinterpret_cast<int*>(pers_w + L.off_last)[0] = -1;
+    reinterpret_cast<double*>(pers_w + L.off_ld)[0] = st.logden[0];
+  }
+  {
+    int myT = 0;
+    if (has_u && lane == 0) myT = (int)T_w;
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+  // the owner of utterance slot r is rank r: it alone writes that utterance's lasting outputs and
+  // computes its early MSEs
+  const bool owner_wg = rank < UIS_RS_UTT && cluster + ncl * rank < U;
+  long own_off0 = 0, own_N = 0;
+  if (owner_wg) { own_off0 = (long)st.off[cluster + ncl * rank]; own_N = (long)st.off[cluster + ncl * rank + 1] - own_off0; }
+  const long own_T = (long)st.tau * own_N;
+
+  f32x4 wg[3][PER];
+  const int ft1 = rank / SH1, tpar1 = rank % SH1;
+  const int ft2 = rank / SH2, tpar2 = rank % SH2;
+#pragma unroll
+  for (int kb = 0; kb < PER; ++kb) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      wg[g][kb] = reinterpret_cast<const f32x4*>(m.whh[0])[((size_t)(g * NFT1 + ft1) * NKB + w * PER + kb) * 64 + lane];
+    s_w1[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w1)[((size_t)ft1 * NKB + w * PER + kb) * 64 + lane];
+    s_w2[(w * PER + kb) * 64 + lane] = reinterpret_cast<const f32x4*>(m.w2)[((size_t)ft2 * NKB + w * PER + kb) * 64 + lane];
+  }
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  float* const hst = st.gi_up;
+  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
+  const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
+  uint32_t bar = 0;
+  long fpos_w = 0, own_fpos = 0;  // step % N of this wave's / the owned utterance, kept incrementally
+  __syncthreads();
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rt_prev = wall_clock64();
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+  for (int s = 0; s < nsteps; ++s) {
+    // ---- select, replicated: wave w decides utterance slot w; every workgroup gets the same rows
+    RsWin win;
+    win.keep = 0; win.C = 0; win.nlead = 0; win.isw = false; win.is_lead = false;
+    win.wb = 0; win.wc = 0; win.Kb = 0; win.src = -2; win.dst = -1; win.ord = 0; win.nprev = 0; win.score = 0.0f;
+    const bool act_w = has_u && (long)s < T_w;
+    const long frame_w = off0_w + fpos_w;
+    if (act_w) {
+#if defined(UIS_RESIDENT_TIMING)
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
+#else
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, nullptr);
+#endif
+    }
+    RSTAMP(0);
+    if (lane == 0) s_ctl[8 + w] = win.nlead;
+    __syncthreads();
+    int base = 0, nrows = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int c = s_ctl[8 + k]; if (k < w) base += c; nrows += c; }
+    if (win.is_lead) {
+      s_head[base + win.ord] = u32x4{(unsigned)u_w, (unsigned)win.src, (unsigned)win.dst, (unsigned)win.nprev};
+      s_frame[base + win.ord] = frame_w;
+    }
+    __syncthreads();
+    const int nrt = (nrows + 15) >> 4;
+    RSTAMP(1);
+
+    // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
+    bool back_done = false;
+    {
+      const int my1 = nrt > tpar1 ? (nrt - tpar1 + SH1 - 1) / SH1 : 0;
+      for (int i0 = 0; i0 < my1; i0 += RC) {
+        uint32_t boff[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          const int tile = tpar1 + SH1 * (i0 + r < my1 ? i0 + r : i0);
+          const RowHead rh = lds_row_head(s_head, 16 * tile + (t & 15));
+          boff[r] = rh.src >= 0 ? (uint32_t)((((size_t)rh.utt * S + rh.src) * HP) * 4) : h1_off;
+        }
+        const int j = ft1 * 16 + (t & 15);
+        RowHead re[EPT];
+        float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
+        bool ework[EPT];
+        const bool do_back = !back_done;
+        auto epilogue_operands = [&]() {
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const int r = (t >> 8) + 2 * k;
+            const int lrow = 16 * (tpar1 + SH1 * (i0 + r)) + ((t & 255) >> 4);
+            ework[k] = r < RC && i0 + r < my1 && lrow < nrows;
+            gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
+            re[k] = RowHead{0, 0, 0, 0};
+            if (ework[k]) {
+              re[k] = lds_row_head(s_head, lrow);
+              const long frame = s_frame[lrow];
+              const float* gi = st.gi0 + (size_t)frame * m.G;
+              gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
+              hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
+            }
+          }
+          // the select's back part, while the stage's operands travel
+          if (do_back && act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, scr_w + 0, s_lden, rank == w, win);
+        };
+        resident_tile<3, PER, RC, 64>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
+                                      epilogue_operands);
+        back_done = true;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          if (!ework[k]) continue;
+          const int r = (t >> 8) + 2 * k, e = t & 255;
+          const float ghr = splitk_combine<RC, 3>(spart, r, 0, e);
+          const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
+          const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
+          const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+          st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
+          hst[((tile0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;
+        }
+        __syncthreads();
+      }
+    }
+    // (a rank without a row tile of the GRU stage, or a step without rows)
+    if (!back_done && act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, scr_w, s_lden, rank == w, win);
+    if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
+    RSTAMP(2);
+    if (owner_wg) {
+      // arrive; then the next step's MSEs of the clusters this step does not rewrite; then wait
+      xcd_arrive(st, cluster, s_ctl);  // (its workgroup barrier also orders every wave's rs_back before the masks are read)
+      if ((long)s + 1 < own_T) {
+        own_fpos = own_fpos + 1 == own_N ? 0 : own_fpos + 1;
+        rs_early_mse<DP>(m, st, L, cluster + ncl * rank, s, own_off0 + own_fpos, s_pers + (size_t)rank * L.persist_stride,
+                         reinterpret_cast<int*>(s_scr), swgt);
+      }
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
+    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+    RSTAMP(3);
+
+    // ---- linear_mean1 + relu -> a1
+    {
+      const int my1h = nrt > tpar1 ? (nrt - tpar1 + SH1 - 1) / SH1 : 0;
+      for (int i0 = 0; i0 < my1h; i0 += RC) {
+        uint32_t boff[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          const int tile = tpar1 + SH1 * (i0 + r < my1h ? i0 + r : i0);
+          boff[r] = (uint32_t)((((tile0 + tile) * NFT1) * 256 + (t & 15) * 16) * 4);
+        }
+        f32x4 w1r[1][PER];
+#pragma unroll
+        for (int kb = 0; kb < PER; ++kb) w1r[0][kb] = s_w1[(w * PER + kb) * 64 + lane];
+        resident_tile<1, PER, RC, 1024>(w1r, m.b1 + ft1 * 16, 0, rs_hst, boff, my1h - i0 < RC ? my1h - i0 : RC, spart, []() {});
+        for (int e = t; e < RC * 256; e += 512) {
+          const int r = e >> 8, tile = tpar1 + SH1 * (i0 + r), lrow = 16 * tile + ((e & 255) >> 4);
+          if (i0 + r < my1h && lrow < nrows) {
+            const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
+            st.a1[((tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    RSTAMP(4);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(5);
+
+    // ---- linear_mean2 + running mean -> dst slot
+    {
+      const int my_tiles = nrt > tpar2 ? (nrt - tpar2 + SH2 - 1) / SH2 : 0;
+      for (int i0 = 0; i0 < my_tiles; i0 += RC) {
+        uint32_t boff[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          const int tile = tpar2 + SH2 * (i0 + r < my_tiles ? i0 + r : i0);
+          boff[r] = (uint32_t)((((tile0 + tile) * NFT1) * 256 + (t & 15) * 16) * 4);
+        }
+        const int f = ft2 * 16 + (t & 15);
+        RowHead re[EPT];
+        float old[EPT];
+        bool ework[EPT];
+        auto epilogue_operands = [&]() {
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            const int r = (t >> 8) + 2 * k;
+            const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
+            ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
+            old[k] = 0.0f;
+            re[k] = RowHead{0, 0, 0, 0};
+            if (ework[k]) {
+              re[k] = lds_row_head(s_head, lrow);
+              if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
+            }
+          }
+        };
+        f32x4 w2r[1][PER];
+#pragma unroll
+        for (int kb = 0; kb < PER; ++kb) w2r[0][kb] = s_w2[(w * PER + kb) * 64 + lane];
+        resident_tile<1, PER, RC, 1024>(w2r, m.b2 + ft2 * 16, 0, rs_a1, boff, my_tiles - i0 < RC ? my_tiles - i0 : RC, spart,
+                                        epilogue_operands);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          if (!ework[k]) continue;
+          const int r = (t >> 8) + 2 * k;
+          float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
+          if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
+          if (f >= m.D) v = 0.0f;
+          st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+        }
+        __syncthreads();
+      }
+    }
+    RSTAMP(6);
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(7);
+  }
+#if defined(UIS_RESIDENT_TIMING)
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 31 * ncl))
+    for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
+  if (t == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = ph_acc[k];
+#endif
+  if (owner_wg && t == 0) {  // this utterance's statistics
+    const unsigned long long* acc =
+        reinterpret_cast<const unsigned long long*>(s_pers + (size_t)rank * L.persist_stride + L.off_stats);
+    atomicAdd(&st.counters[0], acc[0]);
+    atomicAdd(&st.counters[1], acc[1]);
+    atomicAdd(&st.counters[2], acc[2]);
+    atomicMax(&st.counters[3], acc[3]);
+  }
+}
