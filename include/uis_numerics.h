@@ -29,7 +29,7 @@
 /* Bumped whenever the order of operations below changes; liboracle.so and
    libuisrnn_hip.so both export it and the tests require them to agree, so a
    stale binary on either side is caught instead of showing up as 1-ulp noise. */
-#define UIS_NUMERICS_VERSION 2
+#define UIS_NUMERICS_VERSION 3
 
 /* Dense chains pad their contraction length to a multiple of this. */
 #define UIS_KBLOCK 16
@@ -170,27 +170,57 @@ UIS_HD float uis_mse_finish(float sum, float first_sq, int dim) {
 }
 
 /*
- * Canonical summation tree of the D weighted terms: 64 virtual lanes; lane j
- * owns d = 256*q + 4*j + i (i = 0..3, q = 0,1,...) and adds them in increasing
- * d starting from 0.0f; then an xor butterfly with offsets 32,16,8,4,2,1
- * (lane j adds lane j^off).  Host-side helper; the kernels implement the same
- * tree with DPP/shuffles.
+ * Canonical summation order of the D weighted terms (version 3).  The reference promises none
+ * (torch.mean over a CPU tensor, uisrnn/loss_func.py:33-41); this one is chosen so that the
+ * producer of a cluster mean -- the linear_mean2 epilogue, which holds one 16-feature tile of a
+ * row in 16 adjacent lanes -- can emit the tile's partial sum itself, and a select then adds a
+ * handful of partial sums instead of re-reading the mean:
+ *   1. tile sums: the terms are cut into tiles of UIS_MSE_TILE = 16 consecutive d (terms past D
+ *      are +0.0f); inside a tile every 4 consecutive terms are added left to right,
+ *      q_i = ((t[4i] + t[4i+1]) + t[4i+2]) + t[4i+3]  (one 16-byte load of a lane), and the tile is
+ *      P = (q0 + q1) + (q2 + q3)  (an xor butterfly over four adjacent lanes);
+ *   2. sixteen accumulators: A[p] = P[p] + P[p + 16] + P[p + 32] + ... left to right, +0.0f where
+ *      there is no tile p;
+ *   3. an xor butterfly over p with offsets 8, 4, 2, 1:
+ *        (((A0+A8)+(A4+A12)) + ((A2+A10)+(A6+A14))) + (((A1+A9)+(A5+A13)) + ((A3+A11)+(A7+A15))).
+ * (Which of the many legal orders: every reference-recorded fixture of tests/golden keeps its
+ * labels under any of them; the WHOLE final beam of d32_lookahead3 -- hypotheses one float32 ulp
+ * apart -- is reproduced by this one and not, e.g., by the plain adjacent-pair tree.)
+ * Host-side helpers; the kernels implement the same order with DPP / shuffles / registers.
  */
+#define UIS_MSE_TILE 16
+
+UIS_HD float uis_mse_quad_sum(float t0, float t1, float t2, float t3) { return ((t0 + t1) + t2) + t3; }
+
+UIS_HD float uis_mse_tile_sum(const float* t) { /* 16 terms */
+  float q0 = uis_mse_quad_sum(t[0], t[1], t[2], t[3]), q1 = uis_mse_quad_sum(t[4], t[5], t[6], t[7]);
+  float q2 = uis_mse_quad_sum(t[8], t[9], t[10], t[11]), q3 = uis_mse_quad_sum(t[12], t[13], t[14], t[15]);
+  return (q0 + q1) + (q2 + q3);
+}
+
+UIS_HD float uis_mse_acc_sum(const float* A) { /* 16 accumulators */
+  float a0 = A[0] + A[8], a1 = A[1] + A[9], a2 = A[2] + A[10], a3 = A[3] + A[11];
+  float a4 = A[4] + A[12], a5 = A[5] + A[13], a6 = A[6] + A[14], a7 = A[7] + A[15];
+  float b0 = a0 + a4, b1 = a1 + a5, b2 = a2 + a6, b3 = a3 + a7;
+  float c0 = b0 + b2, c1 = b1 + b3;
+  return c0 + c1;
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 static inline float uis_tree_sum(const float* term, int dim) {
-  float lane[64];
-  for (int j = 0; j < 64; ++j) {
-    float acc = 0.0f;
-    for (int base = 4 * j; base < dim; base += 256)
-      for (int i = 0; i < 4 && base + i < dim; ++i) acc = acc + term[base + i];
-    lane[j] = acc;
+  float A[16];
+  for (int p = 0; p < 16; ++p) A[p] = 0.0f;
+  int ntile = (dim + UIS_MSE_TILE - 1) / UIS_MSE_TILE;
+  for (int ft = 0; ft < ntile; ++ft) {
+    float t[UIS_MSE_TILE];
+    for (int j = 0; j < UIS_MSE_TILE; ++j) {
+      int d = ft * UIS_MSE_TILE + j;
+      t[j] = d < dim ? term[d] : 0.0f;
+    }
+    float P = uis_mse_tile_sum(t);
+    A[ft & 15] = ft < 16 ? P : A[ft & 15] + P;
   }
-  for (int off = 32; off >= 1; off >>= 1) {
-    float nxt[64];
-    for (int j = 0; j < 64; ++j) nxt[j] = lane[j] + lane[j ^ off];
-    for (int j = 0; j < 64; ++j) lane[j] = nxt[j];
-  }
-  return lane[0];
+  return uis_mse_acc_sum(A);
 }
 #endif
 

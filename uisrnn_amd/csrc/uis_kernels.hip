@@ -15,29 +15,59 @@
 
 // ------------------------------------------------------------------ helpers
 
-__device__ __forceinline__ float wave_tree_sum(float v) {
-  // xor butterfly 32,16,...,1 == uis_tree_sum's second stage
+// The canonical order of the weighted-MSE sum (include/uis_numerics.h, version 3) on the device.
+// dpp_perm<CTRL>: this lane's copy of another lane's value, DPP control CTRL (every lane is a
+// valid source for the permutations used here).
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// the quad sum of one 16-byte load's worth of terms
+__device__ __forceinline__ float mse_quad(const f32x4& a, const f32x4& b, const f32x4& w) {
+  return uis_mse_quad_sum(uis_mse_term(a[0], b[0], w[0]), uis_mse_term(a[1], b[1], w[1]), uis_mse_term(a[2], b[2], w[2]),
+                          uis_mse_term(a[3], b[3], w[3]));
+}
+// q = this lane's quad sum; a tile's four quads sit in four adjacent lanes: (q0 + q1) + (q2 + q3), in all four
+__device__ __forceinline__ float mse_tile_of_lanes4(float q) {
+  q = q + dpp_perm<0xB1>(q);  // quad_perm [1,0,3,2]: lane ^ 1
+  q = q + dpp_perm<0x4E>(q);  // quad_perm [2,3,0,1]: lane ^ 2
+  return q;
+}
+// Sixteen lanes per row: lane p (= lane & 15) holds the 16-byte chunks d = 256 q + 4 (p + 16 k),
+// k = 0..3, of 256-float block q; A[k] is this lane's copy of accumulator (p >> 2) + 4 k.
+// Chunks past the padded dimension must arrive zero-filled (their terms are +0).
+__device__ __forceinline__ void mse16_block(const f32x4 (&mv)[4], const f32x4 (&xv)[4], const f32x4 (&wv)[4], float (&A)[4]) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
+  for (int k = 0; k < 4; ++k) A[k] = A[k] + mse_tile_of_lanes4(mse_quad(mv[k], xv[k], wv[k]));
+}
+__device__ __forceinline__ float mse16_total(const float (&A)[4]) {  // the butterfly over the accumulators: 8, 4, 2, 1
+  float r = (A[0] + A[2]) + (A[1] + A[3]);  // accumulator index ^ 8, then ^ 4: registers
+  r = r + dpp_perm<0x128>(r);               // ^ 2: row_ror:8 = lane ^ 8
+  r = r + dpp_perm<0x141>(r);               // ^ 1: row_half_mirror = the neighbouring quad (the value is quad-uniform)
+  return r;
 }
 
-// Weighted MSE of one row against the frame staged in LDS, canonical tree.
+// Weighted MSE of one row against the frame staged in LDS, canonical order.
 // All 64 lanes of the calling wave participate; every lane returns the value.
+// (lane l holds the chunk d = 256 q + 4 l: quad l & 3 of accumulator l >> 2)
 __device__ __forceinline__ float wave_weighted_mse(const float* __restrict__ mean,
                                                    const float* sx, const float* swgt,
                                                    int Dp, int D, int lane) {
   float acc = 0.0f;
-  for (int base = 4 * lane; base < Dp; base += 256) {
-    f32x4 m = *reinterpret_cast<const f32x4*>(mean + base);
-    f32x4 x = *reinterpret_cast<const f32x4*>(sx + base);
-    f32x4 w = *reinterpret_cast<const f32x4*>(swgt + base);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = acc + uis_mse_term(m[i], x[i], w[i]);
+  for (int base0 = 0; base0 < Dp; base0 += 256) {
+    const int base = base0 + 4 * lane;
+    f32x4 m = {0.0f, 0.0f, 0.0f, 0.0f}, x = m, w = m;
+    if (base < Dp) {
+      m = *reinterpret_cast<const f32x4*>(mean + base);
+      x = *reinterpret_cast<const f32x4*>(sx + base);
+      w = *reinterpret_cast<const f32x4*>(swgt + base);
+    }
+    acc = acc + mse_tile_of_lanes4(mse_quad(m, x, w));
   }
-  float sum = wave_tree_sum(acc);
+#pragma unroll
+  for (int off = 32; off >= 4; off >>= 1) acc = acc + __shfl_xor(acc, off, 64);  // accumulator index ^ 8, 4, 2, 1
   float d0 = mean[0] - sx[0];
-  return uis_mse_finish(sum, d0 * d0, D);
+  return uis_mse_finish(acc, d0 * d0, D);
 }
 
 // -------------------------------------------------------------- dense chains
@@ -946,10 +976,8 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
   }
 
   // ---- A: weighted MSE of the frame against every live cluster state.
-  // 16 lanes per cluster state (16 states per pass over the workgroup): physical lane p
-  // carries the canonical tree's virtual lanes p, p+16, p+32, p+48 (uis_numerics.h), so
-  // the first two butterfly levels are register adds and the last four stay inside a
-  // 16-lane row.
+  // 16 lanes per cluster state (16 states per pass over the workgroup), canonical order
+  // (uis_numerics.h): quad sums in registers, tiles and accumulators by DPP inside the 16-lane row.
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
   const float* xrow = st.x + (size_t)frame * m.Dp;
   {
@@ -960,31 +988,22 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
       const int sl = slivelist[act ? i : 0];
       const float* mean = pmean + (size_t)sl * m.Dp;
       const int cnt = (p == 0) ? st.pool_cnt[(size_t)u * S + sl] : 0;
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       float first_sq = 0.0f;
       for (int q = 0; q < m.Dp; q += 256) {
-        f32x4 mv[4], xv[4];
+        f32x4 mv[4], xv[4], wv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int d = q + 4 * (p + 16 * k);
           const bool in = d < m.Dp;
           mv[k] = in ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          wv[k] = in ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int d = q + 4 * (p + 16 * k);
-          if (d < m.Dp) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
-            if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
-          }
-        }
+        mse16_block(mv, xv, wv, A);
+        if (q == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
       }
-      float t = (v[0] + v[2]) + (v[1] + v[3]);   // butterfly levels 32 and 16
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+      const float t = mse16_total(A);
       if (p == 0 && act) { smse[sl] = uis_mse_finish(t, first_sq, m.D); scnt[sl] = cnt; }
     }
   }
@@ -1419,19 +1438,10 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
         }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int d = 4 * (p + 16 * k);
-            if (d < Dp) {
-#pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[h2][k][e2], xv[k][e2], wv[k][e2]);
-            }
-          }
+          float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          mse16_block(mv[h2], xv, wv, A);  // (chunks past Dp are zero-filled)
           const float d0 = mv[h2][0][0] - xv[0][0];
-          float t = (v[0] + v[2]) + (v[1] + v[3]);
-#pragma unroll
-          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+          const float t = mse16_total(A);
           if (p == 0 && act[h2]) { smse[sl[h2]] = uis_mse_finish(t, d0 * d0, m.D); scnt[sl[h2]] = cnt[h2]; }
         }
       }
@@ -1442,10 +1452,10 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
         const int sl = slivelist[act ? i : 0];
         const float* mean = pmean + (size_t)sl * Dp;
         const int cnt = (p == 0) ? (KEEP ? spcnt[sl] : st.pool_cnt[(size_t)u * S + sl]) : 0;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float first_sq = 0.0f;
         for (int q = 0; q < Dp; q += 256) {
-          f32x4 mv[4], xv[4];
+          f32x4 mv[4], xv[4], wv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
@@ -1454,21 +1464,12 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
             else if (RES) mv[k] = load_sc1(rs_mean, (uint32_t)((((size_t)u * S + sl) * Dp + d) * 4));
             else mv[k] = *reinterpret_cast<const f32x4*>(mean + d);
             xv[k] = in ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            wv[k] = in ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int d = q + 4 * (p + 16 * k);
-            if (d < Dp) {
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
-#pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
-              if (q == 0 && k == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
-            }
-          }
+          mse16_block(mv, xv, wv, A);
+          if (q == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
         }
-        float t = (v[0] + v[2]) + (v[1] + v[3]);
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+        const float t = mse16_total(A);
         if (p == 0 && act) { smse[sl] = uis_mse_finish(t, first_sq, m.D); scnt[sl] = cnt; }
       }
     }
@@ -3245,18 +3246,10 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
         }
 #pragma unroll
         for (int h2 = 0; h2 < 4; ++h2) {
-          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (4 * (p + 16 * k) < m.Dp) {
-#pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[h2][k][e2], xv[k][e2], wv[k][e2]);
-            }
-          }
+          float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          mse16_block(mv[h2], xv, wv, A);  // (chunks past Dp are zero-filled)
           const float d0 = mv[h2][0][0] - xv[0][0];
-          float t = (v[0] + v[2]) + (v[1] + v[3]);
-#pragma unroll
-          for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+          const float t = mse16_total(A);
           if (p == 0 && act[h2]) { mse[sl[h2]] = uis_mse_finish(t, d0 * d0, m.D); cntv[sl[h2]] = st.pool_cnt[(size_t)u * S + sl[h2]]; }
         }
       }
@@ -3266,25 +3259,22 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
         const bool act = i < nlive;
         const int sl = livelist[act ? i : 0];
         const float* mean = pmean + (size_t)sl * m.Dp;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float first_sq = 0.0f;
         for (int q = 0; q < m.Dp; q += 256) {
+          f32x4 mv[4], xv[4], wv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
-            if (d < m.Dp) {
-              const f32x4 mv = *reinterpret_cast<const f32x4*>(mean + d);
-              const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + d);
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(m.wgt + d);
-#pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[e2], xv[e2], wv[e2]);
-              if (q == 0 && k == 0) { const float d0 = mv[0] - xv[0]; first_sq = d0 * d0; }
-            }
+            const bool in_ = d < m.Dp;
+            mv[k] = in_ ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            xv[k] = in_ ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            wv[k] = in_ ? *reinterpret_cast<const f32x4*>(m.wgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
+          mse16_block(mv, xv, wv, A);
+          if (q == 0) { const float d0 = mv[0][0] - xv[0][0]; first_sq = d0 * d0; }
         }
-        float t = (v[0] + v[2]) + (v[1] + v[3]);
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
+        const float t = mse16_total(A);
         if (p == 0 && act) { mse[sl] = uis_mse_finish(t, first_sq, m.D); cntv[sl] = st.pool_cnt[(size_t)u * S + sl]; }
       }
     }

@@ -48,10 +48,10 @@ struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
   int off_slot, off_blk;                     // uint16 [B][Kmax]
   int off_K, off_last, off_sum, off_score;   // int32 / float [B]
-  int off_ld;                                // double [B]   log(sum(block_counts) + alpha) of the hypothesis
   int off_hdr;                               // int32 [4]    {hypotheses, grid stride, its magic, 0}
   int set_stride;
   int off_pcnt;                              // uint16 [S]   frames assigned to the cluster state in slot s
+  int off_flag;                              // uint8 [S]    scratch of rs_back: 1 = referenced by the next beam, 3 = and written by this step
   int off_live;                              // u64 [4]      slots referenced by the CURRENT beam
   int off_new;                               // u64 [4]      of those, written by the previous step
   int off_newlist;                           // int32 [1 + B] count, slots written by the previous step
@@ -74,11 +74,11 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   l.off_last = take(B * 4);
   l.off_sum = take(B * 4);
   l.off_score = take(B * 4);
-  l.off_ld = take(B * 8);
   l.off_hdr = take(16);
   l.set_stride = o;
   o += l.set_stride;
   l.off_pcnt = take(S * 2);
+  l.off_flag = take(S);
   l.off_live = take(4 * 8);
   l.off_new = take(4 * 8);
   l.off_newlist = take((1 + B) * 4);
@@ -107,7 +107,8 @@ __host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, i
   const size_t spart = (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4;
   const size_t scratch = (size_t)UIS_RS_UTT * L.scratch_stride;
   return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)UIS_RS_UTT * L.persist_stride +
-         (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 24;
+         (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 16 +
+         (size_t)UIS_RS_UTT * 8;
 }
 
 // minimum of a row of 16 lanes in its lane 15 (DPP row shifts; lanes shifted in from outside the
@@ -133,26 +134,20 @@ __device__ __forceinline__ int rs_wave_max_i32(int v) {  // small non-negative v
 
 // Weighted MSE of the frame (xv: this lane's four float4 chunks) against the mean whose chunks are
 // in mv, by the 16 lanes of a quarter wave in the canonical tree (include/uis_numerics.h): lane p
-// holds d = 4 * (p + 16 k), k = 0..3.  All 16 lanes return the value.  DP <= 256.
+// holds d = 4 * (p + 16 k), k = 0..3.  Lane p == 0 returns the value.  DP <= 256.
 template <int DP>
 __device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&mv)[4], const f32x4 (&xv)[4], const float* swgt,
                                                int p) {
-  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 wv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int d = 4 * (p + 16 * k);
-    if (d < DP) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(swgt + d);
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) v[k] = v[k] + uis_mse_term(mv[k][e2], xv[k][e2], wv[e2]);
-    }
+    wv[k] = d < DP ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  const float d0 = mv[0][0] - xv[0][0];  // meaningful on lane p == 0 (d = 0)
-  float t = (v[0] + v[2]) + (v[1] + v[3]);
-#pragma unroll
-  for (int off = 8; off >= 1; off >>= 1) t = t + __shfl_xor(t, off, 64);
-  const float d0b = __shfl(d0, (threadIdx.x & 63) & ~15, 64);
-  return uis_mse_finish(t, d0b * d0b, m.D);
+  float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  mse16_block(mv, xv, wv, A);  // (chunks past DP are zero-filled)
+  const float d0 = mv[0][0] - xv[0][0];  // meaningful on lane p == 0 (d = 0): the only lane whose value is stored
+  return uis_mse_finish(mse16_total(A), d0 * d0, m.D);
 }
 template <int DP>
 __device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, size_t slot_index, int p, f32x4 (&mv)[4]) {
@@ -163,12 +158,22 @@ __device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, s
   }
 }
 
-// What the front part of a wave's select leaves in registers: lane r = winner r.
+// What the front part of a wave's select leaves in registers: lane r = winner r (four packed
+// words per lane, so that they can stay live across the GRU stage's MFMA chain).
 struct RsWin {
-  int keep, C, nlead;          // wave-uniform: winners, candidates, rnn rows of this utterance
-  bool isw, is_lead;
-  int wb, wc, Kb, src, dst, ord, nprev;
+  int keep, C, nlead;  // wave-uniform: winners, candidates, rnn rows of this utterance
+  unsigned a;          // wb | wc << 8 | Kb << 20
+  unsigned b;          // (src + 1) & 0xffff | (dst & 0xffff) << 16      (src = -1: fresh cluster)
+  unsigned c;          // nprev | ord << 16 | is_lead << 24
   float score;
+  __device__ __forceinline__ int wb() const { return (int)(a & 0xffu); }
+  __device__ __forceinline__ int wc() const { return (int)((a >> 8) & 0xfffu); }
+  __device__ __forceinline__ int Kb() const { return (int)(a >> 20); }
+  __device__ __forceinline__ int src() const { return (int)(b & 0xffffu) - 1; }
+  __device__ __forceinline__ int dst() const { return (int)(b >> 16); }
+  __device__ __forceinline__ int nprev() const { return (int)(c & 0xffffu); }
+  __device__ __forceinline__ int ord() const { return (int)((c >> 16) & 0xffu); }
+  __device__ __forceinline__ bool is_lead() const { return ((c >> 24) & 1u) != 0u; }
 };
 
 __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); }  // lanes of ONE wave talk through LDS: program order is enough
@@ -179,7 +184,7 @@ __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); 
 template <int DP>
 __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
                                           unsigned char* pers, unsigned char* scr, const float* swgt, const double* s_lblk,
-                                          unsigned long long* ph) {
+                                          const double* s_lden, unsigned long long* ph) {
   // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
   // it would have to stay live -- spilled -- across the dense stages)
   int lane_ = threadIdx.x & 63;
@@ -199,7 +204,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
   const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
   const float* sscore = reinterpret_cast<const float*>(set_cur + L.off_score);
-  const double* sld = reinterpret_cast<const double*>(set_cur + L.off_ld);
+  const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
   const int* shdr = reinterpret_cast<const int*>(set_cur + L.off_hdr);
   const unsigned short* spcnt = reinterpret_cast<const unsigned short*>(pers + L.off_pcnt);
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
@@ -246,7 +251,41 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
       }
     }
   }
-  // the published values first (they arrive first), then the rewritten clusters
+  // ---- while that travels: everything about the candidates that does not need an MSE.  The grid:
+  // position e = b * Kcur + c (hypothesis b, cluster c <= K_b), three positions per lane.
+  const int nch = (nb * Kcur + 63) >> 6;
+  int cslot0 = -2, cslot1 = -2, cslot2 = -2;  // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
+  double pr0 = 0.0, pr1 = 0.0, pr2 = 0.0;
+  float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f;
+  auto prep_at = [&](int e, int& cslot, double& prior, float& base) {
+    const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
+    if (b < nb) {
+      const int Kb = sK[b];
+      if (c <= Kb) {
+        const int sum = ssum[b];
+        const double ld = sum < UIS_RS_LOGTAB ? s_lden[sum] : st.logden[sum];
+        base = sscore[b];
+        if (c < Kb) {
+          cslot = (int)sslot[b * Kmax + c];
+          if (c == slast[b]) prior = m.lp_stay;
+          else {
+            const int blk = (int)sblk[b * Kmax + c];
+            const double lb = blk < UIS_RS_LOGTAB ? s_lblk[blk] : st.logblk[blk];
+            prior = (m.lp_sw + lb) - ld;
+          }
+        } else {
+          cslot = -1;
+          prior = (m.lp_sw + m.l_alpha) - ld;
+        }
+      }
+    }
+  };
+  prep_at(lane, cslot0, pr0, bs0);
+  if (nch > 1) prep_at(lane + 64, cslot1, pr1, bs1);
+  if (nch > 2) prep_at(lane + 128, cslot2, pr2, bs2);
+  const int C = __popcll(__ballot(cslot0 != -2)) + __popcll(__ballot(cslot1 != -2)) + __popcll(__ballot(cslot2 != -2));
+  PSTAMP(0);
+  // ---- the MSEs: the published values first (they arrive first), then the rewritten clusters
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (((lv[k] & ~nw[k]) >> lane) & 1ull) smse[lane + 64 * k] = vold[k];
@@ -260,47 +299,25 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     }
   }
   rs_lds_fence();
-  PSTAMP(0);
+  PSTAMP(1);
 
-  // ---- candidate scores on the (hypothesis, cluster) grid: position e = b * Kcur + c
+  // ---- candidate scores
   uint32_t key0 = UIS_RS_NOKEY, key1 = UIS_RS_NOKEY, key2 = UIS_RS_NOKEY;
   float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;
-  int nfin = 0, C = 0;
-  const int nch = (nb * Kcur + 63) >> 6;
-  auto score_at = [&](int e, uint32_t& key, float& sc) {
-    const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
-    bool valid = false;
-    if (b < nb) {
-      const int Kb = sK[b];
-      if (c <= Kb) {
-        valid = true;
-        const double ld = sld[b];
-        float mse;
-        double prior;
-        if (c < Kb) {
-          mse = smse[sslot[b * Kmax + c]];
-          if (c == slast[b]) prior = m.lp_stay;
-          else {
-            const int blk = (int)sblk[b * Kmax + c];
-            const double lb = blk < UIS_RS_LOGTAB ? s_lblk[blk] : st.logblk[blk];
-            prior = (m.lp_sw + lb) - ld;
-          }
-        } else {
-          mse = mse_new;
-          prior = (m.lp_sw + m.l_alpha) - ld;
-        }
-        sc = sscore[b] + uis_step_loss(mse, prior);
-        if (uis_isfinite(sc)) key = uis_score_key(sc);
-      }
+  auto score_at = [&](int cslot, double prior, float base, uint32_t& key, float& sc) {
+    if (cslot != -2) {
+      const float mse = cslot >= 0 ? smse[cslot] : mse_new;
+      sc = base + uis_step_loss(mse, prior);
+      if (uis_isfinite(sc)) key = uis_score_key(sc);
     }
-    C += __popcll(__ballot(valid));
-    nfin += __popcll(__ballot(key != UIS_RS_NOKEY));
   };
-  score_at(lane, key0, sc0);
-  if (nch > 1) score_at(lane + 64, key1, sc1);
-  if (nch > 2) score_at(lane + 128, key2, sc2);
+  score_at(cslot0, pr0, bs0, key0, sc0);
+  if (nch > 1) score_at(cslot1, pr1, bs1, key1, sc1);
+  if (nch > 2) score_at(cslot2, pr2, bs2, key2, sc2);
+  const int nfin = __popcll(__ballot(key0 != UIS_RS_NOKEY)) + __popcll(__ballot(key1 != UIS_RS_NOKEY)) +
+                   __popcll(__ballot(key2 != UIS_RS_NOKEY));
   const int keep = nfin < B ? nfin : B;
-  PSTAMP(1);
+  PSTAMP(2);
 
   // ---- prune: `keep` rounds of the wave-wide minimum; ties to the lowest grid position
   int win_e = 0;
@@ -334,7 +351,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     }
     if (lane == r) { win_e = e; win_sc = s; }
   }
-  PSTAMP(2);
+  PSTAMP(3);
 
   // ---- winners: lane r = winner r
   RsWin out;
@@ -377,7 +394,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     }
   }
   rs_lds_fence();
-  int dst = -1, nprev = 0;
+  int dst = 0xffff, nprev = 0;
   if (is_lead) {
     dst = sdst[ord];
     nprev = src >= 0 ? (int)spcnt[src] : 0;
@@ -386,11 +403,11 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     const int dl = __shfl(dst, lead, 64);
     if (isw && !is_lead) dst = dl;
   }
-  PSTAMP(3);
+  PSTAMP(4);
   out.nlead = nlead;
-  out.isw = isw;
-  out.is_lead = is_lead;
-  out.wb = wb; out.wc = wc; out.Kb = Kb; out.src = src; out.dst = dst; out.ord = ord; out.nprev = nprev;
+  out.a = (unsigned)wb | ((unsigned)wc << 8) | ((unsigned)Kb << 20);
+  out.b = ((unsigned)(src + 1) & 0xffffu) | (((unsigned)dst & 0xffffu) << 16);
+  out.c = (unsigned)nprev | ((unsigned)ord << 16) | (is_lead ? 1u << 24 : 0u);
   out.score = win_sc;
   return out;
 }
@@ -398,12 +415,11 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 // BACK: the next step's tables, masks and counts, the back-pointers -- nothing anybody waits for.
 // `owner`: this workgroup writes what outlives the step to memory.
 __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long off0,
-                                        unsigned char* pers, unsigned char* scr, const double* s_lden, bool owner,
-                                        const RsWin& w) {
+                                        unsigned char* pers, bool owner, const RsWin& w) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
-  const int B = st.B, Kmax = st.Kmax, U = st.U;
+  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
   const int par = step & 1, nxt = par ^ 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   unsigned char* const set_nxt = pers + nxt * L.set_stride;
@@ -411,13 +427,13 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
   const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
   const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
+  unsigned char* sflag = pers + L.off_flag;
   unsigned short* nslot = reinterpret_cast<unsigned short*>(set_nxt + L.off_slot);
   unsigned short* nblk = reinterpret_cast<unsigned short*>(set_nxt + L.off_blk);
   int* nK = reinterpret_cast<int*>(set_nxt + L.off_K);
   int* nlast = reinterpret_cast<int*>(set_nxt + L.off_last);
   int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
   float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
-  double* nld = reinterpret_cast<double*>(set_nxt + L.off_ld);
   int* nhdr = reinterpret_cast<int*>(set_nxt + L.off_hdr);
   unsigned short* spcnt = reinterpret_cast<unsigned short*>(pers + L.off_pcnt);
   unsigned long long* slive = reinterpret_cast<unsigned long long*>(pers + L.off_live);
@@ -425,55 +441,67 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   int* snewlist = reinterpret_cast<int*>(pers + L.off_newlist);
 
   const int r = lane;
+  const bool isw = r < w.keep;
   int Knew_w = 0;
-  unsigned info_a = 0u, info_b = 0u;  // per winner, for the table copy below
-  if (w.isw) {
-    const bool is_new = w.wc == w.Kb;
-    const int lastb = slast[w.wb];
-    Knew_w = w.Kb + (is_new ? 1 : 0);
-    const int blk_new = is_new ? 1 : (int)sblk[w.wb * Kmax + w.wc] + (w.wc != lastb ? 1 : 0);
+  unsigned info_b = 0u;  // per winner, for the table copy below: changed entry's slot | block count << 16
+  if (isw) {
+    const int wb = w.wb(), wc = w.wc(), Kb = w.Kb();
+    const bool is_new = wc == Kb;
+    const int lastb = slast[wb];
+    Knew_w = Kb + (is_new ? 1 : 0);
+    const int blk_new = is_new ? 1 : (int)sblk[wb * Kmax + wc] + (wc != lastb ? 1 : 0);
     if (Knew_w > Kmax) { Knew_w = Kmax; if (owner) st.overflow[u] = 1; }
-    const int sum_new = ssum[w.wb] + ((is_new || w.wc != lastb) ? 1 : 0);
+    const int sum_new = ssum[wb] + ((is_new || wc != lastb) ? 1 : 0);
     nK[r] = Knew_w;
-    nlast[r] = w.wc;
+    nlast[r] = wc;
     nsum[r] = sum_new;
     nscore[r] = w.score;
-    nld[r] = sum_new < UIS_RS_LOGTAB ? s_lden[sum_new] : st.logden[sum_new];
-    info_a = (unsigned)w.wb | ((unsigned)w.wc << 8) | ((unsigned)Knew_w << 20);  // B <= 16, clusters <= 191
-    info_b = ((unsigned)w.dst & 0xffffu) | ((unsigned)blk_new << 16);
+    info_b = ((unsigned)w.dst() & 0xffffu) | ((unsigned)blk_new << 16);
     if (owner) {
       st.beam_score[((size_t)nxt * U + u) * B + r] = w.score;  // (the final beam's scores are read back by k_backtrace)
-      st.bp[((size_t)st.tau * off0 + step) * B + r] = ((unsigned)w.wb << 16) | (unsigned)w.wc;
+      st.bp[((size_t)st.tau * off0 + step) * B + r] = ((unsigned)wb << 16) | (unsigned)wc;
     }
   }
-  if (lane < 4) { slive[lane] = 0ull; snew[lane] = 0ull; }
+  // which slots the next beam references: byte flags (plain stores; LDS atomics on four mask words
+  // would serialise 64 lanes x 8 waves), read back by the slot's own lane below
+  for (int i = lane; 4 * i < S; i += 64) reinterpret_cast<uint32_t*>(sflag)[i] = 0u;
   rs_lds_fence();
+  const int Kmaxseen = rs_wave_max_i32(Knew_w);
   {
-    // every entry of every winner in one pass: the changed entry from the winner's record, the
-    // unchanged ones from the parent's row (BeamState(source), uisrnn.py:66-69)
-    const unsigned kmagicK = ((1u << 20) + (unsigned)Kmax - 1u) / (unsigned)Kmax;  // e / Kmax = (e * magic) >> 20, exact for e < 2048
-    for (int e0 = 0; e0 < w.keep * Kmax; e0 += 64) {
-      const int e = e0 + lane;
-      const int rr = (int)(((unsigned)e * kmagicK) >> 20), c2 = e - rr * Kmax;
-      const unsigned ia = (unsigned)__shfl((int)info_a, rr < 64 ? rr : 0, 64), ib = (unsigned)__shfl((int)info_b, rr < 64 ? rr : 0, 64);
-      if (e < w.keep * Kmax) {
-        const int rb = (int)(ia & 0xffu), rc = (int)((ia >> 8) & 0xfffu), Knew = (int)(ia >> 20);
-        if (c2 < Knew) {
-          int slot, blk;
-          if (c2 == rc) { slot = (int)(ib & 0xffffu); blk = (int)(ib >> 16); }
-          else { slot = (int)sslot[rb * Kmax + c2]; blk = (int)sblk[rb * Kmax + c2]; }
-          nslot[e] = (unsigned short)slot;
-          nblk[e] = (unsigned short)blk;
-          atomicOr(&slive[slot >> 6], 1ull << (slot & 63));
-        }
+    // every entry of every winner: four lanes per winner (B <= 16), lane q of them takes the
+    // clusters q, q + 4, ...; the changed entry from the winner's record, the unchanged ones from
+    // the parent's row (BeamState(source), uisrnn.py:66-69)
+    const int rr = lane >> 2, q = lane & 3;
+    const unsigned ia = (unsigned)__shfl((int)w.a, rr, 64), ib = (unsigned)__shfl((int)info_b, rr, 64);
+    const int Knew = __shfl(Knew_w, rr, 64);
+    const int rb = (int)(ia & 0xffu), rc = (int)((ia >> 8) & 0xfffu);
+    for (int c2 = q; c2 < Kmaxseen; c2 += 4) {
+      if (rr < w.keep && c2 < Knew) {
+        int slot, blk;
+        if (c2 == rc) { slot = (int)(ib & 0xffffu); blk = (int)(ib >> 16); }
+        else { slot = (int)sslot[rb * Kmax + c2]; blk = (int)sblk[rb * Kmax + c2]; }
+        nslot[rr * Kmax + c2] = (unsigned short)slot;
+        nblk[rr * Kmax + c2] = (unsigned short)blk;
+        sflag[slot] = (unsigned char)1;
       }
     }
   }
-  const int Kmaxseen = rs_wave_max_i32(Knew_w);
-  if (w.is_lead) {
-    spcnt[w.dst] = (unsigned short)(w.nprev + 1);
-    atomicOr(&snew[w.dst >> 6], 1ull << (w.dst & 63));
-    snewlist[1 + w.ord] = w.dst;
+  rs_lds_fence();
+  if (w.is_lead()) {
+    const int dst = w.dst();
+    spcnt[dst] = (unsigned short)(w.nprev() + 1);
+    if (sflag[dst]) sflag[dst] = (unsigned char)3;  // (not referenced: a cluster beyond the cap, the call reports the overflow)
+    snewlist[1 + w.ord()] = dst;
+  }
+  rs_lds_fence();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (64 * k < S) {
+      const int sl = lane + 64 * k;
+      const unsigned f = sl < S ? (unsigned)sflag[sl] : 0u;
+      const unsigned long long lm = __ballot((f & 1u) != 0u), nm = __ballot((f & 2u) != 0u);
+      if (lane == 0) { slive[k] = lm; snew[k] = nm; }
+    }
   }
   if (lane == 0) {
     snewlist[0] = w.nlead;
@@ -490,51 +518,105 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   }
 }
 
-// The owner's early MSE: for utterance u, every slot the NEXT beam references that this step does
-// not rewrite, against the next step's frame (row `frame_next`); one float per slot into
-// mse_tab[(step + 1) parity].  Called by all 512 threads of the owner workgroup between the arrival
-// at a barrier and the wait (it needs nobody else's data of this step: those means were final a
-// step ago).
+// The early MSEs, one step ahead: for this wave's utterance u, every slot the NEXT beam references
+// that this step did not rewrite, against the next step's frame (row `frame_next`); one float per
+// slot into mse_tab[(step + 1) parity].  The 32 workgroups of the cluster share the slots of an
+// utterance round robin (every workgroup holds the same masks), so each wave computes at most a
+// handful, in one round trip, between the arrival at the barrier behind the GRU stage and the wait
+// (it needs nobody else's data of this step: those means were final a step ago).
 template <int DP>
 __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step,
-                                             long frame_next, const unsigned char* pers, int* s_list, const float* swgt) {
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+                                             long frame_next, const unsigned char* pers, unsigned char* scr, const float* swgt,
+                                             int rank, int w) {
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
   const int S = st.S, U = st.U;
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
-  // list of old live slots (wave 0 compacts, 64 slots at a time)
-  if (w == 0) {
-    int n = 0;
-    for (int base = 0; base < S; base += 64) {
-      const unsigned long long mask = slive[base >> 6] & ~snew[base >> 6];
-      const bool on = (mask >> lane) & 1ull;
-      if (on) s_list[1 + n + __popcll(mask & ((1ull << lane) - 1ull))] = base + lane;
-      n += __popcll(mask);
+  int* s_list = reinterpret_cast<int*>(scr + L.sc_mse);  // (the front part's MSE area is free by now)
+  int n = 0, before = 0;
+  const int mine_mod = (rank + 4 * w) & 31;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (64 * k < S) {
+      const unsigned long long mask = slive[k] & ~snew[k];
+      const int idx = before + __popcll(mask & ((1ull << lane) - 1ull));
+      const bool mine = ((mask >> lane) & 1ull) && (idx & 31) == mine_mod;
+      const unsigned long long mm = __ballot(mine);
+      if (mine) s_list[n + __popcll(mm & ((1ull << lane) - 1ull))] = lane + 64 * k;
+      n += __popcll(mm);
+      before += __popcll(mask);
     }
-    if (lane == 0) s_list[0] = n;
   }
-  __syncthreads();
-  const int n = s_list[0];
+  if (n == 0) return;
+  rs_lds_fence();
   const __amdgpu_buffer_rsrc_t rs_mean =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
-  const int grp = t >> 4, p = t & 15;
-  if (grp < n) {
-    const float* xrow = st.x + (size_t)frame_next * DP;
-    f32x4 xv[4];
+  const int grp = lane >> 4, p = lane & 15;
+  const float* xrow = st.x + (size_t)frame_next * DP;
+  f32x4 xv[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int d = 4 * (p + 16 * k);
-      xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    float* tab = st.mse_tab + ((size_t)((step + 1) & 1) * U + u) * S;
-    for (int i = grp; i < n; i += 32) {
-      const int sl = s_list[1 + i];
-      f32x4 mv[4];
-      rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
-      const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
-      if (p == 0) tab[sl] = v;
-    }
+  for (int k = 0; k < 4; ++k) {
+    const int d = 4 * (p + 16 * k);
+    xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
+  float* tab = st.mse_tab + ((size_t)((step + 1) & 1) * U + u) * S;
+  for (int i0 = 0; i0 < n; i0 += 4) {
+    const int i = i0 + grp;
+    const int sl = s_list[i < n ? i : 0];
+    f32x4 mv[4];
+    rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
+    const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
+    if (p == 0 && i < n) tab[sl] = v;
+  }
+}
+
+// resident_tile_nv without the workgroup barrier that ends the pass: the caller places it (and may
+// put work that needs no other wave's partial tiles in front of it).
+template <int NG, int PER, int RC, int NV, int KBS, typename After>
+__device__ __forceinline__ void rs_tile_nv(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
+                                           __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], float* spart,
+                                           After after_issue) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4;
+  f32x4 bv[NG];  // oldest in the vmcnt queue: the chain's first operand
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    bv[g] = w == 0 ? *reinterpret_cast<const f32x4*>(bias + (size_t)g * gate_stride + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 b[NV][PER];
+#pragma unroll
+  for (int kb = 0; kb < PER; ++kb)
+#pragma unroll
+    for (int r = 0; r < NV; ++r) b[r][kb] = load_sc1(rsrc, boff[r] + (uint32_t)((w * PER + kb) * KBS + q * 16));
+  after_issue();
+  f32x4 acc[NV][NG];
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[r][g] = bv[g];
+#pragma unroll
+  for (int kb = 0; kb < PER; ++kb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < NV; ++r)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][kb][e], b[r][kb][e], acc[r][g], 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
+}
+template <int NG, int PER, int RC, int KBS, typename After>
+__device__ __forceinline__ void rs_tile(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
+                                        __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], int nvalid, float* spart,
+                                        After after_issue) {
+  static_assert(RC == 3, "dispatch below");
+  if (nvalid >= 3) rs_tile_nv<NG, PER, RC, 3, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+  else if (nvalid == 2) rs_tile_nv<NG, PER, RC, 2, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+  else rs_tile_nv<NG, PER, RC, 1, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
 }
 
 // The one-launch decode with the replicated select (see the top of this file).  Same grid, same
@@ -567,7 +649,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   f32x4* s_w2 = s_w1 + NKB * 64;
   const int head_tiles = rs_head_tiles(B);
   u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);
-  long* s_frame = reinterpret_cast<long*>(s_head + head_tiles * 16);
+  long* s_wframe = reinterpret_cast<long*>(s_head + head_tiles * 16);  // [8] this step's frame of every wave's utterance
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -578,7 +660,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   }
   for (int i = t; i < DP; i += 512) swgt[i] = m.wgt[i];
   for (int i = t; i < UIS_RS_LOGTAB; i += 512) { s_lblk[i] = st.logblk[i]; s_lden[i] = st.logden[i]; }
-  for (int i = t; i < head_tiles * 16; i += 512) { s_head[i] = u32x4{0u, 0u, 0u, 0u}; s_frame[i] = 0; }
+  for (int i = t; i < head_tiles * 16; i += 512) s_head[i] = u32x4{0u, 0u, 0u, 0u};
+  if (t < UIS_RS_UTT) s_wframe[t] = 0;
   // ---- this wave's utterance: slot w of the cluster
   const int u_w = cluster + ncl * w;
   const bool has_u = w < UIS_RS_UTT && u_w < U;
@@ -594,7 +677,6 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     int* hdr = reinterpret_cast<int*>(pers_w + L.off_hdr);
     hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
     reinterpret_cast<int*>(pers_w + L.off_last)[0] = -1;
-    reinterpret_cast<double*>(pers_w + L.off_ld)[0] = st.logden[0];
   }
   {
     int myT = 0;
@@ -603,12 +685,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   }
   __syncthreads();
   const int nsteps = s_ctl[1];
-  // the owner of utterance slot r is rank r: it alone writes that utterance's lasting outputs and
-  // computes its early MSEs
+  // the owner of utterance slot r is rank r: it alone writes that utterance's lasting outputs
   const bool owner_wg = rank < UIS_RS_UTT && cluster + ncl * rank < U;
-  long own_off0 = 0, own_N = 0;
-  if (owner_wg) { own_off0 = (long)st.off[cluster + ncl * rank]; own_N = (long)st.off[cluster + ncl * rank + 1] - own_off0; }
-  const long own_T = (long)st.tau * own_N;
 
   f32x4 wg[3][PER];
   const int ft1 = rank / SH1, tpar1 = rank % SH1;
@@ -631,44 +709,46 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
   uint32_t bar = 0;
-  long fpos_w = 0, own_fpos = 0;  // step % N of this wave's / the owned utterance, kept incrementally
+  long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
   __syncthreads();
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rt_prev = wall_clock64();
   unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ft_acc[4] = {0, 0, 0, 0}, rt_prev2 = rt_prev;
 #endif
 
   for (int s = 0; s < nsteps; ++s) {
     // ---- select, replicated: wave w decides utterance slot w; every workgroup gets the same rows
     RsWin win;
-    win.keep = 0; win.C = 0; win.nlead = 0; win.isw = false; win.is_lead = false;
-    win.wb = 0; win.wc = 0; win.Kb = 0; win.src = -2; win.dst = -1; win.ord = 0; win.nprev = 0; win.score = 0.0f;
+    win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
     const bool act_w = has_u && (long)s < T_w;
     const long frame_w = off0_w + fpos_w;
     if (act_w) {
 #if defined(UIS_RESIDENT_TIMING)
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, s_lden, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
 #else
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, s_lden, nullptr);
 #endif
     }
+#if defined(UIS_RS_BACK_INLINE)  // diagnostic: the back part on the critical path, straight after the front part
+    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
+#endif
     RSTAMP(0);
-    if (lane == 0) s_ctl[8 + w] = win.nlead;
+    if (lane == 0) { s_ctl[8 + w] = win.nlead; s_wframe[w] = frame_w; }
     __syncthreads();
     int base = 0, nrows = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int c = s_ctl[8 + k]; if (k < w) base += c; nrows += c; }
-    if (win.is_lead) {
-      s_head[base + win.ord] = u32x4{(unsigned)u_w, (unsigned)win.src, (unsigned)win.dst, (unsigned)win.nprev};
-      s_frame[base + win.ord] = frame_w;
+    if (win.is_lead()) {
+      // (the wave's number rides in the top bits of the frame count: the row's frame is s_wframe[that])
+      s_head[base + win.ord()] = u32x4{(unsigned)u_w, (unsigned)win.src(), (unsigned)win.dst(), (unsigned)win.nprev() | ((unsigned)w << 16)};
     }
     __syncthreads();
     const int nrt = (nrows + 15) >> 4;
     RSTAMP(1);
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
-    bool back_done = false;
     {
       const int my1 = nrt > tpar1 ? (nrt - tpar1 + SH1 - 1) / SH1 : 0;
       for (int i0 = 0; i0 < my1; i0 += RC) {
@@ -683,29 +763,28 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
         RowHead re[EPT];
         float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
         bool ework[EPT];
-        const bool do_back = !back_done;
         auto epilogue_operands = [&]() {
 #pragma unroll
           for (int k = 0; k < EPT; ++k) {
             const int r = (t >> 8) + 2 * k;
             const int lrow = 16 * (tpar1 + SH1 * (i0 + r)) + ((t & 255) >> 4);
             ework[k] = r < RC && i0 + r < my1 && lrow < nrows;
-            gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
-            re[k] = RowHead{0, 0, 0, 0};
-            if (ework[k]) {
-              re[k] = lds_row_head(s_head, lrow);
-              const long frame = s_frame[lrow];
-              const float* gi = st.gi0 + (size_t)frame * m.G;
-              gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
-              hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
-            }
+            // (no branch around the loads: behind divergent control flow the compiler waits for
+            // EVERYTHING in flight -- these gi0 rows, first touched here, come from HBM -- before
+            // the stage's first MFMA; a thread without a row fetches row 0's operands instead)
+            re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);
+            const long frame = s_wframe[((unsigned)re[k].nprev >> 16) & 7u];
+            re[k].nprev &= 0xffff;
+            const float* gi = st.gi0 + (size_t)frame * m.G;
+            gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
+            hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
           }
-          // the select's back part, while the stage's operands travel
-          if (do_back && act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, scr_w + 0, s_lden, rank == w, win);
         };
-        resident_tile<3, PER, RC, 64>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
-                                      epilogue_operands);
-        back_done = true;
+        FSTAMP(0);
+        rs_tile<3, PER, RC, 64>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
+                                epilogue_operands);
+        __syncthreads();
+        FSTAMP(1);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           if (!ework[k]) continue;
@@ -717,22 +796,19 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
           hst[((tile0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;
         }
+        FSTAMP(2);
         __syncthreads();
+        FSTAMP(3);
       }
     }
-    // (a rank without a row tile of the GRU stage, or a step without rows)
-    if (!back_done && act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, scr_w, s_lden, rank == w, win);
-    if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
     RSTAMP(2);
-    if (owner_wg) {
-      // arrive; then the next step's MSEs of the clusters this step does not rewrite; then wait
-      xcd_arrive(st, cluster, s_ctl);  // (its workgroup barrier also orders every wave's rs_back before the masks are read)
-      if ((long)s + 1 < own_T) {
-        own_fpos = own_fpos + 1 == own_N ? 0 : own_fpos + 1;
-        rs_early_mse<DP>(m, st, L, cluster + ncl * rank, s, own_off0 + own_fpos, s_pers + (size_t)rank * L.persist_stride,
-                         reinterpret_cast<int*>(s_scr), swgt);
-      }
-    }
+    // arrive; then the select's back part (the next step's tables and masks: nothing anybody waits
+    // for, and the wait is idle time for every wave); then wait
+    xcd_arrive(st, cluster, s_ctl);
+#if !defined(UIS_RS_BACK_INLINE)
+    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
+#endif
+    if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
@@ -764,6 +840,11 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       }
     }
     RSTAMP(4);
+    // arrive; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
+    // its share of every utterance's; visible to all behind the step's last barrier); then wait
+    xcd_arrive(st, cluster, s_ctl);
+    if (has_u && (long)s + 1 < T_w)
+      rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
 
@@ -787,12 +868,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             const int r = (t >> 8) + 2 * k;
             const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
             ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
-            old[k] = 0.0f;
-            re[k] = RowHead{0, 0, 0, 0};
-            if (ework[k]) {
-              re[k] = lds_row_head(s_head, lrow);
-              if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
-            }
+            re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);  // (no branch around the load: see the GRU stage)
+            re[k].nprev &= 0xffff;
+            old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + (re[k].src >= 0 ? re[k].src : 0)) * m.Dp + f);
           }
         };
         f32x4 w2r[1][PER];
@@ -820,6 +898,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 31 * ncl))
     for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
   if (t == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = ph_acc[k];
+  if (t == 0 && blockIdx.x == 31 * ncl) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
 #endif
   if (owner_wg && t == 0) {  // this utterance's statistics
     const unsigned long long* acc =
