@@ -661,7 +661,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                   (UIS_RS_DEFAULT || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) && m.Dp <= 256 &&
                   rs_select_ok(B, Kmax, S, U, ncl, (long)maxT) &&
                   resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
-  if (rs) ENSURE(mse_tab, (size_t)2 * U * S * 4);
+  const size_t mse_tab_bytes = ((size_t)2 * U * S * 4 + 255) & ~(size_t)255;
+  if (rs) ENSURE(mse_tab, mse_tab_bytes + (size_t)nclq * rx_stride * 32 * 4);
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -728,6 +729,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
   HIPCHK(hipMemsetAsync(ctl, 0, ctl_words * 4, h->stream));
+  if (rs)  // tiles a model does not have stay +0 in every row's partial sums
+    HIPCHK(hipMemsetAsync(h->mse_tab.as<char>() + mse_tab_bytes, 0, (size_t)nclq * rx_stride * 32 * 4, h->stream));
   // once per decode: pad (only when D is not a multiple of 16), gi0 = W_ih0 x + b_ih0, mse0.
   // Host frames (uis_decode) arrive in chunks on the copy stream; chunk i's kernels overlap the
   // H2D of chunk i+1 (true overlap needs pinned host memory, uis_host_alloc).
@@ -815,7 +818,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       st.rx_stride = rx_stride;
       st.rx_nrows = reinterpret_cast<int32_t*>(ctl) + 32;
       st.rx_bar = ctl + 32 + UIS_MAX_CLUSTERS * 32;
-      if (rs) st.mse_tab = h->mse_tab.as<float>() + 0;  // (one group: resident_ok)
+      if (rs) {  // (one group: resident_ok)
+        st.mse_tab = h->mse_tab.as<float>();
+        st.mse_part = reinterpret_cast<float*>(h->mse_tab.as<char>() + mse_tab_bytes);
+      }
     }
     if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;

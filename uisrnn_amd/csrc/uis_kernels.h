@@ -131,6 +131,10 @@ struct DecodeState {
   // that step's frame against the cluster mean in `slot`, published one step ahead by the
   // utterance's owner rank for the clusters the step in between does not rewrite
   float* mse_tab;
+  // ... and mse_part[(c * rx_stride + row) * 32 + ft] = tile ft's partial sum (uis_numerics.h) of the
+  // NEXT step's weighted MSE against the mean that row `row` of cluster c's current step writes,
+  // [.. + 16] = the squared first difference; emitted by the linear_mean2 epilogue
+  float* mse_part;
   // streaming (uis_stream_*): utterances are NOT in lock-step.  avail[u] = frames received so far
   // (= decode steps that may run; test_iteration is 1), foff[u] + step = row of step `step`'s
   // frame in the current chunk's x / gi0 / mse0, lab_off[u] = where the utterance's labels go.

@@ -35,7 +35,7 @@
 // 1: k_decode_rs is the default wherever it applies (UIS_FLAG_OWNER_SELECT keeps k_decode_resident);
 // 0: it runs only with UIS_FLAG_REPLICATED_SELECT
 #ifndef UIS_RS_DEFAULT
-#define UIS_RS_DEFAULT 0
+#define UIS_RS_DEFAULT 1
 #endif
 #define UIS_RS_UTT 8        // utterances per cluster (one per wave)
 #define UIS_RS_MAXB 16      // beam_size
@@ -108,7 +108,7 @@ __host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, i
   const size_t scratch = (size_t)UIS_RS_UTT * L.scratch_stride;
   return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)UIS_RS_UTT * L.persist_stride +
          (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 16 +
-         (size_t)UIS_RS_UTT * 8;
+         (size_t)2 * UIS_RS_UTT * 8;
 }
 
 // minimum of a row of 16 lanes in its lane 15 (DPP row shifts; lanes shifted in from outside the
@@ -181,9 +181,11 @@ __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); 
 // FRONT: scores, prune, winners, rows.  One wave (all 64 lanes), utterance u, decode step `step`
 // whose frame is row `frame` of the stream.  pers = the utterance's persistent block, scr = this
 // wave's scratch.
+// `part0` = where the partial sums of the rows this utterance emitted in the previous step start
+// (the i-th slot of its new-slot list was written by its i-th row).
 template <int DP>
 __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
-                                          unsigned char* pers, unsigned char* scr, const float* swgt, const double* s_lblk,
+                                          unsigned char* pers, unsigned char* scr, const float* part0, const double* s_lblk,
                                           const double* s_lden, unsigned long long* ph) {
   // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
   // it would have to stay live -- spilled -- across the dense stages)
@@ -215,10 +217,9 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 
   const int nb = shdr[0], Kcur = shdr[1], kmagic = shdr[2];
   // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
-  // step left alone, the means of the ones it rewrote, the frame
+  // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
+  // (sixteen floats + the squared first difference per cluster: lane i takes new cluster i)
   const float mse_new = st.mse0[frame];
-  const __amdgpu_buffer_rsrc_t rs_mean =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   unsigned long long lv[4], nw[4];
   float vold[4];
   {
@@ -232,24 +233,16 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     }
   }
   const int nn = snewlist[0];
-  const int grp = lane >> 4, p = lane & 15;
-  f32x4 xv[4], mv[4][4];
-  int nsl[4];
-  if (nn > 0) {
-    const float* xrow = st.x + (size_t)frame * DP;
+  f32x4 pv[4];
+  float pfirst = 0.0f;
+  int nsl = 0;
+  if (lane < nn) {
+    const __amdgpu_buffer_rsrc_t rs_part =
+        __builtin_amdgcn_make_buffer_rsrc((void*)part0, (short)0, 0x7fffffff, 0x00020000);
+    nsl = snewlist[1 + lane];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int d = 4 * (p + 16 * k);
-      xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      if (4 * ps < nn) {
-        const int i = 4 * ps + grp;
-        nsl[ps] = snewlist[1 + (i < nn ? i : 0)];
-        rs_load_mean16<DP>(rs_mean, (size_t)u * S + nsl[ps], p, mv[ps]);
-      }
-    }
+    for (int k = 0; k < 4; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * 128 + 16 * k));
+    pfirst = load_f32_sc1(part0 + lane * 32 + 16);
   }
   // ---- while that travels: everything about the candidates that does not need an MSE.  The grid:
   // position e = b * Kcur + c (hypothesis b, cluster c <= K_b), three positions per lane.
@@ -289,14 +282,11 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (((lv[k] & ~nw[k]) >> lane) & 1ull) smse[lane + 64 * k] = vold[k];
-  if (nn > 0) {
+  if (lane < nn) {
+    float A[16];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      if (4 * ps < nn) {
-        const float v = rs_mse16_regs<DP>(m, mv[ps], xv, swgt, p);
-        if (p == 0 && 4 * ps + grp < nn) smse[nsl[ps]] = v;
-      }
-    }
+    for (int k = 0; k < 4; ++k) { A[4 * k] = pv[k][0]; A[4 * k + 1] = pv[k][1]; A[4 * k + 2] = pv[k][2]; A[4 * k + 3] = pv[k][3]; }
+    smse[nsl] = uis_mse_finish(uis_mse_acc_sum(A), pfirst, m.D);
   }
   rs_lds_fence();
   PSTAMP(1);
@@ -650,6 +640,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const int head_tiles = rs_head_tiles(B);
   u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);
   long* s_wframe = reinterpret_cast<long*>(s_head + head_tiles * 16);  // [8] this step's frame of every wave's utterance
+  long* s_wnext = s_wframe + UIS_RS_UTT;                               // [8] ... and the next step's
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -661,7 +652,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   for (int i = t; i < DP; i += 512) swgt[i] = m.wgt[i];
   for (int i = t; i < UIS_RS_LOGTAB; i += 512) { s_lblk[i] = st.logblk[i]; s_lden[i] = st.logden[i]; }
   for (int i = t; i < head_tiles * 16; i += 512) s_head[i] = u32x4{0u, 0u, 0u, 0u};
-  if (t < UIS_RS_UTT) s_wframe[t] = 0;
+  if (t < UIS_RS_UTT) { s_wframe[t] = 0; s_wnext[t] = 0; }
   // ---- this wave's utterance: slot w of the cluster
   const int u_w = cluster + ncl * w;
   const bool has_u = w < UIS_RS_UTT && u_w < U;
@@ -710,6 +701,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
   uint32_t bar = 0;
   long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
+  float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * 32;  // this cluster's rows of partial sums
+  int prev_base = 0;  // first row of this wave's utterance in the previous step's row list
   __syncthreads();
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -726,16 +719,20 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     const long frame_w = off0_w + fpos_w;
     if (act_w) {
 #if defined(UIS_RESIDENT_TIMING)
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, s_lden, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, s_lblk, s_lden, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
 #else
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, swgt, s_lblk, s_lden, nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, s_lblk, s_lden, nullptr);
 #endif
     }
 #if defined(UIS_RS_BACK_INLINE)  // diagnostic: the back part on the critical path, straight after the front part
     if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
 #endif
     RSTAMP(0);
-    if (lane == 0) { s_ctl[8 + w] = win.nlead; s_wframe[w] = frame_w; }
+    if (lane == 0) {
+      s_ctl[8 + w] = win.nlead;
+      s_wframe[w] = frame_w;
+      s_wnext[w] = off0_w + (fpos_w + 1 == N_w ? 0 : fpos_w + 1);  // (after the last step: some frame of the utterance, unused)
+    }
     __syncthreads();
     int base = 0, nrows = 0;
 #pragma unroll
@@ -746,6 +743,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     }
     __syncthreads();
     const int nrt = (nrows + 15) >> 4;
+    prev_base = base;
     RSTAMP(1);
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
@@ -860,7 +858,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
         }
         const int f = ft2 * 16 + (t & 15);
         RowHead re[EPT];
-        float old[EPT];
+        float old[EPT], xn[EPT];
         bool ework[EPT];
         auto epilogue_operands = [&]() {
 #pragma unroll
@@ -869,6 +867,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
             ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
             re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);  // (no branch around the load: see the GRU stage)
+            xn[k] = st.x[(size_t)s_wnext[((unsigned)re[k].nprev >> 16) & 7u] * DP + f];  // the NEXT frame of the row's utterance
             re[k].nprev &= 0xffff;
             old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + (re[k].src >= 0 ? re[k].src : 0)) * m.Dp + f);
           }
@@ -886,6 +885,16 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
           if (f >= m.D) v = 0.0f;
           st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+          // this tile's share of the next step's weighted MSE against the mean just written
+          // (uis_numerics.h: the row's 16 features of the tile sit in 16 adjacent lanes -- quad sums
+          // left to right, then (q0 + q1) + (q2 + q3)); the select adds the tiles' sums
+          const float term = uis_mse_term(v, xn[k], swgt[f]);
+          float q = ((dpp_perm<0x00>(term) + dpp_perm<0x55>(term)) + dpp_perm<0xAA>(term)) + dpp_perm<0xFF>(term);
+          q = q + dpp_perm<0x141>(q);  // row_half_mirror: the neighbouring quad's sum
+          q = q + dpp_perm<0x140>(q);  // row_mirror: the other half's
+          const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
+          if ((t & 15) == 0) part_c[(size_t)lrow * 32 + ft2] = q;
+          if (f == 0) { const float d0 = v - xn[k]; part_c[(size_t)lrow * 32 + 16] = d0 * d0; }
         }
         __syncthreads();
       }
