@@ -178,78 +178,69 @@ struct RsWin {
 
 __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); }  // lanes of ONE wave talk through LDS: program order is enough
 
-// FRONT: scores, prune, winners, rows.  One wave (all 64 lanes), utterance u, decode step `step`
-// whose frame is row `frame` of the stream.  pers = the utterance's persistent block, scr = this
-// wave's scratch.
-// `part0` = where the partial sums of the rows this utterance emitted in the previous step start
-// (the i-th slot of its new-slot list was written by its i-th row).
-template <int DP>
-__device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
-                                          unsigned char* pers, unsigned char* scr, const float* part0, const double* s_lblk,
-                                          const double* s_lden, unsigned long long* ph) {
-  // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
-  // it would have to stay live -- spilled -- across the dense stages)
+// PREP: everything about a step's candidates that needs nothing but the utterance's tables -- the
+// candidate grid with each candidate's slot, prior and hypothesis score, the live / new slot masks,
+// the first beam_size free slots.  Runs one step ahead, inside the previous step's last barrier.
+// The grid: position e = b * Kcur + c (hypothesis b, cluster c <= K_b), three positions per lane.
+struct RsPrep {
+  int nb, nch, C, nn;                 // wave-uniform
+  int Kcur, kmagic;
+  unsigned long long old0, old1, old2, old3;  // live slots the previous step left alone (their MSEs are published)
+  int cslot0, cslot1, cslot2;         // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
+  double pr0, pr1, pr2;
+  float bs0, bs1, bs2;
+};
+
+__device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& st, const RsLds& L, int step,
+                                          const unsigned char* pers, unsigned char* scr, const double* s_lblk,
+                                          const double* s_lden) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
-#if defined(UIS_RESIDENT_TIMING)
-  unsigned long long ph_prev = wall_clock64();
-#define PSTAMP(k) do { if (ph) { const unsigned long long n_ = wall_clock64(); ph[k] += n_ - ph_prev; ph_prev = n_; } } while (0)
-#else
-#define PSTAMP(k) do {} while (0)
-#endif
-  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int B = st.B, Kmax = st.Kmax, S = st.S;
   const int par = step & 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
   const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
   const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
   const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
-  const float* sscore = reinterpret_cast<const float*>(set_cur + L.off_score);
   const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
+  const float* sscore = reinterpret_cast<const float*>(set_cur + L.off_score);
   const int* shdr = reinterpret_cast<const int*>(set_cur + L.off_hdr);
-  const unsigned short* spcnt = reinterpret_cast<const unsigned short*>(pers + L.off_pcnt);
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
   const int* snewlist = reinterpret_cast<const int*>(pers + L.off_newlist);
-  float* smse = reinterpret_cast<float*>(scr + L.sc_mse);
   int* sdst = reinterpret_cast<int*>(scr + L.sc_dst);
-
-  const int nb = shdr[0], Kcur = shdr[1], kmagic = shdr[2];
-  // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
-  // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
-  // (sixteen floats + the squared first difference per cluster: lane i takes new cluster i)
-  const float mse_new = st.mse0[frame];
-  unsigned long long lv[4], nw[4];
-  float vold[4];
+  RsPrep P;
+  P.nb = shdr[0]; P.Kcur = shdr[1]; P.kmagic = shdr[2];
+  P.nn = snewlist[0];
+  const int nb = P.nb, Kcur = P.Kcur, kmagic = P.kmagic;
+  unsigned long long lv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lv[k] = 64 * k < S ? slive[k] : 0ull;
+  P.old0 = lv[0] & ~snew[0];
+  P.old1 = 64 < S ? lv[1] & ~snew[1] : 0ull;
+  P.old2 = 128 < S ? lv[2] & ~snew[2] : 0ull;
+  P.old3 = 192 < S ? lv[3] & ~snew[3] : 0ull;
+  // the first beam_size free slots (not referenced by the current beam), in slot order: slot-lane
+  // l + 64 k knows its own rank among the free ones
   {
-    const float* tab = st.mse_tab + ((size_t)par * U + u) * S;
+    int before = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      lv[k] = 64 * k < S ? slive[k] : 0ull;
-      nw[k] = 64 * k < S ? snew[k] : 0ull;
-      vold[k] = 0.0f;
-      if (((lv[k] & ~nw[k]) >> lane) & 1ull) vold[k] = load_f32_sc1(tab + lane + 64 * k);
+      if (64 * k < S && before < B) {
+        unsigned long long fm = ~lv[k];
+        if (S - 64 * k < 64) fm &= (1ull << (S - 64 * k)) - 1ull;
+        const int rk = before + __popcll(fm & ((1ull << lane) - 1ull));
+        if (((fm >> lane) & 1ull) && rk < B) sdst[rk] = lane + 64 * k;
+        before += __popcll(fm);
+      }
     }
   }
-  const int nn = snewlist[0];
-  f32x4 pv[4];
-  float pfirst = 0.0f;
-  int nsl = 0;
-  if (lane < nn) {
-    const __amdgpu_buffer_rsrc_t rs_part =
-        __builtin_amdgcn_make_buffer_rsrc((void*)part0, (short)0, 0x7fffffff, 0x00020000);
-    nsl = snewlist[1 + lane];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * 128 + 16 * k));
-    pfirst = load_f32_sc1(part0 + lane * 32 + 16);
-  }
-  // ---- while that travels: everything about the candidates that does not need an MSE.  The grid:
-  // position e = b * Kcur + c (hypothesis b, cluster c <= K_b), three positions per lane.
-  const int nch = (nb * Kcur + 63) >> 6;
-  int cslot0 = -2, cslot1 = -2, cslot2 = -2;  // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
-  double pr0 = 0.0, pr1 = 0.0, pr2 = 0.0;
-  float bs0 = 0.0f, bs1 = 0.0f, bs2 = 0.0f;
+  P.nch = (nb * Kcur + 63) >> 6;
+  P.cslot0 = P.cslot1 = P.cslot2 = -2;
+  P.pr0 = P.pr1 = P.pr2 = 0.0;
+  P.bs0 = P.bs1 = P.bs2 = 0.0f;
   auto prep_at = [&](int e, int& cslot, double& prior, float& base) {
     const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
     if (b < nb) {
@@ -273,15 +264,77 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
       }
     }
   };
-  prep_at(lane, cslot0, pr0, bs0);
-  if (nch > 1) prep_at(lane + 64, cslot1, pr1, bs1);
-  if (nch > 2) prep_at(lane + 128, cslot2, pr2, bs2);
-  const int C = __popcll(__ballot(cslot0 != -2)) + __popcll(__ballot(cslot1 != -2)) + __popcll(__ballot(cslot2 != -2));
+  prep_at(lane, P.cslot0, P.pr0, P.bs0);
+  if (P.nch > 1) prep_at(lane + 64, P.cslot1, P.pr1, P.bs1);
+  if (P.nch > 2) prep_at(lane + 128, P.cslot2, P.pr2, P.bs2);
+  P.C = __popcll(__ballot(P.cslot0 != -2)) + __popcll(__ballot(P.cslot1 != -2)) + __popcll(__ballot(P.cslot2 != -2));
+  return P;
+}
+
+// FRONT: the MSEs, scores, prune, winners, rows -- what the step's dense stages wait for.  One wave
+// (all 64 lanes), utterance u, decode step `step` whose frame is row `frame` of the stream.  pers =
+// the utterance's persistent block, scr = this wave's scratch (rs_prep left the free slots there).
+// `part0` = where the partial sums of the rows this utterance emitted in the previous step start
+// (the i-th slot of its new-slot list was written by its i-th row).
+template <int DP>
+__device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
+                                          unsigned char* pers, unsigned char* scr, const float* part0, const RsPrep& P,
+                                          unsigned long long* ph) {
+  // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
+  // it would have to stay live -- spilled -- across the dense stages)
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long ph_prev = wall_clock64();
+#define PSTAMP(k) do { if (ph) { const unsigned long long n_ = wall_clock64(); ph[k] += n_ - ph_prev; ph_prev = n_; } } while (0)
+#else
+#define PSTAMP(k) do {} while (0)
+#endif
+  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int par = step & 1;
+  const unsigned char* const set_cur = pers + par * L.set_stride;
+  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
+  const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
+  const unsigned short* spcnt = reinterpret_cast<const unsigned short*>(pers + L.off_pcnt);
+  const int* snewlist = reinterpret_cast<const int*>(pers + L.off_newlist);
+  float* smse = reinterpret_cast<float*>(scr + L.sc_mse);
+  const int* sdst = reinterpret_cast<const int*>(scr + L.sc_dst);
+
+  const int Kcur = P.Kcur, kmagic = P.kmagic, nch = P.nch, C = P.C, nn = P.nn;
+  const int cslot0 = P.cslot0, cslot1 = P.cslot1, cslot2 = P.cslot2;
+  const double pr0 = P.pr0, pr1 = P.pr1, pr2 = P.pr2;
+  const float bs0 = P.bs0, bs1 = P.bs1, bs2 = P.bs2;
+  const unsigned long long old[4] = {P.old0, P.old1, P.old2, P.old3};
+  // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
+  // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
+  // (sixteen floats + the squared first difference per cluster: lane i takes new cluster i)
+  const float mse_new = st.mse0[frame];
+  float vold[4];
+  {
+    const float* tab = st.mse_tab + ((size_t)par * U + u) * S;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      vold[k] = 0.0f;
+      if ((old[k] >> lane) & 1ull) vold[k] = load_f32_sc1(tab + lane + 64 * k);
+    }
+  }
+  f32x4 pv[4];
+  float pfirst = 0.0f;
+  int nsl = 0;
+  if (lane < nn) {
+    const __amdgpu_buffer_rsrc_t rs_part =
+        __builtin_amdgcn_make_buffer_rsrc((void*)part0, (short)0, 0x7fffffff, 0x00020000);
+    nsl = snewlist[1 + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * 128 + 16 * k));
+    pfirst = load_f32_sc1(part0 + lane * 32 + 16);
+  }
   PSTAMP(0);
   // ---- the MSEs: the published values first (they arrive first), then the rewritten clusters
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (((lv[k] & ~nw[k]) >> lane) & 1ull) smse[lane + 64 * k] = vold[k];
+    if ((old[k] >> lane) & 1ull) smse[lane + 64 * k] = vold[k];
   if (lane < nn) {
     float A[16];
 #pragma unroll
@@ -368,22 +421,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const unsigned long long lmask = __ballot(is_lead);
   const int nlead = __popcll(lmask);
   const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
-  // the ord-th free slot (not referenced by the current beam), in slot order: slot-lane l + 64 k
-  // knows its own rank among the free ones
-  {
-    int before = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (64 * k < S && before < nlead) {
-        unsigned long long fm = ~lv[k];
-        if (S - 64 * k < 64) fm &= (1ull << (S - 64 * k)) - 1ull;
-        const int rk = before + __popcll(fm & ((1ull << lane) - 1ull));
-        if (((fm >> lane) & 1ull) && rk < nlead) sdst[rk] = lane + 64 * k;
-        before += __popcll(fm);
-      }
-    }
-  }
-  rs_lds_fence();
+  // (the ord-th free slot: rs_prep listed them)
   int dst = 0xffff, nprev = 0;
   if (is_lead) {
     dst = sdst[ord];
@@ -711,6 +749,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   unsigned long long ft_acc[4] = {0, 0, 0, 0}, rt_prev2 = rt_prev;
 #endif
 
+  RsPrep prep = rs_prep(m, st, L, 0, pers_w, scr_w, s_lblk, s_lden);  // (later steps: inside the previous step's last barrier)
   for (int s = 0; s < nsteps; ++s) {
     // ---- select, replicated: wave w decides utterance slot w; every workgroup gets the same rows
     RsWin win;
@@ -719,9 +758,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     const long frame_w = off0_w + fpos_w;
     if (act_w) {
 #if defined(UIS_RESIDENT_TIMING)
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, s_lblk, s_lden, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, prep, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
 #else
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, s_lblk, s_lden, nullptr);
+      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, prep, nullptr);
 #endif
     }
 #if defined(UIS_RS_BACK_INLINE)  // diagnostic: the back part on the critical path, straight after the front part
@@ -900,6 +939,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       }
     }
     RSTAMP(6);
+    // arrive; then the next step's candidate grid (this wave's own tables: nobody else's data); then wait
+    xcd_arrive(st, cluster, s_ctl);
+    if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
