@@ -18,21 +18,29 @@ utterances (weak scaling) and the only collective is the final all_gather of the
 labels (RCCL over xGMI).  `--gpus N` with N > 1 and no WORLD_SIZE in the environment
 re-executes itself under `python -m torch.distributed.run --nproc-per-node N`; under
 torchrun (the driver's launch) it reads RANK / LOCAL_RANK / WORLD_SIZE.  It refuses to
-run when fewer than N HIP devices are visible.
+run when fewer than N HIP devices are visible.  Every rank pins itself to its share of the
+host cores (the library's float64 -> float32 cast threads follow the affinity mask).
 
-The frame stream and the label buffer live in HBM before the timed region starts
-(torch is used for device memory and torch.distributed only).  `value` is that
-HBM-resident rate; `value_host_buffers` is the same pass through uis_decode from
-pinned host memory (H2D of the frames and D2H of the labels inside the clock,
-SURVEY.md 8d).
-
-Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     -- the dominant kernel timed with HIP events on the decode stream
-  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on
-                  this box's host cores on a bounded sample (the GPU labels are checked
-                  against it), next to the reference's own measured rates
-                  (tests/golden/reference_cpu_rate.json, recorded in the dev container:
-                  google/uis-rnn cannot travel to the GPU box).
+What the ONE JSON line (rank 0) says, field by field:
+  value                 frames/s of the whole job with the frame stream and the label buffer
+                        resident in HBM when the clock starts (the bench contract's definition);
+                        value_device is the same number under an explicit name
+  value_host_buffers    the same passes through uis_decode from PINNED float32 host memory:
+                        H2D of the frames and D2H of the labels inside the clock
+  value_predict_f64     the same passes through uis_decode_f64 from the list of float64 arrays
+                        UISRNN.predict receives (cast + H2D + decode + D2H inside the clock)
+  setup_passes/_ms      untimed decodes before the warm-up (cluster cap, control-word placement)
+  per_rank_ms           min / max over ranks of a rank's own time per step
+  roofline              the dominant kernel, timed with HIP events on the decode stream:
+                        `frac` = what the MFMA pipes EXECUTED (rows after de-duplication) / peak,
+                        never above 1; `effective` = the algorithmic rows (one CoreRNN step per
+                        surviving hypothesis) / peak -- de-duplication's credit
+  cpu_baseline          the CPU oracle (oracle/, a port of the reference algorithm) timed on this
+                        box's host cores on a bounded sample (the GPU labels are checked against
+                        it); the reference's own measured rates (dev container, google/uis-rnn
+                        cannot travel) as reference_* scalars
+  extra_configs         configs[2], the configs[3] share and configs[4] at their stated sizes,
+                        a few passes each, with frac and a parity check against the oracle
 """
 
 import argparse
@@ -103,14 +111,14 @@ def committed_traffic(kernel):
   """
   import glob
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
-  if not files:
-    return None
-  try:
-    entry = json.load(open(files[-1]))['kernels'][kernel]
-    return {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
-            'source': os.path.relpath(files[-1], ROOT)}
-  except (KeyError, ValueError):
-    return None
+  for path in reversed(files):
+    try:
+      entry = json.load(open(path))['kernels'][kernel]
+      return {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
+              'source': os.path.relpath(path, ROOT)}
+    except (KeyError, ValueError, OSError):
+      continue
+  return None
 
 
 def reference_rates():
@@ -136,18 +144,25 @@ def parse(argv=None):
   ap.add_argument('--utterances', type=int, default=None, help='utterances per GPU')
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--beam_size', type=int, default=None)
+  ap.add_argument('--ragged', action='store_true',
+                  help='utterance lengths uniform in [frames / 2, frames]; the whole job\'s utterances are '
+                       'dealt to the ranks by uisrnn_amd.distributed.shard_utterances (longest first)')
   ap.add_argument('--model', default='auto', choices=['auto', 'trained', 'tracker'],
                   help='trained = tests/golden/trained_d{256,512}.uisrnn (the reference\'s fit, '
                        'SURVEY.md 8d); tracker = closed-form weights (uisrnn_amd.synth); '
                        'auto = trained where it applies')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--no_host_buffers', action='store_true',
-                  help='skip the PCIe-inclusive pass (value_host_buffers)')
+                  help='skip the PCIe-inclusive passes (value_host_buffers, value_predict_f64)')
+  ap.add_argument('--no_extra_configs', action='store_true',
+                  help='skip the short runs of the other BASELINE configs (extra_configs)')
   ap.add_argument('--cpu_sample', type=int, default=0,
                   help='utterances in the CPU-baseline sample (0 = auto)')
   ap.add_argument('--flags', type=int, default=0, help='UIS_FLAG_* for the timed run')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for N > 1 (nccl = RCCL over xGMI)')
+  ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'],
+                  help='cpu: plumbing tests only (gloo, a stand-in decoder; tests/test_bench_dist.py)')
   ap.add_argument('--force_dist', action='store_true',
                   help='initialise the process group and run the gather even with one rank '
                        '(exercises the RCCL calls on a single-GPU box)')
@@ -171,12 +186,29 @@ def respawn_under_torchrun(n_gpus, argv):
   os.execv(sys.executable, cmd)
 
 
-def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None):
+def pin_rank_to_cores(local_rank, local_world):
+  """Give this rank its share of the host cores (8 ranks x the library's cast threads would
+  otherwise all land on the same cores).  Returns the number of cores this rank may use."""
+  try:
+    cores = sorted(os.sched_getaffinity(0))
+    if local_world > 1 and len(cores) >= local_world:
+      per = len(cores) // local_world
+      mine = cores[local_rank * per:(local_rank + 1) * per]
+      os.sched_setaffinity(0, mine)
+      return len(mine)
+    return len(cores)
+  except (AttributeError, OSError):
+    return os.cpu_count() or 1
+
+
+def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None, per_rank=None):
   """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both
   sides; returns the MAX over ranks of the elapsed seconds.
 
   step_fn(): one pass of the hot path (incl. the final label gather when dist is set);
   sync_fn(): wait for this rank's device.  `dist` is torch.distributed or None.
+  per_rank: optional list that receives every rank's own seconds BEFORE the closing barrier
+  (how long it alone needed: the spread shows imbalance).
   """
   import torch  # pylint: disable=import-outside-toplevel
   for _ in range(warmup):
@@ -189,6 +221,7 @@ def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None)
   for _ in range(steps):
     step_fn()
   sync_fn()
+  own = time.perf_counter() - t0
   if dist is not None:
     dist.barrier()
   elapsed = time.perf_counter() - t0
@@ -196,6 +229,12 @@ def timed_region(step_fn, sync_fn, steps, warmup, dist=None, reduce_device=None)
     t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if per_rank is not None:
+      every = torch.empty(dist.get_world_size(), dtype=torch.float64, device=reduce_device)
+      dist.all_gather_into_tensor(every, torch.tensor([own], dtype=torch.float64, device=reduce_device))
+      per_rank.extend(float(v) for v in every.tolist())
+  elif per_rank is not None:
+    per_rank.append(own)
   return elapsed
 
 
@@ -215,6 +254,186 @@ def load_model(cfg, which):
           'closed-form tracker (uisrnn_amd.synth)')
 
 
+class Workload:
+  """One BASELINE config on this rank: the model, this rank's utterances, the buffers in HBM."""
+
+  def __init__(self, cfg, args, rank, world, dev, dev_index):
+    import torch  # pylint: disable=import-outside-toplevel
+    from uisrnn_amd import _capi, distributed, synth  # pylint: disable=import-outside-toplevel
+    self.cfg, self.args, self.torch, self.capi = cfg, args, torch, _capi
+    self.dim, self.hid = cfg['observation_dim'], cfg['rnn_hidden_size']
+    self.beam, self.look, self.tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
+    n_utt, n_frames = cfg['utterances_per_gpu'], cfg['frames']
+    self.params, cfg['model'] = load_model(cfg, args.model)
+    if args.ragged:
+      # the WHOLE job's utterances (same list on every rank), dealt longest first
+      rng = np.random.default_rng(4242)
+      lengths = rng.integers(max(n_frames // 2, 1), n_frames + 1, size=n_utt * world)
+      mine = distributed.shard_utterances(lengths, world)[rank]
+      self.seqs = [synth.make_utterance(10_000 + int(i), int(lengths[i]), self.dim)[0] for i in mine]
+      self.job_frames = int(lengths.sum())
+    else:
+      self.seqs, _ = synth.make_utterances(10_000 + rank * n_utt, n_utt, n_frames, self.dim)
+      self.job_frames = world * n_utt * n_frames
+    self.n_utt = len(self.seqs)
+    lens = np.array([s.shape[0] for s in self.seqs], dtype=np.int64)
+    self.offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    self.rank_frames = int(self.offsets[-1])
+    self.frames = (np.concatenate(self.seqs, axis=0).astype(np.float32) if self.n_utt
+                   else np.zeros((0, self.dim), np.float32))
+    self.decoder = _capi.Decoder(self.params, device=dev_index)
+    self.d_frames = torch.from_numpy(self.frames).to(dev)
+    self.d_labels = torch.empty(max(self.rank_frames, 1), dtype=torch.int32, device=dev)
+    self.d_scores = torch.empty(max(self.n_utt, 1), dtype=torch.float32, device=dev)
+    self.cap = cfg['max_clusters']
+    self.timing = False
+    self.last = None
+
+  def decode_once(self, flags):
+    while True:
+      out = self.decoder.decode_device(self.d_frames.data_ptr(), self.offsets, self.beam, self.look, self.tau,
+                                       self.d_labels.data_ptr(), self.d_scores.data_ptr(),
+                                       max_clusters=self.cap, flags=flags, n_streams=self.args.streams)
+      if out['status'] == 0:
+        self.last = out
+        return out
+      # a surviving hypothesis needed more clusters than the tables hold: the Python host's
+      # policy (uisrnn_amd/uisrnn.py) is to decode again with twice the room; only set-up / warm-up
+      # passes may do that -- a timed pass that retried would be counted as failed
+      if self.timing:
+        raise RuntimeError('decode hit the cluster cap inside the timed region')
+      self.cap *= 2
+
+  def setup(self, sync_fn):
+    """Untimed decodes before anything is measured: the first settles the cluster cap, the next
+    four are the decoder's trials of its control-word placement for this shape.
+    Returns (passes, total ms)."""
+    passes = 5 if self.rank_frames <= 2_000_000 else 1
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+      self.decode_once(self.args.flags)
+    sync_fn()
+    return passes, 1e3 * (time.perf_counter() - t0)
+
+  def roofline(self, value_rank):
+    """The dominant kernel's line, from one profiled pass (HIP events around every launch)."""
+    cfg, hid, dim = self.cfg, self.hid, self.dim
+    prof = self.decoder.decode_device(self.d_frames.data_ptr(), self.offsets, self.beam, self.look, self.tau,
+                                      self.d_labels.data_ptr(), self.d_scores.data_ptr(), max_clusters=self.cap,
+                                      flags=self.args.flags | self.capi.UIS_FLAG_PROFILE)['stats']
+    n_steps = prof['n_steps']
+    resident = prof['kernel_launches']['select'] == 0 and prof['kernel_launches']['gru'] == 1
+    fpf = flops_per_frame(cfg)
+    ceiling = PEAK_F32_MFMA_TFLOPS * 1e12 / fpf
+    bps = bytes_per_step(cfg)
+    if resident:
+      # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
+      # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
+      # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
+      n_cu = (self.torch.cuda.get_device_properties(self.d_frames.device).multi_processor_count
+              if self.d_frames.is_cuda else 256)
+      ncl = max(n_cu // 32, 1)
+      if self.n_utt > n_cu - n_cu % 32 and not self.args.flags & 0x200:
+        kernel = 'k_decode_big'       # more utterances than workgroups: a wave per row tile
+      elif (self.n_utt <= 8 * ncl and dim <= 256 and self.beam <= 16 and not self.args.flags & 0x800):
+        kernel = 'k_decode_rs'        # at most 8 utterances per XCD: the replicated select
+      else:
+        kernel = 'k_decode_resident'
+      kclass = 'gru'
+      per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
+      flop_algo = per_row * prof['rnn_rows_nodedup']
+      flop_exec = per_row * prof['rnn_rows']
+      algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) + self.n_utt * n_steps * bps)
+    else:
+      # the class that takes the most device time; for the GRU GEMM one launch = one step's
+      # hidden-side matvecs (3H x H MACs per surviving hypothesis / prefix)
+      kclass = max(('gru', 'head1', 'head2', 'select', 'expand', 'upper_in'),
+                   key=lambda k: prof['kernel_ms'][k])
+      level = self.beam
+      for j in range(1, self.look):
+        level = min(level * (self.cap + j), 32768)
+      cap_rows = 0 if self.args.flags & 0x200 else self.n_utt * (self.beam if self.look == 1 else level)
+      fam = 'k_wt' if hid in (256, 512) and cap_rows > 1280 else ('k_big' if cap_rows > 2048 else 'k_dense')
+      kernel = {'gru': fam + '_gru', 'head1': fam + '_head1' if fam != 'k_wt' else 'k_wt_head<1>',
+                'head2': fam + '_head2' if fam != 'k_wt' else 'k_wt_head<2>',
+                'select': 'k_select_fast', 'expand': 'k_window', 'upper_in': 'k_dense_upper_in'}[kclass]
+      launches_gru = max(prof['kernel_launches']['gru'], 1)
+      per_row = {'gru': 2.0 * 3 * hid * hid, 'head1': 2.0 * hid * hid, 'head2': 2.0 * dim * hid}.get(kclass, 0.0)
+      flop_algo = per_row * prof['rnn_rows_nodedup'] / launches_gru
+      flop_exec = per_row * prof['rnn_rows'] / launches_gru
+      algo_bytes = int(4 * 3 * hid * hid + prof['rnn_rows_nodedup'] / launches_gru * 4 * (hid + 3 * hid + hid))
+    k_launches = max(prof['kernel_launches'][kclass], 1)
+    avg_us = 1e3 * prof['kernel_ms'][kclass] / k_launches
+    effective = flop_algo / (avg_us * 1e-6) / 1e12 if flop_algo else 0.0
+    executed = flop_exec / (avg_us * 1e-6) / 1e12 if flop_exec else 0.0
+    return {
+        'bound': 'mfma', 'kernel': kernel,
+        'decode_path': 'one launch ({})'.format(kernel) if resident else 'launch per step',
+        # what the silicon did: the rows the MFMA pipes executed (after row de-duplication)
+        'achieved': round(executed, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(min(executed / PEAK_F32_MFMA_TFLOPS, 1.0), 4),
+        # the algorithmic rows (one CoreRNN step per surviving hypothesis, SURVEY.md 8d) over the same
+        # time: de-duplication's credit (8 f1); may exceed 1
+        'effective': {'tflops': round(effective, 3), 'frac': round(effective / PEAK_F32_MFMA_TFLOPS, 4)},
+        'traffic': committed_traffic(kernel),
+        'avg_launch_us': round(avg_us, 3), 'launches': k_launches,
+        'algorithmic_bytes_per_launch': algo_bytes,
+        'rows_per_step_algorithmic': round(prof['rnn_rows_nodedup'] / max(n_steps, 1), 1),
+        'rows_per_step_executed': round(prof['rnn_rows'] / max(n_steps, 1), 1),
+        'ceiling_frames_per_s_fp32': round(ceiling, 0),
+        'path_frac_fp32': round(value_rank / ceiling, 4),
+        # SURVEY.md 8(d) asks for both fractions; HBM is not the binding one (~300 FLOP/B)
+        'path_frac_hbm': round(value_rank * self.tau * bps / (PEAK_HBM_GBS * 1e9), 4),
+        'kernel_ms_profile_pass': {k: round(v, 3) for k, v in prof['kernel_ms'].items()},
+    }
+
+  def oracle_check(self, sample, sample_frames, threads):
+    """The CPU oracle on `sample` utterances cut to `sample_frames`: (seconds, labels identical)."""
+    from oracle import oracle  # pylint: disable=import-outside-toplevel
+    sample_seqs = [s[:sample_frames] for s in self.seqs[:sample]]
+    t0 = time.perf_counter()
+    ref = oracle.decode(self.params, sample_seqs, self.beam, self.look, self.tau, n_threads=threads)
+    cpu_s = time.perf_counter() - t0
+    whole = all(s.shape[0] <= sample_frames for s in self.seqs[:sample])
+    if whole:
+      got = self.d_labels.cpu().numpy()
+      parity = all(np.array_equal(got[self.offsets[u]:self.offsets[u + 1]], ref['labels'][u]) for u in range(sample))
+    else:  # truncated utterances: decode exactly those on the GPU for the comparison
+      lens = np.array([s.shape[0] for s in sample_seqs], dtype=np.int64)
+      offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+      chk = self.decoder.decode(np.concatenate(sample_seqs).astype(np.float32), offs,
+                                self.beam, self.look, self.tau, max_clusters=self.cap)
+      parity = all(np.array_equal(chk['labels'][offs[u]:offs[u + 1]], ref['labels'][u]) for u in range(sample))
+    return cpu_s, bool(parity), int(sum(s.shape[0] for s in sample_seqs))
+
+
+def run_extra_config(index, args, rank, dev, dev_index, sync_fn):
+  """A few passes of another BASELINE config at its stated size: rate, frac, parity."""
+  cfg = dict(CONFIGS[index])
+  w = Workload(cfg, args, rank, 1, dev, dev_index)
+  passes, setup_ms = w.setup(sync_fn)
+  w.timing = True
+  steps = 3
+  el = timed_region(lambda: w.decode_once(args.flags), sync_fn, steps, 1)
+  rate = w.rank_frames * steps / el
+  roof = w.roofline(rate)
+  # parity against the oracle on a sample it finishes in seconds (wide beams: truncated utterances)
+  threads = min(os.cpu_count() or 1, 64)
+  sample = min(w.n_utt, 4 if w.look > 1 else 8)
+  cut = 60 if w.look > 1 else min(cfg['frames'], 250)
+  cpu_s, parity, _ = w.oracle_check(sample, cut, threads)
+  out = {'config': index, 'workload': cfg['workload'], 'value': round(rate, 1), 'unit': 'frames/s',
+         'ms_per_step': round(1e3 * el / steps, 3), 'steps': steps, 'setup_passes': passes,
+         'setup_ms': round(setup_ms, 1), 'max_clusters': w.cap, 'model': cfg['model'],
+         'kernel': roof['kernel'], 'frac': roof['frac'], 'effective_frac': roof['effective']['frac'],
+         'avg_launch_us': roof['avg_launch_us'], 'path_frac_fp32': roof['path_frac_fp32'],
+         'parity': 'labels identical to oracle: {} ({} utterances x {} frames, {:.1f}s on {} threads)'.format(
+             parity, sample, cut, cpu_s, threads)}
+  del w
+  return out
+
+
 def main(argv=None):
   args = parse(argv)
   env_world = os.environ.get('WORLD_SIZE')
@@ -230,9 +449,10 @@ def main(argv=None):
     raise SystemExit('bench.py --gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+  rank_cores = pin_rank_to_cores(local_rank, local_world)
 
   import torch  # device memory + torch.distributed only
-  from uisrnn_amd import _capi, synth
 
   cfg = dict(CONFIGS[args.config])
   if args.utterances is not None:
@@ -244,19 +464,28 @@ def main(argv=None):
   if args.utterances is not None or args.frames is not None or args.beam_size is not None:
     cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}]'.format(
         cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'])
+  if args.ragged:
+    cfg['workload'] += ' [ragged: lengths uniform in [frames / 2, frames], longest-first sharding]'
   big = cfg['utterances_per_gpu'] * cfg['frames'] > 200_000 or cfg['look_ahead'] > 1
   steps = args.steps if args.steps is not None else (3 if big else 10)
-  # five warm-up passes: the decoder tries its control-word placements on passes 2-5 of a shape
-  warmup = args.warmup if args.warmup is not None else (5 if cfg['utterances_per_gpu'] * cfg['frames'] <= 2_000_000 else 1)
+  warmup = args.warmup if args.warmup is not None else (3 if cfg['utterances_per_gpu'] * cfg['frames'] <= 2_000_000 else 1)
 
-  n_dev = torch.cuda.device_count()
-  if n_dev < 1:
-    raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
-  if local_rank >= n_dev:
-    raise RuntimeError('rank {} (local rank {}) has no GPU of its own: {} HIP device(s) visible, '
-                       'one rank per GPU is required'.format(rank, local_rank, n_dev))
-  dev_index = local_rank
-  torch.cuda.set_device(dev_index)
+  on_gpu = args.device == 'cuda'
+  if on_gpu:
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+      raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
+    if local_rank >= n_dev:
+      raise RuntimeError('rank {} (local rank {}) has no GPU of its own: {} HIP device(s) visible, '
+                         'one rank per GPU is required'.format(rank, local_rank, n_dev))
+    dev_index = local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    sync_fn = torch.cuda.synchronize
+  else:
+    if args.backend != 'gloo':
+      raise SystemExit('--device cpu is test plumbing: it needs --backend gloo and a stand-in decoder')
+    dev_index, dev, sync_fn = 0, torch.device('cpu'), (lambda: None)
   use_dist = world > 1 or args.force_dist
   if use_dist:
     import torch.distributed as dist
@@ -269,179 +498,98 @@ def main(argv=None):
       dist.init_process_group('gloo', rank=rank, world_size=world)
   else:
     dist = None
-  dev = torch.device('cuda', dev_index)
 
-  dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
-  n_utt, n_frames = cfg['utterances_per_gpu'], cfg['frames']
-  beam, look, tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
-  params, model_note = load_model(cfg, args.model)
-  cfg['model'] = model_note
-  seqs, _ = synth.make_utterances(10_000 + rank * n_utt, n_utt, n_frames, dim)
-  frames = np.concatenate(seqs, axis=0).astype(np.float32)
-  offsets = np.arange(n_utt + 1, dtype=np.int64) * n_frames
-  total_frames = n_utt * n_frames
-
-  decoder = _capi.Decoder(params, device=dev_index)
-  d_frames = torch.from_numpy(frames).to(dev)
-  d_labels = torch.empty(total_frames, dtype=torch.int32, device=dev)
-  d_scores = torch.empty(n_utt, dtype=torch.float32, device=dev)
+  w = Workload(cfg, args, rank, world, dev, dev_index)
+  tau = w.tau
   gather_dev = dev if args.backend == 'nccl' else torch.device('cpu')
-  gathered = (torch.empty(world * total_frames, dtype=torch.int32, device=gather_dev)
-              if use_dist else None)
-  state = {'last': None, 'cap': cfg['max_clusters']}
-
-  def decode_once(flags):
-    while True:
-      out = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
-                                  d_labels.data_ptr(), d_scores.data_ptr(),
-                                  max_clusters=state['cap'], flags=flags,
-                                  n_streams=args.streams)
-      if out['status'] == 0:
-        return out
-      # a surviving hypothesis needed more clusters than the tables hold: the Python host's
-      # policy (uisrnn_amd/uisrnn.py) is to decode again with twice the room; only warm-up
-      # passes may do that -- a timed pass that retried would be counted as failed
-      if state.get('timing'):
-        raise RuntimeError('decode hit the cluster cap inside the timed region')
-      state['cap'] *= 2
+  # one padded label buffer per rank: with --ragged the ranks hold different numbers of frames
+  width = w.rank_frames
+  if use_dist:
+    wt = torch.tensor([width], dtype=torch.int64, device=gather_dev)
+    dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+    width = int(wt.item())
+    if w.d_labels.numel() < width:
+      w.d_labels = torch.empty(width, dtype=torch.int32, device=dev)
+  gathered = (torch.empty(world * max(width, 1), dtype=torch.int32, device=gather_dev) if use_dist else None)
 
   def one_step():
-    state['last'] = decode_once(args.flags)
+    w.decode_once(args.flags)
     if use_dist:  # the final gather: the only collective of the path (RCCL over xGMI)
-      dist.all_gather_into_tensor(
-          gathered, d_labels if args.backend == 'nccl' else d_labels.cpu())
+      src = w.d_labels[:max(width, 1)]
+      dist.all_gather_into_tensor(gathered, src if args.backend == 'nccl' else src.cpu())
 
-  # set-up passes before anything is timed: the first settles the cluster cap, the next four are
-  # the decoder's trials of its control-word placement for this shape, so
-  # that they stay outside the clock whatever --warmup says
-  for _ in range(5 if total_frames <= 2_000_000 else 1):
-    decode_once(args.flags)
-  state['timing'] = True
-  elapsed = timed_region(one_step, torch.cuda.synchronize, steps, warmup, dist, gather_dev)
+  setup_passes, setup_ms = w.setup(sync_fn)
+  w.timing = True
+  per_rank = []
+  elapsed = timed_region(one_step, sync_fn, steps, warmup, dist, gather_dev, per_rank)
   ms_per_step = 1e3 * elapsed / max(steps, 1)
-  value = world * total_frames * steps / elapsed
-  stats = state['last']['stats'] if state['last'] else {}
+  value = w.job_frames * steps / elapsed
+  stats = w.last['stats'] if w.last else {}
 
   result = None
   if rank == 0:
-    # ---- PCIe-inclusive rate: pinned host frames in, labels out, same passes
-    host_rate = None
-    if not args.no_host_buffers:
-      pin_frames = torch.from_numpy(frames).pin_memory()
-      pin_labels = torch.empty(total_frames, dtype=torch.int32).pin_memory()
-      pin_scores = torch.empty(n_utt, dtype=torch.float32).pin_memory()
+    # ---- PCIe-inclusive rates: host buffers in, labels out, same passes
+    host_rate = f64_rate = None
+    if not args.no_host_buffers and on_gpu and w.n_utt and world == 1:
+      pin_frames = torch.from_numpy(w.frames).pin_memory()
+      pin_labels = torch.empty(w.rank_frames, dtype=torch.int32).pin_memory()
+      pin_scores = torch.empty(w.n_utt, dtype=torch.float32).pin_memory()
       def host_step():
-        rc = decoder.decode_host(pin_frames.data_ptr(), offsets, beam, look, tau,
-                                 pin_labels.data_ptr(), pin_scores.data_ptr(),
-                                 max_clusters=state['cap'], flags=args.flags)
+        rc = w.decoder.decode_host(pin_frames.data_ptr(), w.offsets, w.beam, w.look, tau,
+                                   pin_labels.data_ptr(), pin_scores.data_ptr(),
+                                   max_clusters=w.cap, flags=args.flags)
         if rc['status'] != 0:
           raise RuntimeError('host-buffer decode hit the cluster cap')
-      el = timed_region(host_step, torch.cuda.synchronize, max(steps // 2, 1), 1)
-      host_rate = total_frames * max(steps // 2, 1) / el
-      if not np.array_equal(pin_labels.numpy(), d_labels.cpu().numpy()):
+      n_host = max(steps // 2, 1)
+      el = timed_region(host_step, sync_fn, n_host, 1)
+      host_rate = w.rank_frames * n_host / el
+      if not np.array_equal(pin_labels.numpy(), w.d_labels[:w.rank_frames].cpu().numpy()):
         raise RuntimeError('host-buffer decode and device-buffer decode disagree')
+      # ... and the entry UISRNN.predict uses: the list of float64 arrays as the caller holds them
+      f64_out = {}
+      def f64_step():
+        f64_out['r'] = w.decoder.decode_f64(w.seqs, w.beam, w.look, tau, max_clusters=w.cap, flags=args.flags)
+        if f64_out['r']['status'] != 0:
+          raise RuntimeError('float64-list decode hit the cluster cap')
+      el = timed_region(f64_step, sync_fn, n_host, 1)
+      f64_rate = w.rank_frames * n_host / el
+      if not np.array_equal(f64_out['r']['labels'], pin_labels.numpy()):
+        raise RuntimeError('float64-list decode and host-buffer decode disagree')
 
-    # ---- roofline of the dominant kernel: HIP events around every launch
-    prof = decoder.decode_device(d_frames.data_ptr(), offsets, beam, look, tau,
-                                 d_labels.data_ptr(), d_scores.data_ptr(),
-                                 max_clusters=state['cap'],
-                                 flags=args.flags | _capi.UIS_FLAG_PROFILE)['stats']
-    n_steps = prof['n_steps']
-    resident = prof['kernel_launches']['select'] == 0 and prof['kernel_launches']['gru'] == 1
-    rows_algo = prof['rnn_rows_nodedup'] / max(n_steps, 1)
-    rows_exec = prof['rnn_rows'] / max(n_steps, 1)
-    fpf = flops_per_frame(cfg)
-    ceiling = PEAK_F32_MFMA_TFLOPS * 1e12 / fpf
-    bps = bytes_per_step(cfg)
-    if resident:
-      # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
-      # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
-      # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
-      # (more utterances than workgroups -- 32 per XCD-sized cluster of CUs -- run the variant whose
-      # dense stages give a wave a whole row tile, unless flag 0x200 keeps the split-K passes)
-      n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-      kernel = 'k_decode_big' if n_utt > n_cu - n_cu % 32 and not args.flags & 0x200 else 'k_decode_resident'
-      kclass = 'gru'
-      per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
-      flop_per_launch = per_row * prof['rnn_rows_nodedup']
-      flop_exec = per_row * prof['rnn_rows']
-      algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) + n_utt * n_steps * bps)
-    else:
-      # the class that takes the most device time; for the GRU GEMM one launch = one step's
-      # hidden-side matvecs (3H x H MACs per surviving hypothesis / prefix)
-      kclass = max(('gru', 'head1', 'head2', 'select', 'expand', 'upper_in'),
-                   key=lambda k: prof['kernel_ms'][k])
-      # which family of dense kernels the library picks (uis_decoder.hip, launch_rnn): a wave per row
-      # tile above a row capacity of 1280 (weight slice in LDS, hidden size 256 / 512) or 2048 (others)
-      level = beam
-      for j in range(1, look):
-        level = min(level * (state['cap'] + j), 32768)
-      cap_rows = 0 if args.flags & 0x200 else n_utt * (beam if look == 1 else level)
-      fam = 'k_wt' if hid in (256, 512) and cap_rows > 1280 else ('k_big' if cap_rows > 2048 else 'k_dense')
-      kernel = {'gru': fam + '_gru', 'head1': fam + '_head1' if fam != 'k_wt' else 'k_wt_head<1>',
-                'head2': fam + '_head2' if fam != 'k_wt' else 'k_wt_head<2>',
-                'select': 'k_select_fast', 'expand': 'k_window', 'upper_in': 'k_dense_upper_in'}[kclass]
-      launches_gru = max(prof['kernel_launches']['gru'], 1)
-      rows_per_launch = prof['rnn_rows_nodedup'] / launches_gru
-      per_row = {'gru': 2.0 * 3 * hid * hid, 'head1': 2.0 * hid * hid, 'head2': 2.0 * dim * hid}.get(kclass, 0.0)
-      flop_per_launch = per_row * rows_per_launch
-      flop_exec = per_row * prof['rnn_rows'] / launches_gru
-      algo_bytes = int(4 * 3 * hid * hid + rows_per_launch * 4 * (hid + 3 * hid + hid))
-    k_launches = max(prof['kernel_launches'][kclass], 1)
-    avg_us = 1e3 * prof['kernel_ms'][kclass] / k_launches
-    achieved = flop_per_launch / (avg_us * 1e-6) / 1e12 if flop_per_launch else 0.0
-    executed = flop_exec / (avg_us * 1e-6) / 1e12 if flop_exec else 0.0
-    roofline = {
-        'bound': 'mfma', 'kernel': kernel,
-        'decode_path': 'one launch ({})'.format(kernel) if resident else 'launch per step',
-        'achieved': round(achieved, 3),
-        'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-        'traffic': committed_traffic(kernel),
-        'avg_launch_us': round(avg_us, 3), 'launches': k_launches,
-        'algorithmic_bytes_per_launch': algo_bytes,
-        # `achieved` counts the algorithmic rows (one CoreRNN step per surviving hypothesis,
-        # SURVEY.md 8d); row de-duplication (8 f1) executes fewer -- what the MFMA pipes ran:
-        'executed': {'tflops': round(executed, 3), 'frac': round(executed / PEAK_F32_MFMA_TFLOPS, 4)},
-        'rows_per_step_algorithmic': round(rows_algo, 1),
-        'rows_per_step_executed': round(rows_exec, 1),
-        'ceiling_frames_per_s_fp32': round(ceiling, 0),
-        'path_frac_fp32': round(value / world / ceiling, 4),
-        # SURVEY.md 8(d) asks for both fractions; HBM is not the binding one (~300 FLOP/B)
-        'path_frac_hbm': round(value / world * tau * bps / (PEAK_HBM_GBS * 1e9), 4),
-        'kernel_ms_profile_pass': {k: round(v, 3) for k, v in prof['kernel_ms'].items()},
-    }
+    roofline = w.roofline(value / world)
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # (N > 1: the other ranks would wait at the barrier)
-      from oracle import oracle
       cores = os.cpu_count() or 1
       threads = min(cores, 64)
-      sample = args.cpu_sample or min(n_utt, max(threads, 1))
-      if look > 1:
+      sample = args.cpu_sample or min(w.n_utt, max(threads, 1))
+      if w.look > 1:
         sample = min(sample, 8)
-      sample_frames = n_frames if look == 1 else min(n_frames, 100)
-      sample_seqs = [s[:sample_frames] for s in seqs[:sample]]
-      t0 = time.perf_counter()
-      ref = oracle.decode(params, sample_seqs, beam, look, tau, n_threads=threads)
-      cpu_s = time.perf_counter() - t0
-      if sample_frames == n_frames:
-        got = d_labels.cpu().numpy()
-        parity = all(
-            np.array_equal(got[u * n_frames:(u + 1) * n_frames], ref['labels'][u])
-            for u in range(sample))
-      else:  # truncated utterances: decode exactly those on the GPU for the comparison
-        chk = decoder.decode(np.concatenate(sample_seqs).astype(np.float32),
-                             np.arange(sample + 1, dtype=np.int64) * sample_frames,
-                             beam, look, tau, max_clusters=state['cap'])
-        parity = all(
-            np.array_equal(chk['labels'][u * sample_frames:(u + 1) * sample_frames], ref['labels'][u])
-            for u in range(sample))
-      cpu = {'value': round(sample * sample_frames / cpu_s, 2), 'unit': 'frames/s',
+      sample_frames = cfg['frames'] if w.look == 1 else min(cfg['frames'], 100)
+      cpu_s, parity, n_sample_frames = w.oracle_check(sample, sample_frames, threads)
+      ref = reference_rates() or {}
+      cpu = {'value': round(n_sample_frames / cpu_s, 2), 'unit': 'frames/s',
              'cores': threads, 'kind': 'port',
-             'reference': reference_rates(),
+             # the reference itself (google/uis-rnn cannot travel to this box): measured in the dev
+             # container by tests/golden/make_trained.py wholebox on the same trained model
+             'reference_whole_box_frames_per_s': ref.get('whole_box_frames_per_s'),
+             'reference_one_process_frames_per_s': ref.get('one_process_one_thread_frames_per_s'),
+             'reference_cores': ref.get('cores'),
+             'reference': ref or None,
              'sample': '{} of the {} utterances ({} frames each), {} threads, {:.1f}s; GPU labels '
-                       'identical: {}'.format(sample, n_utt, sample_frames, threads, cpu_s, parity)}
+                       'identical: {}'.format(sample, w.n_utt, sample_frames, threads, cpu_s, parity)}
+    extras = None
+    if (not args.no_extra_configs and world == 1 and on_gpu and args.config == 1 and not args.ragged and
+        args.utterances is None and args.frames is None and args.beam_size is None):
+      first = w.last
+      w_cap = w.cap
+      extras = []
+      for idx in (2, 3, 4):
+        try:
+          extras.append(run_extra_config(idx, args, rank, dev, dev_index, sync_fn))
+        except Exception as e:  # pylint: disable=broad-except
+          extras.append({'config': idx, 'error': '{}: {}'.format(type(e).__name__, e)})
+      w.last, w.cap = first, w_cap
     result = {
         'metric': 'diarization frames/sec (whole node), beam=10, 256-dim',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world,
@@ -450,11 +598,19 @@ def main(argv=None):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic',
         'config': dict(cfg, parallelism='utterance-sharded x{}'.format(world),
-                       max_clusters=state['cap']),
+                       max_clusters=w.cap),
+        'value_definition': 'frame stream and label buffer resident in HBM when the clock starts '
+                            '(uis_decode_device); the PCIe-inclusive rates of the same passes follow',
+        'value_device': round(value, 1),
         'value_host_buffers': round(host_rate, 1) if host_rate else None,
+        'value_predict_f64': round(f64_rate, 1) if f64_rate else None,
+        'setup_passes': setup_passes, 'setup_ms': round(setup_ms, 1),
+        'per_rank_ms': {'min': round(1e3 * min(per_rank) / steps, 3), 'max': round(1e3 * max(per_rank) / steps, 3)},
+        'rank_host_cores': rank_cores,
+        'per_rank_memory_gb': round((w.rank_frames * w.dim * 4 + w.rank_frames * 3 * w.hid * 4) / 1e9, 2),
         'decode_ms_device': round(stats.get('decode_ms', 0.0), 3),
         'n_streams': stats.get('n_streams', 0),
-        'roofline': roofline, 'cpu_baseline': cpu,
+        'roofline': roofline, 'cpu_baseline': cpu, 'extra_configs': extras,
     }
   # the JSON line is the last thing on stdout: whatever native libraries buffered there (RCCL's
   # banner goes through C stdio) is flushed by every rank before rank 0 prints

@@ -60,6 +60,76 @@ def test_timed_region_world_2_gloo(tmp_path):
   assert recs[0]['elapsed'] >= 0.11
 
 
+_MAIN_SCRIPT = textwrap.dedent('''
+    import ctypes, json, os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    from uisrnn_amd import _capi
+
+    class StandInDecoder:
+      """What bench.main needs from _capi.Decoder, without a GPU: labels = the rank."""
+      def __init__(self, params, device=0):
+        self.calls = 0
+      def decode_device(self, d_frames_ptr, offsets, beam_size, look_ahead, test_iteration,
+                        d_labels_ptr, d_scores_ptr, max_clusters=0, flags=0, n_streams=0):
+        n = int(offsets[-1])
+        lab = np.ctypeslib.as_array(ctypes.cast(ctypes.c_void_p(int(d_labels_ptr)),
+                                                ctypes.POINTER(ctypes.c_int32)), shape=(max(n, 1),))
+        lab[:n] = int(os.environ['RANK']) + 7
+        self.calls += 1
+        steps = int(test_iteration) * int(max(np.diff(offsets))) if len(offsets) > 1 else 0
+        rows = steps * (len(offsets) - 1) * 3
+        names = _capi.KERNEL_NAMES
+        return {{'status': 0, 'stats': {{'n_steps': steps, 'decode_ms': 1.0, 'n_streams': 1,
+                 'rnn_rows': rows, 'rnn_rows_nodedup': 2 * rows,
+                 'kernel_ms': {{k: (0.5 if k == 'gru' else 0.0) for k in names}},
+                 'kernel_launches': {{k: (1 if k == 'gru' else 0) for k in names}}}}}}
+    _capi.Decoder = StandInDecoder
+    import bench
+    res = bench.main(['--gpus', '2', '--device', 'cpu', '--backend', 'gloo', '--utterances', '3',
+                      '--frames', '24', '--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--ragged',
+                      '--model', 'tracker'])
+    if int(os.environ['RANK']) == 0:
+      assert res is not None
+    else:
+      assert res is None
+''')
+
+
+def test_bench_main_world_2_gloo_with_a_stand_in_decoder(tmp_path):
+  """bench.main() itself, two ranks over gloo: launch plumbing, per-rank core pinning, ragged
+  utterances dealt by shard_utterances, the padded label gather, the timed region, ONE JSON line
+  from rank 0 with the per-rank spread.  (The decode is a stand-in: no GPU here.)"""
+  script = tmp_path / 'main_rank.py'
+  script.write_text(_MAIN_SCRIPT.format(root=ROOT))
+  import json
+  import socket
+  out = None
+  for attempt in range(3):
+    with socket.socket() as sock:
+      sock.bind(('127.0.0.1', 0))
+      port = sock.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if out.returncode == 0:
+      break
+  assert out.returncode == 0, out.stderr[-3000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1, out.stdout[-2000:]
+  rec = json.loads(lines[0])
+  assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['warmup'] == 1
+  assert rec['scaling'] == 'weak' and rec['unit'] == 'frames/s'
+  assert rec['per_rank_ms']['min'] <= rec['per_rank_ms']['max'] <= rec['ms_per_step'] * 1.5
+  assert rec['setup_passes'] >= 1 and rec['setup_ms'] >= 0.0
+  assert 0.0 <= rec['roofline']['frac'] <= 1.0
+  assert rec['roofline']['effective']['frac'] >= rec['roofline']['frac']
+  assert 'ragged' in rec['config']['workload']
+  # whole-job frames: 6 utterances of 12..24 frames, 2 timed steps
+  assert 6 * 12 * 2 / (rec['ms_per_step'] * 2e-3) <= rec['value'] <= 6 * 24 * 2 / (rec['ms_per_step'] * 2e-3) * 1.01
+
+
 def test_gpus_flag_refuses_to_fold_ranks_onto_one_device():
   """`bench.py --gpus 2` on a box with fewer than 2 GPUs must fail loudly, not run one rank."""
   env = dict(os.environ)

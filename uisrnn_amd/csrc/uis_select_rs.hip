@@ -841,9 +841,14 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     RSTAMP(2);
     // arrive; then the select's back part (the next step's tables and masks: nothing anybody waits
     // for, and the wait is idle time for every wave); then wait
+#if defined(UIS_RS_SHADOW_BEFORE)
+    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
+    xcd_arrive(st, cluster, s_ctl);
+#else
     xcd_arrive(st, cluster, s_ctl);
 #if !defined(UIS_RS_BACK_INLINE)
     if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
+#endif
 #endif
     if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
@@ -879,9 +884,14 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     RSTAMP(4);
     // arrive; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
     // its share of every utterance's; visible to all behind the step's last barrier); then wait
+#if defined(UIS_RS_SHADOW_BEFORE)
+    if (has_u && (long)s + 1 < T_w)
+      rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
+#else
     xcd_arrive(st, cluster, s_ctl);
     if (has_u && (long)s + 1 < T_w)
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
+#endif
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(5);
 
@@ -940,8 +950,12 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     }
     RSTAMP(6);
     // arrive; then the next step's candidate grid (this wave's own tables: nobody else's data); then wait
+#if defined(UIS_RS_SHADOW_BEFORE)
+    if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
+#else
     xcd_arrive(st, cluster, s_ctl);
     if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
+#endif
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(7);
   }
