@@ -125,6 +125,9 @@ typedef struct uis_decode_opts {
                                     single wave); A/B switch, results are bit-identical either way */
 #define UIS_FLAG_REPLICATED_SELECT 0x1000u /* one-launch decode: REQUIRE-if-applicable the replicated select
                                     (k_decode_rs) where it is not the default (A/B switch)         */
+#define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook (look_ahead 1): keep every candidate score of every step --
+                                    the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
+                                    uis_debug_scores(); costs device memory and one store per candidate */
 #define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
                                     a wrong XCD, as if the (observed, not promised) workgroup
                                     placement had changed.  The call must then fall back to the
@@ -230,6 +233,17 @@ int32_t uis_decode_device(uis_handle* h, const float* d_frames, const int64_t* o
  *   beam_scores_out : host float32 [n_utt * beam_size] or NULL (+inf padded)
  */
 int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out);
+
+/*
+ * After a decode with UIS_FLAG_DEBUG_SCORES (look_ahead 1): the candidate scores of every step,
+ *   scores_out[((step * n_utt + u) * beam_size + b) * (max_clusters + 1) + c]
+ * = what _calculate_score (uisrnn/uisrnn.py:455-477) returns for hypothesis b of utterance u at
+ * decode step `step` (0 .. test_iteration * longest utterance - 1) at cluster c, +inf where the
+ * reference's padded score_set (uisrnn.py:534-545) holds +inf: clusters past K_b, hypotheses past
+ * the live beam, steps past the utterance's end.  `capacity` = floats available at scores_out;
+ * returns UIS_ERR_INVALID_ARG when the last decode kept none or the buffer is too small.
+ */
+int32_t uis_debug_scores(uis_handle* h, float* scores_out, int64_t capacity);
 
 /*
  * Read back the per-model constants computed at uis_create with the decode

@@ -107,6 +107,26 @@ def decode(params, sequences, beam_size=10, look_ahead=1, test_iteration=2,
   }
 
 
+def candidate_scores(params, sequence, beam_size, look_ahead, test_iteration, cmax):
+  """Every candidate score of every window of ONE utterance: float32
+  [windows, beam_size] + [cmax] * look_ahead, +inf where the reference's padded score_set
+  (uisrnn/uisrnn.py:534-545) holds +inf."""
+  frames, _ = pack([sequence])
+  desc, keep = _capi.make_desc(params)
+  opts = _capi.make_opts(beam_size, look_ahead, test_iteration)
+  total = test_iteration * frames.shape[0]
+  n_win = (total + look_ahead - 1) // look_ahead
+  out = np.empty([n_win, beam_size] + [cmax] * look_ahead, dtype=np.float32)
+  fn = lib().uis_oracle_candidate_scores
+  fn.restype = ctypes.c_int32
+  rc = fn(ctypes.byref(desc), _fp(frames), ctypes.c_int64(frames.shape[0]), ctypes.byref(opts),
+          ctypes.c_int32(cmax), _fp(out), None)
+  del keep
+  if rc != 0:
+    raise RuntimeError('uis_oracle_candidate_scores failed: {}'.format(rc))
+  return out
+
+
 def rnn_step(params, x, h_in):
   """CoreRNN.forward restatement: x [D], h_in [depth, H] -> (mean, h_out)."""
   desc, keep = _capi.make_desc(params)

@@ -333,8 +333,12 @@ typedef struct {
 } oinfo;
 
 /* predict_single (uisrnn/uisrnn.py:479-562) for one utterance. */
+/* dbg (may be NULL): every candidate's score, dense --
+   dbg[((win * B + beam) * Cmax + c_1) * Cmax + c_2 ...] with Lw factors of Cmax per window
+   (stride Cmax^L per hypothesis), the caller pre-fills it with +inf: the arrays _calculate_score
+   returns (uisrnn.py:455-477) inside predict_single's padded score_set (uisrnn.py:534-545). */
 static void decode_one(const omodel* m, const float* seq, long N, int B, int L, int tau,
-                       int32_t* labels, float* beam_scores, oinfo* info) {
+                       int32_t* labels, float* beam_scores, oinfo* info, float* dbg, int Cmax) {
   octx cx; cx.m = m; cx.rnn_calls = 0;
   cx.term = (float*)malloc(m->D * sizeof(float));
   cx.scratch = (float*)malloc(7 * m->H * sizeof(float));
@@ -361,6 +365,18 @@ static void decode_one(const omodel* m, const float* seq, long N, int B, int L, 
     int path[8];
     for (int b = 0; b < nb; ++b) enumerate(&cx, &beam[b], xs, Lw, 0, b, path, &cv);
     info->candidates += cv.n;
+    if (dbg) {
+      long stride = 1;
+      for (int j = 0; j < L; ++j) stride *= Cmax;
+      for (long i = 0; i < cv.n; ++i) {
+        const cand* cd = &cv.v[i];
+        long flat = 0;
+        int ok = 1;
+        for (int j = 0; j < Lw; ++j) { if (cd->path[j] >= Cmax) ok = 0; flat = flat * Cmax + cd->path[j]; }
+        for (int j = Lw; j < L; ++j) flat *= Cmax; /* a ragged last window: the trailing indices stay 0 */
+        if (ok) dbg[(win * B + cd->beam) * stride + flat] = cd->score;
+      }
+    }
     qsort(cv.v, cv.n, sizeof(cand), cand_cmp);
     long n_fin = 0;
     while (n_fin < cv.n && uis_isfinite(cv.v[n_fin].score)) ++n_fin; /* non-finite sort last */
@@ -429,7 +445,7 @@ static void* worker(void* arg) {
     long N = (long)(jb->offsets[u + 1] - jb->offsets[u]);
     oinfo info;
     decode_one(jb->m, jb->frames + (size_t)jb->offsets[u] * jb->m->D, N, jb->B, jb->L, jb->tau,
-               jb->labels + jb->offsets[u], jb->beam_scores ? jb->beam_scores + (size_t)u * jb->B : NULL, &info);
+               jb->labels + jb->offsets[u], jb->beam_scores ? jb->beam_scores + (size_t)u * jb->B : NULL, &info, NULL, 0);
     if (jb->scores) jb->scores[u] = info.best_score;
     if (jb->margins) jb->margins[u] = info.min_rel_margin;
     if (jb->max_clusters) jb->max_clusters[u] = info.max_clusters;
@@ -480,6 +496,27 @@ ORACLE_EXPORT int32_t uis_oracle_decode(const uis_model_desc* desc, const float*
 }
 
 ORACLE_EXPORT int32_t uis_oracle_numerics_version(void) { return UIS_NUMERICS_VERSION; }
+
+/*
+ * One utterance, with every candidate score kept: scores_out is
+ * [windows][beam_size][Cmax]^look_ahead floats (see decode_one), pre-filled with +inf here.
+ */
+ORACLE_EXPORT int32_t uis_oracle_candidate_scores(const uis_model_desc* desc, const float* frames, int64_t n_frames,
+                                                  const uis_decode_opts* opts, int32_t Cmax, float* scores_out,
+                                                  int32_t* labels_out) {
+  if (!desc || !opts || !scores_out || Cmax < 1) return UIS_ERR_INVALID_ARG;
+  omodel* m = model_build(desc);
+  const int B = opts->beam_size, L = opts->look_ahead, tau = opts->test_iteration;
+  long T = (long)tau * n_frames, n_win = (T + L - 1) / L, stride = 1;
+  for (int j = 0; j < L; ++j) stride *= Cmax;
+  for (long i = 0; i < n_win * B * stride; ++i) scores_out[i] = INFINITY;
+  oinfo info;
+  int32_t* lab = labels_out ? labels_out : (int32_t*)malloc((size_t)(n_frames ? n_frames : 1) * sizeof(int32_t));
+  decode_one(m, frames, n_frames, B, L, tau, lab, NULL, &info, scores_out, Cmax);
+  if (!labels_out) free(lab);
+  model_free(m);
+  return UIS_OK;
+}
 
 /* Unit-level entry points so tests can pin single functions against the reference. */
 

@@ -18,7 +18,7 @@ SEEDED_CASES = {
 def case_names():
   """Fixtures of make_golden.py (random / closed-form weights); trained_* are load_trained's."""
   return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                if f.endswith('.npz') and not f.startswith('trained_'))
+                if f.endswith('.npz') and not f.startswith(('trained_', 'fn_')))  # fn_*: make_scores.py
 
 
 TRAINED_CASES = {

@@ -100,3 +100,17 @@ def test_predict_and_evaluate_keeps_labels_on_the_device(oracle_lib):
   off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
   matched = model._get_decoder().eval_matched_device(flat_p.data_ptr(), flat_t.data_ptr(), off)
   assert [m / n for m, n in zip(matched.tolist(), lengths)] == acc
+
+
+def test_recorded_reference_accuracies(decoder):
+  """k_eval pinned to the reference itself: 203 label-sequence pairs whose accuracies
+  google/uis-rnn's evals.compute_sequence_match_accuracy (uisrnn/evals.py:40-73) returned in the
+  dev container (tests/golden/make_scores.py); identical float64 values."""
+  data = np.load(golden_util.GOLDEN_DIR + '/fn_evals.npz')
+  seqs1, seqs2, pos = [], [], 0
+  for n in data['lens']:
+    seqs1.append(data['a'][pos:pos + n].tolist())
+    seqs2.append(data['b'][pos:pos + n].tolist())
+    pos += n
+  got = evals.sequence_match_accuracies_device(decoder, seqs1, seqs2)
+  assert got == data['accuracy'].tolist()

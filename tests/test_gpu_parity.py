@@ -579,3 +579,37 @@ def test_empty_inputs_through_the_c_abi():
     with pytest.raises(_capi.HipLibraryError):
       dec.decode(np.zeros((2, 256), np.float32), np.array([0, 2], np.int64), **args)
   assert lib.uis_last_error()
+
+
+def test_calculate_score_arrays_on_the_device(oracle_lib):
+  """The device select's FULL candidate arrays (UIS_FLAG_DEBUG_SCORES) against what the
+  reference's _calculate_score returned (uisrnn/uisrnn.py:455-477; tests/golden/fn_scores.npz) and,
+  bit for bit, against the oracle's: every path that scores look_ahead-1 candidates."""
+  data = np.load(golden_util.GOLDEN_DIR + '/fn_scores.npz')
+  checked = 0
+  for i in range(int(data['n_cases'])):
+    name = str(data['case_{}'.format(i)][0])
+    utt, keep, beam, look, tau, cmax = (int(v) for v in data['cfg_{}'.format(i)])
+    if look != 1:
+      continue
+    ref = data['scores_{}'.format(i)]
+    case = golden_util.load_case(name)
+    seq = np.asarray(case['seqs'][utt], dtype=np.float64)[:keep]
+    ora = oracle_lib.candidate_scores(case['params'], seq, beam, look, tau, cmax)
+    dec = _capi.Decoder(case['params'])
+    frames, offsets = oracle_lib.pack([seq])
+    kmax = cmax - 1
+    paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_OWNER_SELECT,
+             _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_GENERIC_SELECT]
+    for fl in paths:
+      out = dec.decode(frames, offsets, beam, look, tau, max_clusters=kmax,
+                       flags=fl | _capi.UIS_FLAG_DEBUG_SCORES)
+      assert out['status'] == 0
+      got = dec.debug_scores(tau * keep, 1, beam, kmax)[:, 0]
+      assert got.shape == ref.shape
+      assert np.array_equal(_bits(got), _bits(ora)), (name, fl)
+      assert np.array_equal(np.isinf(got), np.isinf(ref))
+      fin = np.isfinite(ref)
+      np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-4)
+      checked += 1
+  assert checked >= 12

@@ -232,3 +232,43 @@ def test_reference_probes_at_the_edges(oracle_lib):
   # (numpy sorts NaN behind inf, trim_zeros does not drop it) and returns labels; here the
   # beam is empty
   assert 'labels' in probes['nan_last_frame']
+
+
+def _score_cases():
+  data = np.load(golden_util.GOLDEN_DIR + '/fn_scores.npz')
+  for i in range(int(data['n_cases'])):
+    name = str(data['case_{}'.format(i)][0])
+    utt, keep, beam, look, tau, cmax = (int(v) for v in data['cfg_{}'.format(i)])
+    yield name, utt, keep, beam, look, tau, cmax, data['scores_{}'.format(i)], data['labels_{}'.format(i)]
+
+
+def test_calculate_score_arrays_match_reference(oracle_lib):
+  """UISRNN._calculate_score (uisrnn/uisrnn.py:455-477), array by array: every candidate score of
+  every window as the reference returned it (tests/golden/make_scores.py), +inf padding included --
+  not only the survivors' scores."""
+  n_states = 0
+  for name, utt, keep, beam, look, tau, cmax, ref, ref_labels in _score_cases():
+    case = golden_util.load_case(name)
+    seq = np.asarray(case['seqs'][utt], dtype=np.float64)[:keep]
+    got = oracle_lib.candidate_scores(case['params'], seq, beam, look, tau, cmax)
+    assert got.shape == ref.shape
+    assert np.array_equal(np.isinf(got), np.isinf(ref)), (name, 'where the +inf padding sits')
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=RTOL)
+    out = oracle_lib.decode(case['params'], [seq], beam, look, tau)
+    assert np.array_equal(out['labels'][0], ref_labels)
+    n_states += int(np.isfinite(ref.reshape(ref.shape[0], ref.shape[1], -1)).any(axis=2).sum())
+  assert n_states >= 20 * 5
+
+
+def test_sequence_match_accuracy_matches_reference():
+  """evals.compute_sequence_match_accuracy (uisrnn/evals.py:40-73) on 203 recorded pairs: the host
+  mirror gives the reference's float64 accuracies exactly."""
+  from uisrnn_amd import evals
+  data = np.load(golden_util.GOLDEN_DIR + '/fn_evals.npz')
+  pos = 0
+  for n, acc in zip(data['lens'], data['accuracy']):
+    a = data['a'][pos:pos + n].tolist()
+    b = data['b'][pos:pos + n].tolist()
+    pos += n
+    assert evals.compute_sequence_match_accuracy(a, b) == acc

@@ -36,6 +36,7 @@ UIS_FLAG_SMALL_TILES = 0x200
 UIS_FLAG_PERSISTENT = 0x400
 UIS_FLAG_OWNER_SELECT = 0x800
 UIS_FLAG_REPLICATED_SELECT = 0x1000
+UIS_FLAG_DEBUG_SCORES = 0x2000
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
@@ -233,6 +234,8 @@ def load_library(path=None):
       i32p, _fp, ctypes.POINTER(Stats)]
   lib.uis_last_decode_info.restype = i32
   lib.uis_last_decode_info.argtypes = [ctypes.c_void_p, i32p, _fp]
+  lib.uis_debug_scores.restype = i32
+  lib.uis_debug_scores.argtypes = [ctypes.c_void_p, _fp, ctypes.c_int64]
   lib.uis_model_constants.restype = i32
   lib.uis_model_constants.argtypes = [ctypes.c_void_p, _fp, _fp]
   lib.uis_rnn_step.restype = i32
@@ -263,7 +266,7 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
-    'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info',
+    'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info', 'uis_debug_scores',
     'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',
     'uis_stream_labels', 'uis_stream_end', 'uis_eval_accuracy', 'uis_eval_accuracy_device',
     'uis_eval_last_decode', 'uis_host_alloc', 'uis_host_free', 'uis_last_error')
@@ -413,6 +416,14 @@ class Decoder:
     out['overflow'] = overflow
     if want_beam_scores:
       out['beam_scores'] = beam_scores
+    return out
+
+  def debug_scores(self, n_steps, n_utt, beam_size, max_clusters):
+    """The candidate scores of the last decode (flags included UIS_FLAG_DEBUG_SCORES):
+    float32 [n_steps, n_utt, beam_size, max_clusters + 1], +inf where _calculate_score's padded
+    array (uisrnn/uisrnn.py:534-545) holds +inf."""
+    out = np.empty((int(n_steps), int(n_utt), int(beam_size), int(max_clusters) + 1), dtype=np.float32)
+    self._check(self._lib.uis_debug_scores(self._handle, out.ctypes.data_as(_fp), out.size), 'uis_debug_scores')
     return out
 
   # ---- online decoding (uis_stream_*)

@@ -172,7 +172,8 @@ struct uis_handle {
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
-  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab;
+  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores;
+  size_t dbg_floats = 0;  // what the last decode left in dbg_scores (UIS_FLAG_DEBUG_SCORES)
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
   // uis_decode_f64: the caller's float64 utterances (set for the duration of that call) and the
@@ -574,7 +575,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // MI355X: the device overlaps at most ~2 of these small kernels, so more
   // groups mean more launches, not more throughput -- the default is one group.
   int G = opts->n_streams > 0 ? opts->n_streams : 1;
-  if (profile) G = 1;
+  if (profile || (opts->flags & UIS_FLAG_DEBUG_SCORES)) G = 1;
   G = std::max(1, std::min(std::min(G, UIS_MAX_GROUPS), U));
   while ((int)h->gstreams.size() < G) {
     hipStream_t sgrp;
@@ -663,6 +664,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                   resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
   const size_t mse_tab_bytes = ((size_t)2 * U * S * 4 + 255) & ~(size_t)255;
   if (rs) ENSURE(mse_tab, mse_tab_bytes + (size_t)nclq * rx_stride * 32 * 4);
+  const bool dbg = (opts->flags & UIS_FLAG_DEBUG_SCORES) != 0;
+  if (dbg && L != 1) return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DEBUG_SCORES needs look_ahead 1");
+  const size_t dbg_floats = dbg ? (size_t)maxT * U * B * (Kmax + 1) : 0;
+  if (dbg) ENSURE(dbg_scores, std::max<size_t>(dbg_floats, 1) * 4);
+  h->dbg_floats = 0;
   if (L > 1) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
@@ -729,6 +735,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // never-written row descriptors must still name valid slots (step_tile in uis_kernels.hip)
   HIPCHK(hipMemsetAsync(h->rows.p, 0, (size_t)rows_cap * sizeof(RnnRow), h->stream));
   HIPCHK(hipMemsetAsync(ctl, 0, ctl_words * 4, h->stream));
+  if (dbg && dbg_floats) HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->dbg_scores.p), 0x7f800000, dbg_floats, h->stream));
   if (rs)  // tiles a model does not have stay +0 in every row's partial sums
     HIPCHK(hipMemsetAsync(h->mse_tab.as<char>() + mse_tab_bytes, 0, (size_t)nclq * rx_stride * 32 * 4, h->stream));
   // once per decode: pad (only when D is not a multiple of 16), gi0 = W_ih0 x + b_ih0, mse0.
@@ -812,6 +819,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.a1 = h->a1.as<float>() + (u0 * rows_per_utt + 48 * (size_t)g) * m.Hp;
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
     st.cl_abort = ctl + 16;
+    st.dbg_scores = dbg ? h->dbg_scores.as<float>() + 0 : nullptr;  // (one group: groups would need their own utterance offset)
     if (resident) {
       st.ncl = ncl;
       st.cl_xcc = ctl;
@@ -931,6 +939,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   uint32_t abort_word = 0;
   HIPCHK(hipMemcpyAsync(&abort_word, ctl + 16, 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (dbg) h->dbg_floats = dbg_floats;
   if (abort_word) {
     h->inlaunch_failed = true;
     return fail(UIS_ERR_HIP, abort_word == 2 ? "workgroup cluster not placed on one XCD (in-launch barrier path)"
@@ -1074,7 +1083,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};
@@ -1264,6 +1273,16 @@ UIS_EXPORT int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, fl
   if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
   if (overflow_out && h->last_U) memcpy(overflow_out, h->last_overflow.data(), (size_t)h->last_U * 4);
   if (beam_scores_out && h->last_U) memcpy(beam_scores_out, h->last_beam_scores.data(), (size_t)h->last_U * h->last_B * 4);
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_debug_scores(uis_handle* h, float* scores_out, int64_t capacity) {
+  if (!h || !scores_out) return fail(UIS_ERR_INVALID_ARG, "null argument");
+  if (!h->dbg_floats) return fail(UIS_ERR_INVALID_ARG, "the last decode kept no candidate scores (UIS_FLAG_DEBUG_SCORES)");
+  if (capacity < (int64_t)h->dbg_floats)
+    return fail(UIS_ERR_INVALID_ARG, "uis_debug_scores: " + std::to_string((long long)h->dbg_floats) + " floats needed");
+  if (hipSetDevice(h->device) != hipSuccess) return fail(UIS_ERR_HIP, "hipSetDevice");
+  HIPCHK(hipMemcpy(scores_out, h->dbg_scores.p, h->dbg_floats * 4, hipMemcpyDeviceToHost));
   return UIS_OK;
 }
 

@@ -112,6 +112,8 @@ struct DecodeState {
   // intermediates, one row per rnn row
   float* gi_up;           // [U*B][G]   input-side gates of GRU layers >= 1
   float* a1;              // [U*B][Hp]  relu(linear_mean1)
+  // UIS_FLAG_DEBUG_SCORES: every candidate score of every step, [step][U][B][Kmax + 1] (+inf filled), or null
+  float* dbg_scores;
   // counters (device): [0] rnn rows, [1] rnn rows without dedup, [2] candidates, [3] max K
   unsigned long long* counters;
   // in-launch barrier bookkeeping of k_decode_resident: the XCC id each cluster's rank 0 saw

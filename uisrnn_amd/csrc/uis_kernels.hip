@@ -1032,6 +1032,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
     }
     const float sc = sscore[b] + uis_step_loss(mse, prior);  // float32 accumulate, uisrnn.py:452
     scscore[i] = sc;
+    if (st.dbg_scores) st.dbg_scores[(((size_t)step * U + u) * B + b) * (Kmax + 1) + c] = sc;
     const bool fin = uis_isfinite(sc);
     skey[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
     if (fin) atomicAdd(&smisc[1], 1);
@@ -1491,6 +1492,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
     }
     my_sc = sscore[my_b] + uis_step_loss(mse, prior);
     if (uis_isfinite(my_sc)) my_key = ((unsigned long long)uis_score_key(my_sc) << 32) | (unsigned)tid;
+    if (st.dbg_scores) st.dbg_scores[(((size_t)step * U + u) * B + my_b) * (Kmax + 1) + my_c] = my_sc;
   }
   int keep;
   if (C <= 64) {

@@ -357,6 +357,15 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   score_at(cslot0, pr0, bs0, key0, sc0);
   if (nch > 1) score_at(cslot1, pr1, bs1, key1, sc1);
   if (nch > 2) score_at(cslot2, pr2, bs2, key2, sc2);
+  if (st.dbg_scores) {  // UIS_FLAG_DEBUG_SCORES: the step's _calculate_score arrays
+    auto keep_at = [&](int e, int cslot, float sc) {
+      const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
+      if (cslot != -2) st.dbg_scores[(((size_t)step * U + u) * B + b) * (Kmax + 1) + c] = sc;
+    };
+    keep_at(lane, cslot0, sc0);
+    if (nch > 1) keep_at(lane + 64, cslot1, sc1);
+    if (nch > 2) keep_at(lane + 128, cslot2, sc2);
+  }
   const int nfin = __popcll(__ballot(key0 != UIS_RS_NOKEY)) + __popcll(__ballot(key1 != UIS_RS_NOKEY)) +
                    __popcll(__ballot(key2 != UIS_RS_NOKEY));
   const int keep = nfin < B ? nfin : B;
