@@ -114,3 +114,20 @@ def test_recorded_reference_accuracies(decoder):
     pos += n
   got = evals.sequence_match_accuracies_device(decoder, seqs1, seqs2)
   assert got == data['accuracy'].tolist()
+
+
+def test_predict_and_evaluate_with_more_ids_than_the_device_kernel_takes(oracle_lib):
+  """A ground truth with more than 64 distinct ids in one utterance: k_eval refuses it
+  (UIS_ERR_UNSUPPORTED), the reference's evals.py has no such limit -- predict_and_evaluate falls
+  back to the host function and returns the same values."""
+  import uisrnn_amd
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(synth.tracker_params(256, 512, 1, seed=0))
+  lengths = [150, 40]
+  seqs, spk = synth.make_utterances(9700, len(lengths), lengths, 256)
+  truth = [list(range(lengths[0])), spk[1].tolist()]   # 150 distinct ids in utterance 0
+  predicted, acc = model.predict_and_evaluate(seqs, truth, inference_args)
+  assert acc == [uisrnn_amd.compute_sequence_match_accuracy(t, p) for t, p in zip(truth, predicted)]
+  with pytest.raises(_capi.HipLibraryError):   # (the device entry point itself still says no)
+    evals.sequence_match_accuracies_device(model._get_decoder(), [truth[0]], [predicted[0]])

@@ -613,3 +613,25 @@ def test_calculate_score_arrays_on_the_device(oracle_lib):
       np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-4)
       checked += 1
   assert checked >= 12
+
+
+def test_level_capacity_names_the_utterances_and_keeps_the_others(oracle_lib):
+  """The Python surface on the same limit: LookAheadWindowError names the utterances whose window
+  overflowed an intermediate level and carries the label lists of every other utterance (decoded
+  again on their own) -- nothing valid is thrown away."""
+  import uisrnn_amd
+  params, rng = _many_cluster_case()
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model_args.observation_dim = 64
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  wild = rng.standard_normal((14, 64))                      # opens a cluster per frame
+  calm = np.tile(rng.standard_normal((1, 64)), (9, 1)) + 0.01 * rng.standard_normal((9, 64))
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 200, 4, 1
+  inference_args.max_clusters = 30
+  with pytest.raises(uisrnn_amd.LookAheadWindowError) as info:
+    model.predict([calm, wild], inference_args)
+  assert info.value.utterances == (1,)
+  assert info.value.results[1] is None
+  ref = oracle_lib.decode(params, [calm], 200, 4, 1)
+  assert info.value.results[0] == ref['labels'][0].tolist()

@@ -16,3 +16,4 @@ UISRNN = _uisrnn.UISRNN
 parallel_predict = _uisrnn.parallel_predict
 OnlineSession = _uisrnn.OnlineSession  # extension: streaming decode
 EmptyBeamError = _uisrnn.EmptyBeamError
+LookAheadWindowError = _uisrnn.LookAheadWindowError

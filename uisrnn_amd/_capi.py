@@ -418,6 +418,14 @@ class Decoder:
       out['beam_scores'] = beam_scores
     return out
 
+  def last_overflow(self, n_utt):
+    """Per-utterance flags of the last decode: bit 0 = a survivor hit the cluster cap, bit 1 = an
+    intermediate level of a look-ahead window was full (uis_last_decode_info)."""
+    overflow = np.zeros(max(int(n_utt), 1), dtype=np.int32)
+    self._check(self._lib.uis_last_decode_info(
+        self._handle, overflow.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), None), 'uis_last_decode_info')
+    return overflow[:int(n_utt)]
+
   def debug_scores(self, n_steps, n_utt, beam_size, max_clusters):
     """The candidate scores of the last decode (flags included UIS_FLAG_DEBUG_SCORES):
     float32 [n_steps, n_utt, beam_size, max_clusters + 1], +inf where _calculate_score's padded

@@ -766,6 +766,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
            d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n);
     return UIS_OK;
   };
+  // From here on DMA from the caller's (or the pinned staging) memory may be in flight: whichever way
+  // this function is left -- an error return inside the chunk loop included -- both streams are
+  // drained first, so the caller never gets its buffers back while the copy engine still reads them.
+  struct Drain {
+    uis_handle* h;
+    ~Drain() { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
+  } drain_on_exit{h};
   if (F > 0 && h_frames) {
     const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / 4096));
     while ((int)h->h2d_done.size() < n_chunks) {
@@ -1350,7 +1357,22 @@ unsigned long long pm_idle_ticks() {
 // After the launch has ended (every cluster left, or an in-launch barrier gave up): look at the abort word.
 int pm_reap(uis_handle* h) {
   uis_handle::Stream& ss = h->stream_state;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  // (a launch that is really stuck must not take the caller with it: poll with a deadline instead
+  // of an unbounded hipStreamSynchronize; the kernel's own barrier time-out is ~1 s)
+  {
+    const double t0 = pm_now_s();
+    hipError_t q;
+    while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {
+      if (pm_now_s() - t0 > 15.0) {
+        ss.persist = false;
+        h->resident_off = true;
+        return fail(UIS_ERR_HIP, "the persistent streaming launch does not leave the device (15 s); the handle's "
+                                 "stream is unusable -- destroy the handle");
+      }
+      __builtin_ia32_pause();
+    }
+    if (q != hipSuccess) return fail(UIS_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+  }
   ss.pm_running = false;
   uint32_t abort_word = 0;
   HIPCHK(hipMemcpy(&abort_word, ss.d_ctl + 16, 4, hipMemcpyDeviceToHost));
@@ -1453,7 +1475,7 @@ int pm_command(uis_handle* h, uint32_t type, uint32_t frames, bool may_launch, c
       if ((++spins & 4095u) == 0) {
         if (pm_now_s() - t0 > 10.0) break;
         // (a launch that ended without saying so -- an in-launch barrier gave up -- is noticed here)
-        if ((spins & 0xfffffu) == 0 && hipStreamQuery(h->stream) == hipSuccess) { left = true; break; }
+        if ((spins & 0xffffu) == 0 && hipStreamQuery(h->stream) == hipSuccess) { left = true; break; }
       }
       __builtin_ia32_pause();
     }
@@ -1764,12 +1786,19 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
     HIPCHK(hipMemsetAsync(ss.d_ctl, 0, ss.ctl_words * 4, h->stream));
     const size_t shmem = std::max<size_t>(resident_lds_bytes(m.Hp, m.Dp, ss.B, ss.Kmax, ss.S), 96 * 1024);
     h->inlaunch_failed = false;
+    // Every push is a COOPERATIVE launch: the kernel spins on in-launch barriers and needs all its
+    // workgroups co-resident, which only that launch path checks against whatever else runs on the
+    // device at that moment (another handle's decode, a second session).  A plain launch of the
+    // same grid saves 15-19 us of host time per push; it is opt-in (UIS_STREAM_PLAIN_LAUNCH=1) for
+    // callers that own the device, and used only after the session's first push went through the
+    // cooperative path.
+    static const bool plain_ok = getenv("UIS_STREAM_PLAIN_LAUNCH") != nullptr && atoi(getenv("UIS_STREAM_PLAIN_LAUNCH")) != 0;
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
   if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_resident<HPV, DPV>),                         \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
     rc = lch.run_cooperative(UIS_K_GRU, &k_decode_resident<HPV, DPV>, h->n_cu, dim3(32 * st.ncl), dim3(512), shmem, \
-                             m, st, !ss.coop_checked);                                                               \
+                             m, st, !(ss.coop_checked && plain_ok));                                                 \
   }
     UIS_RESIDENT_CASE(512, 256)
     UIS_RESIDENT_CASE(512, 512)

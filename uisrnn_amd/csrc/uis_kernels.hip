@@ -2001,6 +2001,12 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   // PERSIST: the session's per-push tables are this cluster's device copies, filled by rank 0
   // (read through the pointer where needed -- all of it outside the step loop)
   const PersistArgs& pm = *st.pm;
+  // PERSIST: a launch that gives up at an in-launch barrier tells the host so (LEFT word 3): the
+  // host's command loop then stops waiting for a completion that will not come
+  auto left_aborted = [&]() {
+    if (PERSIST && rank == 0 && t == 0)
+      __hip_atomic_store(pm.ctl + UIS_PM_LEFT_WORD + 16 * cluster, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
   if (PERSIST) {
     st.foff = reinterpret_cast<const int64_t*>(pm.hdr + (size_t)cluster * pm.hdr_stride);
     st.avail = reinterpret_cast<const int32_t*>(pm.hdr + (size_t)cluster * pm.hdr_stride + (size_t)U * 8);
@@ -2125,7 +2131,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
         backtrace_body(sl, u, pm.labels, pm.scores, pm.beam_scores, reinterpret_cast<unsigned char*>(spart));
         if (t == 0) pm.overflow[u] = st.overflow[u];
       }
-      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
       if (rank == 0 && t == 0) {
         __threadfence_system();
         __hip_atomic_store(pm.ctl + UIS_PM_DONE_WORD + 16 * cluster, (uint32_t)s_ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2230,7 +2236,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     if (!overlap) {
-      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the owner reads its mse0 back from L2)
       __syncthreads();
@@ -2288,7 +2294,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(0);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(1);
     // PERSIST: the step count after this push goes to its global word (the next command reads it)
     // once every workgroup has derived nsteps from the old value, i.e. behind this barrier; the
@@ -2379,7 +2385,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
                                                SelectNoHook(), first_step);
     }
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(3);
 
     // ---- linear_mean1 + relu -> a1 (needs no descriptors: row tile in, row tile out)
@@ -2410,7 +2416,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
                                                SelectNoHook(), first_step);
     }
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(5);
 
     // ---- linear_mean2 + running mean -> dst slot; of every chunk this rank takes the row tiles
@@ -2462,7 +2468,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(6);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(7);
   }
   if (!PERSIST) {
@@ -2480,7 +2486,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   // (the next command's listing reads it), the cluster reports to the host.
   // (the last step's closing barrier has drained everybody's stores, the step count's included)
   gstep += (uint32_t)nsteps;
-  if (nsteps == 0 && xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;  // (nothing to run: my_cur is the old count)
+  if (nsteps == 0 && xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }  // (nothing to run: my_cur is the old count)
   PMSTAMP(3);  // the steps
 #if defined(UIS_PM_TIMING)
   if (blockIdx.x == 0 && t == 0) {
@@ -2497,7 +2503,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   if (PERSIST) {
     // leaving (told to, or idle): the session goes on with ordinary launches from the global tables
     if (did_select && my_cur > launch_step0) write_back(my_cur);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     if (rank == 0 && t == 0) {
       __threadfence_system();
       __hip_atomic_store(pm.ctl + UIS_PM_LEFT_WORD + 16 * cluster, ctype == UIS_PM_QUIT ? 1u : 2u, __ATOMIC_RELAXED,

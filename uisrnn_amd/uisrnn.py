@@ -11,6 +11,8 @@ Training (``fit``) is outside the scope of this package: train with the
 reference and ``load()`` its checkpoint here.
 """
 
+import threading
+
 import numpy as np
 
 from uisrnn_amd import _capi
@@ -51,6 +53,21 @@ class EmptyBeamError(ValueError, IndexError):
   """
 
 
+class LookAheadWindowError(_capi.HipLibraryError):
+  """look_ahead >= 2: inside a window some utterances had more live assignment prefixes than the
+  device tables hold (beam_size * clusters ^ (look_ahead - 1), include/uisrnn_hip.h UIS_LEVEL_CAP);
+  the reference has no such cap.  A larger max_clusters cannot help: lower look_ahead or beam_size
+  for those utterances.
+
+  Attributes:
+    utterances: indices (into the list given to predict) of the affected utterances.
+    results: the label lists of every OTHER utterance (None at the affected positions) -- they were
+      decoded again without the affected ones, so nothing valid is thrown away.
+  """
+  utterances = ()
+  results = None
+
+
 class UISRNN:
   """Unbounded Interleaved-State RNN -- MI355X decode."""
 
@@ -73,6 +90,7 @@ class UISRNN:
     self._extra_decoders = {}
     self.last_stats = None
     self._single_pass = False
+    self._state_lock = threading.Lock()  # last_stats / _single_pass: parallel_predict's workers share the model
 
   # ---- the attributes callers of the reference read and write
   @property
@@ -184,8 +202,23 @@ class UISRNN:
       sub = [sequences[u] for u in pending]
       sub_off = np.zeros(len(pending) + 1, dtype=np.int64)
       sub_off[1:] = np.cumsum([s.shape[0] for s in sub])
-      out = decoder.decode_f64(sub, args.beam_size, args.look_ahead,
-                               args.test_iteration, max_clusters=cap, flags=flags)
+      try:
+        out = decoder.decode_f64(sub, args.beam_size, args.look_ahead,
+                                 args.test_iteration, max_clusters=cap, flags=flags)
+      except _capi.HipLibraryError as err:
+        if err.status != _capi.UIS_ERR_UNSUPPORTED or args.look_ahead < 2:
+          raise
+        level_full = [u for k, u in enumerate(pending) if decoder.last_overflow(len(pending))[k] & 2]
+        if not level_full or len(level_full) == len(pending):
+          raise
+        # name the utterances, and decode the others again on their own: their results are valid
+        rest = [u for u in pending if u not in level_full]
+        partial = self._decode_batch([sequences[u] for u in rest], args, flags, device, decoder)
+        for u, labels in zip(rest, partial):
+          results[u] = labels
+        exc = LookAheadWindowError('{} (utterances {})'.format(err, level_full))
+        exc.status, exc.utterances, exc.results = err.status, tuple(level_full), results
+        raise exc from err
       if stats is None:
         stats = out['stats']
       still = []
@@ -210,8 +243,9 @@ class UISRNN:
         if cap > _MAX_CLUSTERS_LIMIT:
           raise RuntimeError(
               'more than {} clusters per hypothesis'.format(_MAX_CLUSTERS_LIMIT))
-    self.last_stats = stats  # (parallel_predict: the last worker to finish wins)
-    self._single_pass = cap == _initial_cluster_cap(args)  # no retry: one decode covered everything
+    with self._state_lock:  # (parallel_predict: the last worker to finish wins, whole)
+      self.last_stats = stats
+      self._single_pass = cap == _initial_cluster_cap(args)  # no retry: one decode covered everything
     return results
 
   def predict_and_evaluate(self, test_sequences, test_cluster_ids, args):
@@ -228,8 +262,13 @@ class UISRNN:
     Returns:
       (predicted label lists, accuracies) -- accuracies equal
       compute_sequence_match_accuracy(truth, predicted) exactly.
+
+    The device kernel handles label sequences with at most 64 distinct ids each (ids below
+    65536 after densification); a batch with a sequence beyond that -- the reference's evals.py
+    has no such limit, and the cluster-cap retry lets predictions reach 1024 clusters -- is
+    scored by the host function evals.compute_sequence_match_accuracy instead, same values.
     """
-    from uisrnn_amd import evals  # pylint: disable=import-outside-toplevel
+    from uisrnn_amd import _capi, evals  # pylint: disable=import-outside-toplevel
     if not isinstance(test_sequences, list) or not isinstance(test_cluster_ids, list):
       raise TypeError('test_sequences and test_cluster_ids must be lists')
     if len(test_sequences) != len(test_cluster_ids):
@@ -245,13 +284,20 @@ class UISRNN:
     predicted = self._decode_batch(test_sequences, args)
     truth = np.concatenate([evals.dense_ids(list(ids)) for ids in test_cluster_ids])
     lens = np.array([s.shape[0] for s in test_sequences], dtype=np.int64)
-    if self._single_pass:  # the labels of that one decode are still resident: no upload
-      matched = decoder.eval_last_decode(truth, len(test_sequences))
-    else:  # the cluster-cap retry decoded a subset last: hand the labels back
-      offsets = np.zeros(len(lens) + 1, dtype=np.int64)
-      offsets[1:] = np.cumsum(lens)
-      flat = np.concatenate([evals.dense_ids(p) for p in predicted])
-      matched = decoder.eval_matched(truth, flat, offsets)
+    try:
+      if self._single_pass:  # the labels of that one decode are still resident: no upload
+        matched = decoder.eval_last_decode(truth, len(test_sequences))
+      else:  # the cluster-cap retry decoded a subset last: hand the labels back
+        offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum(lens)
+        flat = np.concatenate([evals.dense_ids(p) for p in predicted])
+        matched = decoder.eval_matched(truth, flat, offsets)
+    except _capi.HipLibraryError as err:
+      if err.status != _capi.UIS_ERR_UNSUPPORTED:
+        raise
+      # more than 64 distinct ids in some sequence: the host function has no limit
+      return predicted, [evals.compute_sequence_match_accuracy(list(ids), list(p))
+                         for ids, p in zip(test_cluster_ids, predicted)]
     return predicted, [float(m) / int(n) for m, n in zip(matched, lens)]
 
   def predict_single(self, test_sequence, args):
@@ -288,6 +334,11 @@ class UISRNN:
 
     Raises:
       TypeError: test_sequences is neither a list nor a numpy array.
+      EmptyBeamError: non-finite scores emptied an utterance's beam (the reference raises
+        ValueError / IndexError there; this is both).
+      LookAheadWindowError: look_ahead >= 2 only -- some utterances had more live assignment
+        prefixes inside a window than the device tables hold (a limit the reference does not
+        have); the exception names them and carries the other utterances' results.
     """
     if isinstance(test_sequences, np.ndarray):
       return self.predict_single(test_sequences, args)
