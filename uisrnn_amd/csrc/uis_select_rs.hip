@@ -61,6 +61,8 @@ struct RsLds {
   // never overlap; rs_back, which runs inside the GRU stage, only touches the persistent blocks)
   int sc_mse;                                // float [S]
   int sc_dst;                                // int32 [B]    the ord-th free slot
+  int sc_ckey, sc_ce, sc_csc;                // [32] each: the prune's short list (key, grid position, score)
+  int sc_wine, sc_wins;                      // [B] each: winner r's grid position and score
   int scratch_stride;
 };
 
@@ -87,6 +89,11 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   o = 0;
   l.sc_mse = take(S * 4);
   l.sc_dst = take(B * 4);
+  l.sc_ckey = take(32 * 4);
+  l.sc_ce = take(32 * 4);
+  l.sc_csc = take(32 * 4);
+  l.sc_wine = take(B * 4);
+  l.sc_wins = take(B * 4);
   l.scratch_stride = o;
   return l;
 }
@@ -187,6 +194,7 @@ struct RsPrep {
   int Kcur, kmagic;
   unsigned long long old0, old1, old2, old3;  // live slots the previous step left alone (their MSEs are published)
   int cslot0, cslot1, cslot2;         // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
+  int stay;                           // bit k: the candidate at position lane + 64 k keeps its hypothesis' last cluster
   double pr0, pr1, pr2;
   float bs0, bs1, bs2;
 };
@@ -241,7 +249,8 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
   P.cslot0 = P.cslot1 = P.cslot2 = -2;
   P.pr0 = P.pr1 = P.pr2 = 0.0;
   P.bs0 = P.bs1 = P.bs2 = 0.0f;
-  auto prep_at = [&](int e, int& cslot, double& prior, float& base) {
+  P.stay = 0;
+  auto prep_at = [&](int e, int k, int& cslot, double& prior, float& base) {
     const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
     if (b < nb) {
       const int Kb = sK[b];
@@ -251,7 +260,7 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
         base = sscore[b];
         if (c < Kb) {
           cslot = (int)sslot[b * Kmax + c];
-          if (c == slast[b]) prior = m.lp_stay;
+          if (c == slast[b]) { prior = m.lp_stay; P.stay |= 1 << k; }
           else {
             const int blk = (int)sblk[b * Kmax + c];
             const double lb = blk < UIS_RS_LOGTAB ? s_lblk[blk] : st.logblk[blk];
@@ -264,9 +273,9 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
       }
     }
   };
-  prep_at(lane, P.cslot0, P.pr0, P.bs0);
-  if (P.nch > 1) prep_at(lane + 64, P.cslot1, P.pr1, P.bs1);
-  if (P.nch > 2) prep_at(lane + 128, P.cslot2, P.pr2, P.bs2);
+  prep_at(lane, 0, P.cslot0, P.pr0, P.bs0);
+  if (P.nch > 1) prep_at(lane + 64, 1, P.cslot1, P.pr1, P.bs1);
+  if (P.nch > 2) prep_at(lane + 128, 2, P.cslot2, P.pr2, P.bs2);
   P.C = __popcll(__ballot(P.cslot0 != -2)) + __popcll(__ballot(P.cslot1 != -2)) + __popcll(__ballot(P.cslot2 != -2));
   return P;
 }
@@ -371,37 +380,81 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const int keep = nfin < B ? nfin : B;
   PSTAMP(2);
 
-  // ---- prune: `keep` rounds of the wave-wide minimum; ties to the lowest grid position
+  // ---- prune: the `keep` best, ascending, ties to the lowest grid position.
+  // Short list first: every hypothesis has one candidate that keeps its last cluster; with a full
+  // beam there are beam_size of those, so the beam_size best candidates all score at or below the
+  // worst of them -- in practice the short list is those plus a handful of switches.  It is
+  // compacted (in grid order) and every entry counts the entries that beat it.
   int win_e = 0;
   float win_sc = 0.0f;
-  for (int r = 0; r < keep; ++r) {
-    uint32_t loc = key0 < key1 ? key0 : key1;
-    loc = loc < key2 ? loc : key2;
-    const uint32_t mn = rs_wave_min_u32(loc);
-    unsigned long long mk = __ballot(key0 == mn);
-    int l, e;
-    float s;
-    if (mk) {
-      l = __ffsll((long long)mk) - 1;
-      e = l;
-      s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc0), l));
-      if (lane == l) key0 = UIS_RS_NOKEY;
-    } else {
-      mk = __ballot(key1 == mn);
+  uint32_t thr = UIS_RS_NOKEY;
+  {
+    const bool s0 = (P.stay & 1) != 0, s1 = (P.stay & 2) != 0, s2 = (P.stay & 4) != 0;
+    const int nstay = __popcll(__ballot(s0)) + __popcll(__ballot(s1)) + __popcll(__ballot(s2));
+    if (nstay >= B) {
+      uint32_t wk = s0 ? key0 : 0u;
+      wk = s1 && key1 > wk ? key1 : wk;
+      wk = s2 && key2 > wk ? key2 : wk;
+      thr = ~rs_wave_min_u32(~wk);  // the worst of them (a non-finite one: no threshold)
+    }
+  }
+  const bool v0 = key0 != UIS_RS_NOKEY && key0 <= thr, v1 = key1 != UIS_RS_NOKEY && key1 <= thr,
+             v2 = key2 != UIS_RS_NOKEY && key2 <= thr;
+  const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
+  const int n0 = __popcll(m0), n1 = __popcll(m1), nsv = n0 + n1 + __popcll(m2);
+  if (nsv <= 32) {
+    uint32_t* sck = reinterpret_cast<uint32_t*>(scr + L.sc_ckey);
+    int* sce = reinterpret_cast<int*>(scr + L.sc_ce);
+    float* scs = reinterpret_cast<float*>(scr + L.sc_csc);
+    int* swe = reinterpret_cast<int*>(scr + L.sc_wine);
+    float* sws = reinterpret_cast<float*>(scr + L.sc_wins);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (v0) { const int q = __popcll(m0 & below); sck[q] = key0; sce[q] = lane; scs[q] = sc0; }
+    if (v1) { const int q = n0 + __popcll(m1 & below); sck[q] = key1; sce[q] = lane + 64; scs[q] = sc1; }
+    if (v2) { const int q = n0 + n1 + __popcll(m2 & below); sck[q] = key2; sce[q] = lane + 128; scs[q] = sc2; }
+    rs_lds_fence();
+    const bool mine = lane < nsv;
+    const uint32_t ck = mine ? sck[lane] : UIS_RS_NOKEY;
+    int rank = 0;
+    for (int j = 0; j < nsv; ++j) {  // (compaction kept the grid order: an earlier entry wins a tie)
+      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)ck, j);
+      rank += (kj < ck || (kj == ck && j < lane)) ? 1 : 0;
+    }
+    if (mine && rank < keep) { swe[rank] = sce[lane]; sws[rank] = scs[lane]; }
+    rs_lds_fence();
+    if (lane < keep) { win_e = swe[lane]; win_sc = sws[lane]; }
+  } else {
+    // (a long short list -- an early step, or a model that switches freely: `keep` rounds of the
+    // wave-wide minimum)
+    for (int r = 0; r < keep; ++r) {
+      uint32_t loc = key0 < key1 ? key0 : key1;
+      loc = loc < key2 ? loc : key2;
+      const uint32_t mn = rs_wave_min_u32(loc);
+      unsigned long long mk = __ballot(key0 == mn);
+      int l, e;
+      float s;
       if (mk) {
         l = __ffsll((long long)mk) - 1;
-        e = l + 64;
-        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc1), l));
-        if (lane == l) key1 = UIS_RS_NOKEY;
+        e = l;
+        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc0), l));
+        if (lane == l) key0 = UIS_RS_NOKEY;
       } else {
-        mk = __ballot(key2 == mn);
-        l = __ffsll((long long)mk) - 1;
-        e = l + 128;
-        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc2), l));
-        if (lane == l) key2 = UIS_RS_NOKEY;
+        mk = __ballot(key1 == mn);
+        if (mk) {
+          l = __ffsll((long long)mk) - 1;
+          e = l + 64;
+          s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc1), l));
+          if (lane == l) key1 = UIS_RS_NOKEY;
+        } else {
+          mk = __ballot(key2 == mn);
+          l = __ffsll((long long)mk) - 1;
+          e = l + 128;
+          s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc2), l));
+          if (lane == l) key2 = UIS_RS_NOKEY;
+        }
       }
+      if (lane == r) { win_e = e; win_sc = s; }
     }
-    if (lane == r) { win_e = e; win_sc = s; }
   }
   PSTAMP(3);
 
@@ -656,6 +709,34 @@ __device__ __forceinline__ void rs_tile(const f32x4 (&wr)[NG][PER], const float*
   else rs_tile_nv<NG, PER, RC, 1, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
 }
 
+// The wait half of the in-launch barrier for a workgroup that has ARRIVED already (xcd_arrive: its
+// stores were drained there) and did work of its own since: no second drain -- what that work
+// stored is nobody's input before the next barrier, whose arrival drains it -- and no workgroup
+// barrier in front of the poll.
+__device__ __forceinline__ bool rs_xcd_wait(const DecodeState& st, int cluster, uint32_t target, int* s_abort) {
+  if (threadIdx.x == 0) {
+    uint32_t* ctr = st.rx_bar + cluster * 32;
+    s_abort[2] = 0;
+    unsigned spins = 0;
+    int bad = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
+        __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = 1;
+        break;
+      }
+      if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        bad = 1;
+        break;
+      }
+    }
+    *s_abort = bad;
+  }
+  __syncthreads();
+  return *s_abort != 0;
+}
+
 // The one-launch decode with the replicated select (see the top of this file).  Same grid, same
 // weight residency, same dense stages and arithmetic as k_decode_resident; three in-launch
 // barriers per step instead of four, no row reservation, no descriptor staging.
@@ -860,7 +941,11 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 #endif
 #endif
     if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
+#if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+#else
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+#endif
     if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
@@ -900,8 +985,11 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     xcd_arrive(st, cluster, s_ctl);
     if (has_u && (long)s + 1 < T_w)
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
 #endif
+#if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+#endif
     RSTAMP(5);
 
     // ---- linear_mean2 + running mean -> dst slot
@@ -964,8 +1052,11 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 #else
     xcd_arrive(st, cluster, s_ctl);
     if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
 #endif
+#if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+#endif
     RSTAMP(7);
   }
 #if defined(UIS_RESIDENT_TIMING)
