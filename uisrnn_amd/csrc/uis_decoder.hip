@@ -872,10 +872,30 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
       const bool big = U > 32 * ncl && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
                        big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
-      const size_t shmem = std::max<size_t>(rs    ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
-                                            : big ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
-                                                  : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
+      // ... with the selects of a rank's utterances running concurrently, one wave each (k_decode_big<.., true>),
+      // where the single-wave select applies; UIS_FLAG_OWNER_SELECT keeps them one after the other
+      const int per_rank = (((U + ncl - 1) / ncl) + 31) / 32;
+      const bool big_ws = big && !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
+                          rs_select_ok(B, Kmax, S, 1, 1, (long)maxT) &&
+                          big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+      const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
+                                            : big_ws ? big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
+                                            : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
+                                                     : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
+#define UIS_BIGWS_CASE(HPV, DPV)                                                                                      \
+  if (m.Hp == HPV && m.Dp == DPV && big_ws) {                                                                        \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_big<HPV, DPV, true>),                        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_big<HPV, DPV, true>, h->n_cu, dim3(32 * ncl), dim3(512),     \
+                                 shmem, m, gp.st)))                                                                  \
+      return rc;                                                                                                     \
+  }
+      UIS_BIGWS_CASE(512, 256)
+      UIS_BIGWS_CASE(512, 128)
+      UIS_BIGWS_CASE(256, 256)
+      UIS_BIGWS_CASE(256, 128)
+#undef UIS_BIGWS_CASE
 #define UIS_RS_CASE(HPV, DPV)                                                                                         \
   if (m.Hp == HPV && m.Dp == DPV && rs) {                                                                            \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_rs<HPV, DPV>),                               \
@@ -890,7 +910,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RS_CASE(256, 128)
 #undef UIS_RS_CASE
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
-  if (m.Hp == HPV && m.Dp == DPV && !rs) {                                                                           \
+  if (m.Hp == HPV && m.Dp == DPV && !rs && !big_ws) {                                                                \
     void (*kern)(DevModel, DecodeState) = big ? &k_decode_big<HPV, DPV> : &k_decode_resident<HPV, DPV>;             \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \

@@ -2841,7 +2841,22 @@ __host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax,
   return big_lds_fixed(Hp, Dp, B, Kmax, S) + (size_t)big_store_slots(Hp, Dp, B, Kmax, S) * big_store_stride(Dp, B, Kmax, S);
 }
 
-template <int HP, int DP>
+#include "uis_select_rs.hip"
+
+// WS (wave select): the selects of a rank's utterances run CONCURRENTLY, one wave each, on the
+// single-wave select of uis_select_rs.hip (rs_prep / rs_front<FULL> / rs_back; the wave computes
+// every live cluster's MSE itself) instead of one after the other on the whole workgroup: at 1024
+// utterances a rank owns four, and their 4 x 8 us were a fifth of the step.  LDS of the select part:
+// 1 / (2 sigma^2) | log tables | nws persistent blocks | eight per-wave scratches.
+__host__ __device__ inline size_t big_ws_select_bytes(int Dp, int B, int Kmax, int S, int nws) {
+  const RsLds L = rs_lds_layout(B, Kmax, S);
+  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)nws * L.persist_stride + (size_t)8 * L.scratch_stride;
+}
+__host__ __device__ inline size_t big_ws_lds_bytes(int Hp, int Dp, int B, int Kmax, int S, int nws) {
+  return ((big_ws_select_bytes(Dp, B, Kmax, S, nws) + 255) & ~(size_t)255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+
+template <int HP, int DP, bool WS = false>
 __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
   constexpr int NKB = HP / 16;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
@@ -2853,14 +2868,32 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
   const int U = st.U, S = st.S;
   const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
-  f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((L.total + 255) & ~255));  // [3][NKB][64]
+  // WS: utterances per rank (wave k owns the rank's k-th utterance)
+  const int nws = WS ? (((U + ncl - 1) / ncl) + 31) / 32 : 0;
+  const RsLds RL = rs_lds_layout(st.B, st.Kmax, S);
+  const size_t select_bytes = WS ? big_ws_select_bytes(DP, st.B, st.Kmax, S, nws) : (size_t)L.total;
+  f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((select_bytes + 255) & ~(size_t)255));  // [3][NKB][64]
   f32x4* s_wm = s_whh + 3 * NKB * 64;                                          // [NKB][64] linear_mean1's slice, then linear_mean2's
   int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                         // [0] abort [1] steps [2] arrived
   // the beams of this rank's first `nstore` utterances stay in LDS from step to step (the rest, if
   // the rank has more, goes through the global tables every step)
   unsigned char* s_store = reinterpret_cast<unsigned char*>(s_ctl + 16);
   const int store_stride = (int)big_store_stride(m.Dp, st.B, st.Kmax, S);
-  const int nstore = big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
+  const int nstore = WS ? 0 : big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
+  // WS: the select part of the LDS
+  float* ws_swgt = reinterpret_cast<float*>(smem_raw);
+  double* ws_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
+  double* ws_lden = ws_lblk + UIS_RS_LOGTAB;
+  unsigned char* ws_pers = reinterpret_cast<unsigned char*>(ws_lden + UIS_RS_LOGTAB);
+  unsigned char* ws_scr = ws_pers + (size_t)nws * RL.persist_stride;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int u_w = cluster + ncl * (rank + 32 * wu);
+  const bool has_u = WS && wu < nws && u_w < U;
+  unsigned char* const pers_w = ws_pers + (size_t)(has_u ? wu : 0) * RL.persist_stride;
+  unsigned char* const scr_w = ws_scr + (size_t)wu * RL.scratch_stride;
+  long off0_w = 0, N_w = 0, fpos_w = 0;
+  if (has_u) { off0_w = (long)st.off[u_w]; N_w = (long)st.off[u_w + 1] - off0_w; }
+  const long T_w = (long)st.tau * N_w;
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -2869,7 +2902,19 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
   }
+  if (WS) {
+    for (int i = t; i < DP; i += 512) ws_swgt[i] = m.wgt[i];
+    for (int i = t; i < UIS_RS_LOGTAB; i += 512) { ws_lblk[i] = st.logblk[i]; ws_lden[i] = st.logden[i]; }
+    // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
+    if (has_u)
+      for (int i = lane; i < RL.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = 0;
+  }
   __syncthreads();
+  if (WS && has_u && lane == 0) {
+    int* hdr = reinterpret_cast<int*>(pers_w + RL.off_hdr);
+    hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
+    reinterpret_cast<int*>(pers_w + RL.off_last)[0] = -1;
+  }
   {  // decode steps of this cluster = the longest of its utterances
     int myT = 0;
     for (int i = t; cluster + ncl * i < U; i += 512) {
@@ -2918,19 +2963,47 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
     sink.count = st.rx_nrows + cluster * 32 + par;
-    for (int i = rank, k = 0; cluster + ncl * i < U; i += 32, ++k) {
-      const int u = cluster + ncl * i;
-      if (k < nstore) {
-        unsigned char* blk = s_store + (size_t)k * store_stride;
-        select_fast_body<512, true, true, DP, 7>(m, st, par, u, smem_raw, sink, s, (long)st.off[u], (long)st.off[u + 1], SelectNoHook(), 0,
-                                                 blk - L.off_slot, reinterpret_cast<int*>(blk + 2 * L.set_stride));
-      } else {
-        select_fast_body<512, true, false, DP>(m, st, par, u, smem_raw, sink);
+    if constexpr (WS) {
+      // every utterance of this rank at once, one wave each: candidate grid, MSEs, scores, prune,
+      // winners; the rows go to the cluster's list (their order is whatever the reservations make
+      // it: nothing depends on it); the table update runs inside the barrier
+      const bool act_w = has_u && (long)s < T_w;
+      const long frame_w = off0_w + fpos_w;
+      RsWin win;
+      win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
+      if (act_w) {
+        const RsPrep prep = rs_prep<true>(m, st, RL, s, pers_w, scr_w, ws_lblk, ws_lden);
+        win = rs_front<DP, true>(m, st, RL, u_w, s, frame_w, pers_w, scr_w, nullptr, prep, nullptr, ws_swgt);
+        int row_base = 0;
+        if (lane == 0 && win.nlead > 0) row_base = atomicAdd(sink.count, win.nlead);
+        row_base = __shfl(row_base, 0, 64);
+        if (win.is_lead()) {
+          RnnRow rr; rr.utt = u_w; rr.src = win.src(); rr.dst = win.dst(); rr.nprev = win.nprev(); rr.frame = frame_w; rr.pad = 0;
+          sink.rows[row_base + win.ord()] = rr;
+        }
       }
-      __syncthreads();
+      RSTAMP(0);
+      xcd_arrive(st, cluster, s_ctl);
+      if (act_w) {
+        rs_back(m, st, RL, u_w, s, off0_w, pers_w, true, win);
+        fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
+      }
+      if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    } else {
+      for (int i = rank, k = 0; cluster + ncl * i < U; i += 32, ++k) {
+        const int u = cluster + ncl * i;
+        if (k < nstore) {
+          unsigned char* blk = s_store + (size_t)k * store_stride;
+          select_fast_body<512, true, true, DP, 7>(m, st, par, u, smem_raw, sink, s, (long)st.off[u], (long)st.off[u + 1], SelectNoHook(), 0,
+                                                   blk - L.off_slot, reinterpret_cast<int*>(blk + 2 * L.set_stride));
+        } else {
+          select_fast_body<512, true, false, DP>(m, st, par, u, smem_raw, sink);
+        }
+        __syncthreads();
+      }
+      RSTAMP(0);
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     }
-    RSTAMP(0);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     RSTAMP(1);
     if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
@@ -3047,9 +3120,14 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
     for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
 #endif
+  if (WS && has_u && lane == 0) {  // this utterance's statistics
+    const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_stats);
+    atomicAdd(&st.counters[0], acc[0]);
+    atomicAdd(&st.counters[1], acc[1]);
+    atomicAdd(&st.counters[2], acc[2]);
+    atomicMax(&st.counters[3], acc[3]);
+  }
 }
-
-#include "uis_select_rs.hip"
 
 // ------------------------------------------------------------------ window
 //

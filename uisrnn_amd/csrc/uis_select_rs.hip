@@ -63,6 +63,7 @@ struct RsLds {
   int sc_dst;                                // int32 [B]    the ord-th free slot
   int sc_ckey, sc_ce, sc_csc;                // [32] each: the prune's short list (key, grid position, score)
   int sc_wine, sc_wins;                      // [B] each: winner r's grid position and score
+  int sc_list;                               // uint8 [S]: the live slots, compacted (a select that computes every MSE itself)
   int scratch_stride;
 };
 
@@ -94,6 +95,7 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   l.sc_csc = take(32 * 4);
   l.sc_wine = take(B * 4);
   l.sc_wins = take(B * 4);
+  l.sc_list = take(S);
   l.scratch_stride = o;
   return l;
 }
@@ -192,13 +194,14 @@ __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); 
 struct RsPrep {
   int nb, nch, C, nn;                 // wave-uniform
   int Kcur, kmagic;
-  unsigned long long old0, old1, old2, old3;  // live slots the previous step left alone (their MSEs are published)
+  unsigned long long old0, old1, old2, old3;  // live slots the previous step left alone (their MSEs are published); FULL: every live slot
   int cslot0, cslot1, cslot2;         // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
   int stay;                           // bit k: the candidate at position lane + 64 k keeps its hypothesis' last cluster
   double pr0, pr1, pr2;
   float bs0, bs1, bs2;
 };
 
+template <bool FULL = false>
 __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& st, const RsLds& L, int step,
                                           const unsigned char* pers, unsigned char* scr, const double* s_lblk,
                                           const double* s_lden) {
@@ -226,10 +229,10 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
   unsigned long long lv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) lv[k] = 64 * k < S ? slive[k] : 0ull;
-  P.old0 = lv[0] & ~snew[0];
-  P.old1 = 64 < S ? lv[1] & ~snew[1] : 0ull;
-  P.old2 = 128 < S ? lv[2] & ~snew[2] : 0ull;
-  P.old3 = 192 < S ? lv[3] & ~snew[3] : 0ull;
+  P.old0 = FULL ? lv[0] : lv[0] & ~snew[0];
+  P.old1 = 64 < S ? (FULL ? lv[1] : lv[1] & ~snew[1]) : 0ull;
+  P.old2 = 128 < S ? (FULL ? lv[2] : lv[2] & ~snew[2]) : 0ull;
+  P.old3 = 192 < S ? (FULL ? lv[3] : lv[3] & ~snew[3]) : 0ull;
   // the first beam_size free slots (not referenced by the current beam), in slot order: slot-lane
   // l + 64 k knows its own rank among the free ones
   {
@@ -285,10 +288,13 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
 // the utterance's persistent block, scr = this wave's scratch (rs_prep left the free slots there).
 // `part0` = where the partial sums of the rows this utterance emitted in the previous step start
 // (the i-th slot of its new-slot list was written by its i-th row).
-template <int DP>
+// FULL: the wave computes the MSE of the frame against EVERY live cluster mean itself (no published
+// values, no partial sums: k_decode_big, where a wave owns its utterance alone); P.old* then lists all
+// live slots and `swgt_full` is 1 / (2 sigma^2) in LDS.
+template <int DP, bool FULL = false>
 __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
                                           unsigned char* pers, unsigned char* scr, const float* part0, const RsPrep& P,
-                                          unsigned long long* ph) {
+                                          unsigned long long* ph, const float* swgt_full = nullptr) {
   // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
   // it would have to stay live -- spilled -- across the dense stages)
   int lane_ = threadIdx.x & 63;
@@ -315,10 +321,52 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const double pr0 = P.pr0, pr1 = P.pr1, pr2 = P.pr2;
   const float bs0 = P.bs0, bs1 = P.bs1, bs2 = P.bs2;
   const unsigned long long old[4] = {P.old0, P.old1, P.old2, P.old3};
+  const float mse_new = st.mse0[frame];
+  if (FULL) {
+    // ---- every live cluster's MSE from its mean: the live slots compacted into a list, 16 lanes
+    // per mean, eight means in flight per pass
+    unsigned char* s_list = scr + L.sc_list;
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (64 * k < S) {
+        const bool on = (old[k] >> lane) & 1ull;
+        if (on) s_list[n + __popcll(old[k] & ((1ull << lane) - 1ull))] = (unsigned char)(lane + 64 * k);
+        n += __popcll(old[k]);
+      }
+    }
+    rs_lds_fence();
+    if (n > 0) {
+      const __amdgpu_buffer_rsrc_t rs_mean =
+          __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+      const int grp = lane >> 4, p = lane & 15;
+      const float* xrow = st.x + (size_t)frame * DP;
+      f32x4 xv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = 4 * (p + 16 * k);
+        xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      for (int i0 = 0; i0 < n; i0 += 8) {
+        f32x4 mv[2][4];
+        int sl[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int i = i0 + 4 * h2 + grp;
+          sl[h2] = (int)s_list[i < n ? i : 0];
+          rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl[h2], p, mv[h2]);
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float v = rs_mse16_regs<DP>(m, mv[h2], xv, swgt_full, p);
+          if (p == 0 && i0 + 4 * h2 + grp < n) smse[sl[h2]] = v;
+        }
+      }
+    }
+  } else {
   // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
   // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
   // (sixteen floats + the squared first difference per cluster: lane i takes new cluster i)
-  const float mse_new = st.mse0[frame];
   float vold[4];
   {
     const float* tab = st.mse_tab + ((size_t)par * U + u) * S;
@@ -349,6 +397,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 #pragma unroll
     for (int k = 0; k < 4; ++k) { A[4 * k] = pv[k][0]; A[4 * k + 1] = pv[k][1]; A[4 * k + 2] = pv[k][2]; A[4 * k + 3] = pv[k][3]; }
     smse[nsl] = uis_mse_finish(uis_mse_acc_sum(A), pfirst, m.D);
+  }
   }
   rs_lds_fence();
   PSTAMP(1);
