@@ -308,7 +308,9 @@ class Workload:
     """Untimed decodes before anything is measured: the first settles the cluster cap, the next
     four are the decoder's trials of its control-word placement for this shape.
     Returns (passes, total ms)."""
-    passes = 5 if self.rank_frames <= 2_000_000 else 1
+    # (k_decode_rs -- at most 8 utterances per XCD -- has no placement trials: two passes)
+    small = self.n_utt <= 64 and self.dim <= 256 and self.beam <= 16 and self.look == 1 and not self.args.flags & 0x800
+    passes = (2 if small else 5) if self.rank_frames <= 2_000_000 else 1
     sync_fn()
     t0 = time.perf_counter()
     for _ in range(passes):

@@ -68,7 +68,7 @@ def main():
     cap = max(int(ref['max_clusters'].max()) + look - 1, 2)
     dec = _capi.Decoder(params)
     tag = (dim, hid, depth, beam, look, tau, lengths, seed)
-    flag_sets = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_SMALL_TILES,
+    flag_sets = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_OWNER_SELECT,
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]
     for fl in flag_sets:

@@ -710,7 +710,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // ---- placement of the control words for this decode (uis_handle::CtlTune)
   uis_handle::CtlTune& tn = h->ctl_tune;
   int ctl_cand = 0;
-  if (resident && !getenv("UIS_NO_CTL_TUNE")) {
+  // (not for k_decode_rs: its row descriptors and row counters live in LDS, only the barrier
+  // counters are polled in memory, and what is left of the placement effect is 1 % --
+  // profiles/r03_bimodal.txt -- against 5 % for the kernels that keep them in global memory)
+  if (resident && !rs && !getenv("UIS_NO_CTL_TUNE")) {
     const uint64_t sig = ((uint64_t)U << 44) ^ ((uint64_t)F << 16) ^ ((uint64_t)maxT << 6) ^ ((uint64_t)B << 1) ^ ((uint64_t)Kmax << 54);
     if (tn.sig != sig) { tn = uis_handle::CtlTune{}; tn.sig = sig; }
     ctl_cand = (tn.phase >= 1 && tn.phase <= 4) ? tn.phase - 1 : tn.best;
