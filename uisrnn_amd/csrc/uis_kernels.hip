@@ -2913,7 +2913,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   if (WS && has_u && lane == 0) {
     int* hdr = reinterpret_cast<int*>(pers_w + RL.off_hdr);
     hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
-    reinterpret_cast<int*>(pers_w + RL.off_last)[0] = -1;
+    reinterpret_cast<int*>(pers_w + RL.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
   }
   {  // decode steps of this cluster = the longest of its utterances
     int myT = 0;

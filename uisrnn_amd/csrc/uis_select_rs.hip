@@ -46,8 +46,8 @@
 
 struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
-  int off_slot, off_blk;                     // uint16 [B][Kmax]
-  int off_K, off_last, off_sum, off_score;   // int32 / float [B]
+  int off_hyp;                               // {K, last, sum(block_counts), score bits} int32 x 4 [B]: one 16-byte read per hypothesis
+  int off_ent;                               // uint32 [B][Kmax]: slot | block count << 16
   int off_hdr;                               // int32 [4]    {hypotheses, grid stride, its magic, 0}
   int set_stride;
   int off_pcnt;                              // uint16 [S]   frames assigned to the cluster state in slot s
@@ -71,12 +71,8 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   RsLds l;
   int o = 0;
   auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
-  l.off_slot = take(B * Kmax * 2);
-  l.off_blk = take(B * Kmax * 2);
-  l.off_K = take(B * 4);
-  l.off_last = take(B * 4);
-  l.off_sum = take(B * 4);
-  l.off_score = take(B * 4);
+  l.off_hyp = take(B * 16);
+  l.off_ent = take(B * Kmax * 4);
   l.off_hdr = take(16);
   l.set_stride = o;
   o += l.set_stride;
@@ -118,6 +114,17 @@ __host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, i
   return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)UIS_RS_UTT * L.persist_stride +
          (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 16 +
          (size_t)2 * UIS_RS_UTT * 8;
+}
+
+// ceil(2^20 / d) for 1 <= d < 4096 without the integer-division sequence: the float quotient of
+// two exactly representable numbers is off by at most one, which two multiplications settle
+__device__ __forceinline__ unsigned rs_magic20(unsigned d) {
+  asm volatile("" : "+v"(d));  // (a wave-uniform d sends the float ops to the scalar unit, which gfx950 does not have: "illegal instruction")
+  const unsigned n = (1u << 20) + d - 1u;
+  unsigned q = (unsigned)((float)n * __builtin_amdgcn_rcpf((float)d));
+  if (q * d > n) --q;
+  if ((q + 1u) * d <= n) ++q;
+  return q;
 }
 
 // minimum of a row of 16 lanes in its lane 15 (DPP row shifts; lanes shifted in from outside the
@@ -211,12 +218,8 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
   const int B = st.B, Kmax = st.Kmax, S = st.S;
   const int par = step & 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
-  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
-  const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
-  const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
-  const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
-  const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
-  const float* sscore = reinterpret_cast<const float*>(set_cur + L.off_score);
+  const u32x4* shyp = reinterpret_cast<const u32x4*>(set_cur + L.off_hyp);
+  const uint32_t* sent = reinterpret_cast<const uint32_t*>(set_cur + L.off_ent);
   const int* shdr = reinterpret_cast<const int*>(set_cur + L.off_hdr);
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
@@ -256,17 +259,21 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
   auto prep_at = [&](int e, int k, int& cslot, double& prior, float& base) {
     const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
     if (b < nb) {
-      const int Kb = sK[b];
+      const u32x4 h = shyp[b];  // {K, last, sum, score}
+      const int Kb = (int)h[0];
       if (c <= Kb) {
-        const int sum = ssum[b];
-        const double ld = sum < UIS_RS_LOGTAB ? s_lden[sum] : st.logden[sum];
-        base = sscore[b];
+        const int sum = (int)h[2];
+        double ld = s_lden[sum < UIS_RS_LOGTAB ? sum : 0];  // (no pointer select between LDS and global: two loads)
+        if (sum >= UIS_RS_LOGTAB) ld = st.logden[sum];
+        base = __builtin_bit_cast(float, (uint32_t)h[3]);
         if (c < Kb) {
-          cslot = (int)sslot[b * Kmax + c];
-          if (c == slast[b]) { prior = m.lp_stay; P.stay |= 1 << k; }
+          const uint32_t en = sent[b * Kmax + c];
+          cslot = (int)(en & 0xffffu);
+          if (c == (int)h[1]) { prior = m.lp_stay; P.stay |= 1 << k; }
           else {
-            const int blk = (int)sblk[b * Kmax + c];
-            const double lb = blk < UIS_RS_LOGTAB ? s_lblk[blk] : st.logblk[blk];
+            const int blk = (int)(en >> 16);
+            double lb = s_lblk[blk < UIS_RS_LOGTAB ? blk : 0];
+            if (blk >= UIS_RS_LOGTAB) lb = st.logblk[blk];
             prior = (m.lp_sw + lb) - ld;
           }
         } else {
@@ -309,8 +316,8 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
   const int par = step & 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
-  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
-  const int* sK = reinterpret_cast<const int*>(set_cur + L.off_K);
+  const u32x4* shyp = reinterpret_cast<const u32x4*>(set_cur + L.off_hyp);
+  const uint32_t* sent = reinterpret_cast<const uint32_t*>(set_cur + L.off_ent);
   const unsigned short* spcnt = reinterpret_cast<const unsigned short*>(pers + L.off_pcnt);
   const int* snewlist = reinterpret_cast<const int*>(pers + L.off_newlist);
   float* smse = reinterpret_cast<float*>(scr + L.sc_mse);
@@ -518,8 +525,8 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   if (isw) {
     wb = (int)(((unsigned)win_e * (unsigned)kmagic) >> 20);
     wc = win_e - wb * Kcur;
-    Kb = sK[wb];
-    src = wc < Kb ? (int)sslot[wb * Kmax + wc] : -1;
+    Kb = (int)reinterpret_cast<const uint32_t*>(shyp + wb)[0];
+    src = wc < Kb ? (int)(sent[wb * Kmax + wc] & 0xffffu) : -1;
   }
   int lead = r;
   if (!nodedup) {
@@ -562,17 +569,11 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   const int par = step & 1, nxt = par ^ 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   unsigned char* const set_nxt = pers + nxt * L.set_stride;
-  const unsigned short* sslot = reinterpret_cast<const unsigned short*>(set_cur + L.off_slot);
-  const unsigned short* sblk = reinterpret_cast<const unsigned short*>(set_cur + L.off_blk);
-  const int* slast = reinterpret_cast<const int*>(set_cur + L.off_last);
-  const int* ssum = reinterpret_cast<const int*>(set_cur + L.off_sum);
+  const u32x4* shyp = reinterpret_cast<const u32x4*>(set_cur + L.off_hyp);
+  const uint32_t* sent = reinterpret_cast<const uint32_t*>(set_cur + L.off_ent);
   unsigned char* sflag = pers + L.off_flag;
-  unsigned short* nslot = reinterpret_cast<unsigned short*>(set_nxt + L.off_slot);
-  unsigned short* nblk = reinterpret_cast<unsigned short*>(set_nxt + L.off_blk);
-  int* nK = reinterpret_cast<int*>(set_nxt + L.off_K);
-  int* nlast = reinterpret_cast<int*>(set_nxt + L.off_last);
-  int* nsum = reinterpret_cast<int*>(set_nxt + L.off_sum);
-  float* nscore = reinterpret_cast<float*>(set_nxt + L.off_score);
+  u32x4* nhyp = reinterpret_cast<u32x4*>(set_nxt + L.off_hyp);
+  uint32_t* nent = reinterpret_cast<uint32_t*>(set_nxt + L.off_ent);
   int* nhdr = reinterpret_cast<int*>(set_nxt + L.off_hdr);
   unsigned short* spcnt = reinterpret_cast<unsigned short*>(pers + L.off_pcnt);
   unsigned long long* slive = reinterpret_cast<unsigned long long*>(pers + L.off_live);
@@ -586,15 +587,13 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   if (isw) {
     const int wb = w.wb(), wc = w.wc(), Kb = w.Kb();
     const bool is_new = wc == Kb;
-    const int lastb = slast[wb];
+    const u32x4 h = shyp[wb];  // {K, last, sum, score}
+    const int lastb = (int)h[1];
     Knew_w = Kb + (is_new ? 1 : 0);
-    const int blk_new = is_new ? 1 : (int)sblk[wb * Kmax + wc] + (wc != lastb ? 1 : 0);
+    const int blk_new = is_new ? 1 : (int)(sent[wb * Kmax + (is_new ? 0 : wc)] >> 16) + (wc != lastb ? 1 : 0);
     if (Knew_w > Kmax) { Knew_w = Kmax; if (owner) st.overflow[u] = 1; }
-    const int sum_new = ssum[wb] + ((is_new || wc != lastb) ? 1 : 0);
-    nK[r] = Knew_w;
-    nlast[r] = wc;
-    nsum[r] = sum_new;
-    nscore[r] = w.score;
+    const int sum_new = (int)h[2] + ((is_new || wc != lastb) ? 1 : 0);
+    nhyp[r] = u32x4{(uint32_t)Knew_w, (uint32_t)wc, (uint32_t)sum_new, __builtin_bit_cast(uint32_t, w.score)};
     info_b = ((unsigned)w.dst() & 0xffffu) | ((unsigned)blk_new << 16);
     if (owner) {
       st.beam_score[((size_t)nxt * U + u) * B + r] = w.score;  // (the final beam's scores are read back by k_backtrace)
@@ -616,12 +615,9 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
     const int rb = (int)(ia & 0xffu), rc = (int)((ia >> 8) & 0xfffu);
     for (int c2 = q; c2 < Kmaxseen; c2 += 4) {
       if (rr < w.keep && c2 < Knew) {
-        int slot, blk;
-        if (c2 == rc) { slot = (int)(ib & 0xffffu); blk = (int)(ib >> 16); }
-        else { slot = (int)sslot[rb * Kmax + c2]; blk = (int)sblk[rb * Kmax + c2]; }
-        nslot[rr * Kmax + c2] = (unsigned short)slot;
-        nblk[rr * Kmax + c2] = (unsigned short)blk;
-        sflag[slot] = (unsigned char)1;
+        const uint32_t en = c2 == rc ? ib : sent[rb * Kmax + c2];  // slot | block count << 16
+        nent[rr * Kmax + c2] = en;
+        sflag[en & 0xffffu] = (unsigned char)1;
       }
     }
   }
@@ -647,7 +643,7 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
     const int Kc = Kmaxseen + 1;  // grid stride of the next step: clusters 0 .. K of every hypothesis
     nhdr[0] = w.keep;
     nhdr[1] = Kc;
-    nhdr[2] = (int)(((1u << 20) + (unsigned)Kc - 1u) / (unsigned)Kc);  // e / Kc = (e * magic) >> 20, exact for e < 2048
+    nhdr[2] = (int)rs_magic20((unsigned)Kc);  // e / Kc = (e * magic) >> 20, exact for e < 2048
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(pers + L.off_stats);
     acc[0] += (unsigned long long)w.nlead;
     acc[1] += (unsigned long long)w.keep;
@@ -844,7 +840,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   if (lane == 0) {
     int* hdr = reinterpret_cast<int*>(pers_w + L.off_hdr);
     hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
-    reinterpret_cast<int*>(pers_w + L.off_last)[0] = -1;
+    reinterpret_cast<int*>(pers_w + L.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
   }
   {
     int myT = 0;
