@@ -64,6 +64,7 @@ struct RsLds {
   int sc_ckey, sc_ce, sc_csc;                // [32] each: the prune's short list (key, grid position, score)
   int sc_wine, sc_wins;                      // [B] each: winner r's grid position and score
   int sc_list;                               // uint8 [S]: the live slots, compacted (a select that computes every MSE itself)
+  int sc_lead;                               // uint32 [S + 1]: lowest winner rank per source slot (+ 1; 0 = fresh cluster); all ones outside rs_front
   int scratch_stride;
 };
 
@@ -92,6 +93,7 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   l.sc_wine = take(B * 4);
   l.sc_wins = take(B * 4);
   l.sc_list = take(S);
+  l.sc_lead = take((S + 1) * 4);
   l.scratch_stride = o;
   return l;
 }
@@ -250,6 +252,10 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
         before += __popcll(fm);
       }
     }
+  }
+  {
+    uint32_t* slead = reinterpret_cast<uint32_t*>(scr + L.sc_lead);
+    for (int i = lane; i <= S; i += 64) slead[i] = 0xffffffffu;
   }
   P.nch = (nb * Kcur + 63) >> 6;
   P.cslot0 = P.cslot1 = P.cslot2 = -2;
@@ -468,14 +474,27 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     if (v0) { const int q = __popcll(m0 & below); sck[q] = key0; sce[q] = lane; scs[q] = sc0; }
     if (v1) { const int q = n0 + __popcll(m1 & below); sck[q] = key1; sce[q] = lane + 64; scs[q] = sc1; }
     if (v2) { const int q = n0 + n1 + __popcll(m2 & below); sck[q] = key2; sce[q] = lane + 128; scs[q] = sc2; }
+    if (lane >= nsv && lane < 32) sck[lane] = UIS_RS_NOKEY;  // (beats nobody)
     rs_lds_fence();
     const bool mine = lane < nsv;
     const uint32_t ck = mine ? sck[lane] : UIS_RS_NOKEY;
+    // every entry counts the entries that beat it: the list comes back sixteen keys at a time (the
+    // same address in every lane: a broadcast); compaction kept the grid order, so an EARLIER entry
+    // also wins a tie -- k_j <= ck, written k_j < ck + 1 (keys of finite scores are below all ones)
+    const uint32_t ck1 = ck + 1u;
+    const u32x4* sck4 = reinterpret_cast<const u32x4*>(sck);
     int rank = 0;
-    for (int j = 0; j < nsv; ++j) {  // (compaction kept the grid order: an earlier entry wins a tie)
-      const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)ck, j);
-      rank += (kj < ck || (kj == ck && j < lane)) ? 1 : 0;
-    }
+    auto count16 = [&](int j0) {
+      u32x4 kk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kk[i] = sck4[(j0 >> 2) + i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rank += kk[i][e] < ((j0 + 4 * i + e) < lane ? ck1 : ck) ? 1 : 0;
+    };
+    count16(0);
+    if (nsv > 16) count16(16);
     if (mine && rank < keep) { swe[rank] = sce[lane]; sws[rank] = scs[lane]; }
     rs_lds_fence();
     if (lane < keep) { win_e = swe[lane]; win_sc = sws[lane]; }
@@ -526,14 +545,15 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     wb = (int)(((unsigned)win_e * (unsigned)kmagic) >> 20);
     wc = win_e - wb * Kcur;
     Kb = (int)reinterpret_cast<const uint32_t*>(shyp + wb)[0];
-    src = wc < Kb ? (int)(sent[wb * Kmax + wc] & 0xffffu) : -1;
+    const uint32_t en = sent[wb * Kmax + (wc < Kmax ? wc : Kmax - 1)];  // (both reads in flight together)
+    src = wc < Kb ? (int)(en & 0xffffu) : -1;
   }
   int lead = r;
-  if (!nodedup) {
-    for (int r2 = keep - 1; r2 >= 0; --r2) {  // lowest rank with the same source wins
-      const int s2 = __builtin_amdgcn_readlane(src, r2);
-      if (isw && s2 == src) lead = r2;
-    }
+  if (!nodedup) {  // lowest rank with the same source wins: a minimum per source slot in LDS
+    uint32_t* slead = reinterpret_cast<uint32_t*>(scr + L.sc_lead);
+    if (isw) __hip_atomic_fetch_min(slead + (src + 1), (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    rs_lds_fence();
+    if (isw) lead = (int)slead[src + 1];
   }
   const bool is_lead = isw && lead == r;
   const unsigned long long lmask = __ballot(is_lead);
