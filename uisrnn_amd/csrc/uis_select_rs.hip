@@ -61,8 +61,7 @@ struct RsLds {
   // never overlap; rs_back, which runs inside the GRU stage, only touches the persistent blocks)
   int sc_mse;                                // float [S]
   int sc_dst;                                // int32 [B]    the ord-th free slot
-  int sc_ckey, sc_ce, sc_csc;                // [32] each: the prune's short list (key, grid position, score)
-  int sc_wine, sc_wins;                      // [B] each: winner r's grid position and score
+  int sc_ckey, sc_ce, sc_csc;                // [64] each: the prune's short list (key, grid position, score)
   int sc_list;                               // uint8 [S]: the live slots, compacted (a select that computes every MSE itself)
   int sc_lead;                               // uint32 [S + 1]: lowest winner rank per source slot (+ 1; 0 = fresh cluster); all ones outside rs_front
   int scratch_stride;
@@ -87,11 +86,9 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   o = 0;
   l.sc_mse = take(S * 4);
   l.sc_dst = take(B * 4);
-  l.sc_ckey = take(32 * 4);
-  l.sc_ce = take(32 * 4);
-  l.sc_csc = take(32 * 4);
-  l.sc_wine = take(B * 4);
-  l.sc_wins = take(B * 4);
+  l.sc_ckey = take(64 * 4);
+  l.sc_ce = take(64 * 4);
+  l.sc_csc = take(64 * 4);
   l.sc_list = take(S);
   l.sc_lead = take((S + 1) * 4);
   l.scratch_stride = o;
@@ -127,6 +124,11 @@ __device__ __forceinline__ unsigned rs_magic20(unsigned d) {
   if (q * d > n) --q;
   if ((q + 1u) * d <= n) ++q;
   return q;
+}
+
+// set bits of a wave mask below this lane (v_mbcnt: two instructions)
+__device__ __forceinline__ int rs_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // minimum of a row of 16 lanes in its lane 15 (DPP row shifts; lanes shifted in from outside the
@@ -247,7 +249,7 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
       if (64 * k < S && before < B) {
         unsigned long long fm = ~lv[k];
         if (S - 64 * k < 64) fm &= (1ull << (S - 64 * k)) - 1ull;
-        const int rk = before + __popcll(fm & ((1ull << lane) - 1ull));
+        const int rk = before + rs_below(fm);
         if (((fm >> lane) & 1ull) && rk < B) sdst[rk] = lane + 64 * k;
         before += __popcll(fm);
       }
@@ -344,7 +346,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     for (int k = 0; k < 4; ++k) {
       if (64 * k < S) {
         const bool on = (old[k] >> lane) & 1ull;
-        if (on) s_list[n + __popcll(old[k] & ((1ull << lane) - 1ull))] = (unsigned char)(lane + 64 * k);
+        if (on) s_list[n + rs_below(old[k])] = (unsigned char)(lane + 64 * k);
         n += __popcll(old[k]);
       }
     }
@@ -464,20 +466,19 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
              v2 = key2 != UIS_RS_NOKEY && key2 <= thr;
   const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
   const int n0 = __popcll(m0), n1 = __popcll(m1), nsv = n0 + n1 + __popcll(m2);
-  if (nsv <= 32) {
+  if (nsv <= 64) {
     uint32_t* sck = reinterpret_cast<uint32_t*>(scr + L.sc_ckey);
     int* sce = reinterpret_cast<int*>(scr + L.sc_ce);
     float* scs = reinterpret_cast<float*>(scr + L.sc_csc);
-    int* swe = reinterpret_cast<int*>(scr + L.sc_wine);
-    float* sws = reinterpret_cast<float*>(scr + L.sc_wins);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (v0) { const int q = __popcll(m0 & below); sck[q] = key0; sce[q] = lane; scs[q] = sc0; }
-    if (v1) { const int q = n0 + __popcll(m1 & below); sck[q] = key1; sce[q] = lane + 64; scs[q] = sc1; }
-    if (v2) { const int q = n0 + n1 + __popcll(m2 & below); sck[q] = key2; sce[q] = lane + 128; scs[q] = sc2; }
-    if (lane >= nsv && lane < 32) sck[lane] = UIS_RS_NOKEY;  // (beats nobody)
+    if (v0) { const int q = rs_below(m0); sck[q] = key0; sce[q] = lane; scs[q] = sc0; }
+    if (v1) { const int q = n0 + rs_below(m1); sck[q] = key1; sce[q] = lane + 64; scs[q] = sc1; }
+    if (v2) { const int q = n0 + n1 + rs_below(m2); sck[q] = key2; sce[q] = lane + 128; scs[q] = sc2; }
+    if (lane >= nsv) sck[lane] = UIS_RS_NOKEY;  // (beats nobody)
     rs_lds_fence();
     const bool mine = lane < nsv;
     const uint32_t ck = mine ? sck[lane] : UIS_RS_NOKEY;
+    const int ce = sce[lane];
+    const float cs = scs[lane];
     // every entry counts the entries that beat it: the list comes back sixteen keys at a time (the
     // same address in every lane: a broadcast); compaction kept the grid order, so an EARLIER entry
     // also wins a tie -- k_j <= ck, written k_j < ck + 1 (keys of finite scores are below all ones)
@@ -495,12 +496,15 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     };
     count16(0);
     if (nsv > 16) count16(16);
-    if (mine && rank < keep) { swe[rank] = sce[lane]; sws[rank] = scs[lane]; }
-    rs_lds_fence();
-    if (lane < keep) { win_e = swe[lane]; win_sc = sws[lane]; }
+    if (nsv > 32) { count16(32); if (nsv > 48) count16(48); }
+    // entry -> lane `rank` of the winners: a forward permute (the others send to lane 63, which is
+    // never a winner: keep <= 16)
+    const int to = (mine && rank < keep) ? rank : 63;
+    win_e = __builtin_amdgcn_ds_permute(to << 2, ce);
+    win_sc = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to << 2, __builtin_bit_cast(int, cs)));
   } else {
-    // (a long short list -- an early step, or a model that switches freely: `keep` rounds of the
-    // wave-wide minimum)
+    // (more than 64 survivors -- a model that switches freely, a beam not yet full: `keep` rounds of
+    // the wave-wide minimum)
     for (int r = 0; r < keep; ++r) {
       uint32_t loc = key0 < key1 ? key0 : key1;
       loc = loc < key2 ? loc : key2;
@@ -558,7 +562,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const bool is_lead = isw && lead == r;
   const unsigned long long lmask = __ballot(is_lead);
   const int nlead = __popcll(lmask);
-  const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
+  const int ord = rs_below(lmask);
   // (the ord-th free slot: rs_prep listed them)
   int dst = 0xffff, nprev = 0;
   if (is_lead) {
@@ -696,10 +700,10 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
   for (int k = 0; k < 4; ++k) {
     if (64 * k < S) {
       const unsigned long long mask = slive[k] & ~snew[k];
-      const int idx = before + __popcll(mask & ((1ull << lane) - 1ull));
+      const int idx = before + rs_below(mask);
       const bool mine = ((mask >> lane) & 1ull) && (idx & 31) == mine_mod;
       const unsigned long long mm = __ballot(mine);
-      if (mine) s_list[n + __popcll(mm & ((1ull << lane) - 1ull))] = lane + 64 * k;
+      if (mine) s_list[n + rs_below(mm)] = lane + 64 * k;
       n += __popcll(mm);
       before += __popcll(mask);
     }
