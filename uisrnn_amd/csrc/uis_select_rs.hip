@@ -43,6 +43,9 @@
 #define UIS_RS_MAXC 192     // grid positions: beam_size * (max_clusters + 1) (three per lane)
 #define UIS_RS_LOGTAB 128   // entries of the LDS copies of the log tables (larger counts: global)
 #define UIS_RS_NOKEY 0xffffffffu
+#if !defined(UIS_RS_FLAG_HANDOFF)
+#define UIS_RS_FLAG_HANDOFF 1  // GRU -> linear_mean1 -> linear_mean2 through per-producer phase words (0: cluster barriers)
+#endif
 
 struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
@@ -693,7 +696,10 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
   const int S = st.S, U = st.U;
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
-  int* s_list = reinterpret_cast<int*>(scr + L.sc_mse);  // (the front part's MSE area is free by now)
+  // (the list lives in rs_back's byte-flag area, free between two steps' table updates -- NOT in the
+  // wave's scratch: that aliases the split-K tiles, which a faster wave of this workgroup may
+  // already be writing for the next stage; slots are < 256)
+  unsigned char* s_list = const_cast<unsigned char*>(pers) + L.off_flag;
   int n = 0, before = 0;
   const int mine_mod = (rank + 4 * w) & 31;
 #pragma unroll
@@ -703,7 +709,7 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
       const int idx = before + rs_below(mask);
       const bool mine = ((mask >> lane) & 1ull) && (idx & 31) == mine_mod;
       const unsigned long long mm = __ballot(mine);
-      if (mine) s_list[n + rs_below(mm)] = lane + 64 * k;
+      if (mine) s_list[n + rs_below(mm)] = (unsigned char)(lane + 64 * k);
       n += __popcll(mm);
       before += __popcll(mask);
     }
@@ -723,7 +729,7 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
   float* tab = st.mse_tab + ((size_t)((step + 1) & 1) * U + u) * S;
   for (int i0 = 0; i0 < n; i0 += 4) {
     const int i = i0 + grp;
-    const int sl = s_list[i < n ? i : 0];
+    const int sl = (int)s_list[i < n ? i : 0];
     f32x4 mv[4];
     rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
     const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
@@ -776,6 +782,38 @@ __device__ __forceinline__ void rs_tile(const f32x4 (&wr)[NG][PER], const float*
   if (nvalid >= 3) rs_tile_nv<NG, PER, RC, 3, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
   else if (nvalid == 2) rs_tile_nv<NG, PER, RC, 2, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
   else rs_tile_nv<NG, PER, RC, 1, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+}
+
+// Hand-offs between dense stages without a cluster-wide barrier.  What a consumer wave reads in
+// linear_mean1 / linear_mean2 is ITS K-slice of every row -- 1/8 of the features, produced by four
+// of the cluster's 32 workgroups (ranks 4w .. 4w + 3 for wave w, whatever the hidden size: a rank's
+// feature tile is rank / SH1 and a wave's slice PER = NFT1 / 8 tiles).  So a producer, once its
+// stores have reached L2, publishes a phase word (2 step + 1 behind the GRU stage, 2 step + 2
+// behind linear_mean1) and a consumer wave polls the four words of its producers -- one 16-byte
+// load -- instead of everybody waiting for the slowest of 32 and for thread 0 to tell the rest.
+// The step's last hand-off stays a full barrier (the select needs every workgroup's output), which
+// is also what keeps a producer from overwriting a tile a slow consumer still reads.
+__device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint32_t phase) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rs_flag_wait(const DecodeState& st, __amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off, uint32_t phase) {
+  unsigned spins = 0;
+  for (;;) {
+    const u32x4 f = __builtin_bit_cast(u32x4, load_sc1(rs_flags, byte_off));
+    asm volatile("" ::: "memory");  // (a fresh load every round)
+    uint32_t mn = f[0] < f[1] ? f[0] : f[1];
+    mn = mn < f[2] ? mn : f[2];
+    mn = mn < f[3] ? mn : f[3];
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase) return;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device (the step's full barrier ends the launch)
+      __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  }
 }
 
 // The wait half of the in-launch barrier for a workgroup that has ARRIVED already (xcd_arrive: its
@@ -894,6 +932,10 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const __amdgpu_buffer_rsrc_t rs_hst =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
   float* const hst = st.gi_up;
+  // per-producer phase words of this cluster: the row-counter line of the owner-select kernel, unused here
+  uint32_t* const flags_c = reinterpret_cast<uint32_t*>(st.rx_nrows) + cluster * 32;
+  const __amdgpu_buffer_rsrc_t rs_flags =
+      __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
   uint32_t bar = 0;
@@ -1004,7 +1046,11 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
     xcd_arrive(st, cluster, s_ctl);
 #else
+#if UIS_RS_FLAG_HANDOFF
+    rs_flag_publish(flags_c, rank, 2u * (uint32_t)s + 1u);
+#else
     xcd_arrive(st, cluster, s_ctl);
+#endif
 #if !defined(UIS_RS_BACK_INLINE)
     if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
 #endif
@@ -1012,6 +1058,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
 #if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+#elif UIS_RS_FLAG_HANDOFF
+    if (nrt > tpar1) rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 2u * (uint32_t)s + 1u);
 #else
     if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
 #endif
@@ -1051,10 +1099,18 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     if (has_u && (long)s + 1 < T_w)
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
 #else
+#if UIS_RS_FLAG_HANDOFF
+    rs_flag_publish(flags_c, rank, 2u * (uint32_t)s + 2u);
+#else
     xcd_arrive(st, cluster, s_ctl);
+#endif
     if (has_u && (long)s + 1 < T_w)
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
+#if UIS_RS_FLAG_HANDOFF
+    if (nrt > tpar2) rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 2u * (uint32_t)s + 2u);
+#else
     if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+#endif
 #endif
 #if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
