@@ -788,17 +788,17 @@ __device__ __forceinline__ void rs_tile(const f32x4 (&wr)[NG][PER], const float*
 // linear_mean1 / linear_mean2 is ITS K-slice of every row -- 1/8 of the features, produced by four
 // of the cluster's 32 workgroups (ranks 4w .. 4w + 3 for wave w, whatever the hidden size: a rank's
 // feature tile is rank / SH1 and a wave's slice PER = NFT1 / 8 tiles).  So a producer, once its
-// stores have reached L2, publishes a phase word (2 step + 1 behind the GRU stage, 2 step + 2
-// behind linear_mean1) and a consumer wave polls the four words of its producers -- one 16-byte
-// load -- instead of everybody waiting for the slowest of 32 and for thread 0 to tell the rest.
-// The step's last hand-off stays a full barrier (the select needs every workgroup's output), which
-// is also what keeps a producer from overwriting a tile a slow consumer still reads.
+// stores have reached L2, publishes a phase word (3 step + 1 behind the GRU stage, + 2 behind
+// linear_mean1, + 3 behind linear_mean2) and a consumer wave polls the four words of its producers
+// -- one 16-byte load -- instead of everybody waiting for the slowest of 32 and for thread 0 to
+// tell the rest.  No atomic, no counter: a word has one writer.
 __device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint32_t phase) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void rs_flag_wait(const DecodeState& st, __amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off, uint32_t phase) {
+// true: gave up (a producer never published, or somebody else gave up)
+__device__ __forceinline__ bool rs_flag_wait(const DecodeState& st, __amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off, uint32_t phase) {
   unsigned spins = 0;
   for (;;) {
     const u32x4 f = __builtin_bit_cast(u32x4, load_sc1(rs_flags, byte_off));
@@ -806,13 +806,31 @@ __device__ __forceinline__ void rs_flag_wait(const DecodeState& st, __amdgpu_buf
     uint32_t mn = f[0] < f[1] ? f[0] : f[1];
     mn = mn < f[2] ? mn : f[2];
     mn = mn < f[3] ? mn : f[3];
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase) return;
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase) return false;
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device (the step's full barrier ends the launch)
+    if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
       __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
+      return true;
     }
-    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+  }
+}
+// ... and the step's last hand-off: the select needs every workgroup's partial sums and early MSEs,
+// so a wave waits for all 32 words (lane l < 32 looks at producer l's).  Passing it also means every
+// workgroup is through with the step's reads, which is what lets the next step overwrite the row
+// tiles and reuse freed slots.
+__device__ __forceinline__ bool rs_flag_wait_all(const DecodeState& st, const uint32_t* flags, uint32_t phase) {
+  const int lane = threadIdx.x & 63;
+  unsigned spins = 0;
+  for (;;) {
+    const uint32_t f = lane < 32 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : phase;
+    if (__ballot(f < phase) == 0ull) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 21)) {
+      __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
   }
 }
 
@@ -938,7 +956,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
-  uint32_t bar = 0;
+  uint32_t bar = 0;  // (cluster barriers passed: the UIS_RS_FLAG_HANDOFF 0 build)
+  (void)bar;
   long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
   float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * 32;  // this cluster's rows of partial sums
   int prev_base = 0;  // first row of this wave's utterance in the previous step's row list
@@ -974,6 +993,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       s_wnext[w] = off0_w + (fpos_w + 1 == N_w ? 0 : fpos_w + 1);  // (after the last step: some frame of the utterance, unused)
     }
     __syncthreads();
+#if UIS_RS_FLAG_HANDOFF
+    if (s_ctl[0]) return;  // a hand-off of the previous step gave up (cl_abort tells the host): all waves leave here
+#endif
     int base = 0, nrows = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int c = s_ctl[8 + k]; if (k < w) base += c; nrows += c; }
@@ -1047,7 +1069,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     xcd_arrive(st, cluster, s_ctl);
 #else
 #if UIS_RS_FLAG_HANDOFF
-    rs_flag_publish(flags_c, rank, 2u * (uint32_t)s + 1u);
+    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 1u);
 #else
     xcd_arrive(st, cluster, s_ctl);
 #endif
@@ -1059,7 +1081,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 #if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
 #elif UIS_RS_FLAG_HANDOFF
-    if (nrt > tpar1) rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 2u * (uint32_t)s + 1u);
+    if (nrt > tpar1 && rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 1u)) s_ctl[0] = 1;
 #else
     if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
 #endif
@@ -1100,14 +1122,14 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
 #else
 #if UIS_RS_FLAG_HANDOFF
-    rs_flag_publish(flags_c, rank, 2u * (uint32_t)s + 2u);
+    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 2u);
 #else
     xcd_arrive(st, cluster, s_ctl);
 #endif
     if (has_u && (long)s + 1 < T_w)
       rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
 #if UIS_RS_FLAG_HANDOFF
-    if (nrt > tpar2) rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 2u * (uint32_t)s + 2u);
+    if (nrt > tpar2 && rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 2u)) s_ctl[0] = 1;
 #else
     if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
 #endif
@@ -1175,9 +1197,17 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 #if defined(UIS_RS_SHADOW_BEFORE)
     if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
 #else
+#if UIS_RS_FLAG_HANDOFF
+    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 3u);
+#else
     xcd_arrive(st, cluster, s_ctl);
+#endif
     if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
+#if UIS_RS_FLAG_HANDOFF
+    if (rs_flag_wait_all(st, flags_c, 3u * (uint32_t)s + 3u)) s_ctl[0] = 1;  // (every wave, every step: see there)
+#else
     if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+#endif
 #endif
 #if defined(UIS_RS_SHADOW_BEFORE)
     if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
