@@ -43,9 +43,6 @@
 #define UIS_RS_MAXC 192     // grid positions: beam_size * (max_clusters + 1) (three per lane)
 #define UIS_RS_LOGTAB 128   // entries of the LDS copies of the log tables (larger counts: global)
 #define UIS_RS_NOKEY 0xffffffffu
-#if !defined(UIS_RS_FLAG_HANDOFF)
-#define UIS_RS_FLAG_HANDOFF 1  // GRU -> linear_mean1 -> linear_mean2 through per-producer phase words (0: cluster barriers)
-#endif
 
 struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
@@ -215,10 +212,10 @@ struct RsPrep {
   float bs0, bs1, bs2;
 };
 
-template <bool FULL = false>
+template <bool FULL = false, typename Mid>
 __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& st, const RsLds& L, int step,
                                           const unsigned char* pers, unsigned char* scr, const double* s_lblk,
-                                          const double* s_lden) {
+                                          const double* s_lden, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
@@ -294,6 +291,7 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
       }
     }
   };
+  mid();  // (the caller's early load)
   prep_at(lane, 0, P.cslot0, P.pr0, P.bs0);
   if (P.nch > 1) prep_at(lane + 64, 1, P.cslot1, P.pr1, P.bs1);
   if (P.nch > 2) prep_at(lane + 128, 2, P.cslot2, P.pr2, P.bs2);
@@ -587,8 +585,9 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 
 // BACK: the next step's tables, masks and counts, the back-pointers -- nothing anybody waits for.
 // `owner`: this workgroup writes what outlives the step to memory.
+template <typename Mid>
 __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long off0,
-                                        unsigned char* pers, bool owner, const RsWin& w) {
+                                        unsigned char* pers, bool owner, const RsWin& w, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
@@ -656,6 +655,7 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
     snewlist[1 + w.ord()] = dst;
   }
   rs_lds_fence();
+  mid();  // (the caller's early load: about a round trip of work is left)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (64 * k < S) {
@@ -686,10 +686,10 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
 // utterance round robin (every workgroup holds the same masks), so each wave computes at most a
 // handful, in one round trip, between the arrival at the barrier behind the GRU stage and the wait
 // (it needs nobody else's data of this step: those means were final a step ago).
-template <int DP>
+template <int DP, typename Mid>
 __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step,
                                              long frame_next, const unsigned char* pers, unsigned char* scr, const float* swgt,
-                                             int rank, int w) {
+                                             int rank, int w, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
@@ -714,6 +714,7 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
       before += __popcll(mask);
     }
   }
+  mid();  // (the caller's early load: queued ahead of the means)
   if (n == 0) return;
   rs_lds_fence();
   const __amdgpu_buffer_rsrc_t rs_mean =
@@ -797,6 +798,22 @@ __device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint3
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The first look at the phase words, split in two so that the load can be requested early (from
+// inside the work a wave does between publishing and waiting) and examined late.
+__device__ __forceinline__ u32x4 rs_flag_peek4(__amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off) {
+  return __builtin_bit_cast(u32x4, load_sc1(rs_flags, byte_off));
+}
+__device__ __forceinline__ bool rs_flag_ready4(const u32x4& f, uint32_t phase) {
+  uint32_t mn = f[0] < f[1] ? f[0] : f[1];
+  mn = mn < f[2] ? mn : f[2];
+  mn = mn < f[3] ? mn : f[3];
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase;
+}
+__device__ __forceinline__ uint32_t rs_flag_peek_all(const uint32_t* flags) {
+  const int lane = threadIdx.x & 63;
+  return __hip_atomic_load(flags + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool rs_flag_ready_all(uint32_t f, uint32_t phase) { return __ballot(f < phase) == 0ull; }
 // true: gave up (a producer never published, or somebody else gave up)
 __device__ __forceinline__ bool rs_flag_wait(const DecodeState& st, __amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off, uint32_t phase) {
   unsigned spins = 0;
@@ -956,8 +973,6 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
-  uint32_t bar = 0;  // (cluster barriers passed: the UIS_RS_FLAG_HANDOFF 0 build)
-  (void)bar;
   long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
   float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * 32;  // this cluster's rows of partial sums
   int prev_base = 0;  // first row of this wave's utterance in the previous step's row list
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   unsigned long long ft_acc[4] = {0, 0, 0, 0}, rt_prev2 = rt_prev;
 #endif
 
-  RsPrep prep = rs_prep(m, st, L, 0, pers_w, scr_w, s_lblk, s_lden);  // (later steps: inside the previous step's last barrier)
+  RsPrep prep = rs_prep(m, st, L, 0, pers_w, scr_w, s_lblk, s_lden, []() {});  // (later steps: inside the previous step's last hand-off)
   for (int s = 0; s < nsteps; ++s) {
     // ---- select, replicated: wave w decides utterance slot w; every workgroup gets the same rows
     RsWin win;
@@ -983,9 +998,6 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, prep, nullptr);
 #endif
     }
-#if defined(UIS_RS_BACK_INLINE)  // diagnostic: the back part on the critical path, straight after the front part
-    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
-#endif
     RSTAMP(0);
     if (lane == 0) {
       s_ctl[8 + w] = win.nlead;
@@ -993,9 +1005,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       s_wnext[w] = off0_w + (fpos_w + 1 == N_w ? 0 : fpos_w + 1);  // (after the last step: some frame of the utterance, unused)
     }
     __syncthreads();
-#if UIS_RS_FLAG_HANDOFF
     if (s_ctl[0]) return;  // a hand-off of the previous step gave up (cl_abort tells the host): all waves leave here
-#endif
     int base = 0, nrows = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int c = s_ctl[8 + k]; if (k < w) base += c; nrows += c; }
@@ -1062,29 +1072,20 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       }
     }
     RSTAMP(2);
-    // arrive; then the select's back part (the next step's tables and masks: nothing anybody waits
-    // for, and the wait is idle time for every wave); then wait
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
-    xcd_arrive(st, cluster, s_ctl);
-#else
-#if UIS_RS_FLAG_HANDOFF
-    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 1u);
-#else
-    xcd_arrive(st, cluster, s_ctl);
-#endif
-#if !defined(UIS_RS_BACK_INLINE)
-    if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win);
-#endif
-#endif
-    if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-#elif UIS_RS_FLAG_HANDOFF
-    if (nrt > tpar1 && rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 1u)) s_ctl[0] = 1;
-#else
-    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
-#endif
+    // publish; then the select's back part (the next step's tables and masks: nothing anybody waits
+    // for); the first look at the producers' words is requested from inside it, so that its round
+    // trip is over when the wave gets there; then wait
+    {
+      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 1u);
+      u32x4 pk = u32x4{0u, 0u, 0u, 0u};
+      auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
+      if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win, peek);
+      else peek();
+      if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
+      if (nrt > tpar1 && !rs_flag_ready4(pk, 3u * (uint32_t)s + 1u) &&
+          rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 1u))
+        s_ctl[0] = 1;
+    }
     if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
     if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
@@ -1115,28 +1116,18 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       }
     }
     RSTAMP(4);
-    // arrive; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
-    // its share of every utterance's; visible to all behind the step's last barrier); then wait
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (has_u && (long)s + 1 < T_w)
-      rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
-#else
-#if UIS_RS_FLAG_HANDOFF
-    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 2u);
-#else
-    xcd_arrive(st, cluster, s_ctl);
-#endif
-    if (has_u && (long)s + 1 < T_w)
-      rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w);
-#if UIS_RS_FLAG_HANDOFF
-    if (nrt > tpar2 && rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 2u)) s_ctl[0] = 1;
-#else
-    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
-#endif
-#endif
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-#endif
+    // publish; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
+    // its share of every utterance's; visible to all behind the step's last hand-off); then wait
+    {
+      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 2u);
+      u32x4 pk = u32x4{0u, 0u, 0u, 0u};
+      auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
+      if (has_u && (long)s + 1 < T_w) rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w, peek);
+      else peek();
+      if (nrt > tpar2 && !rs_flag_ready4(pk, 3u * (uint32_t)s + 2u) &&
+          rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 2u))
+        s_ctl[0] = 1;
+    }
     RSTAMP(5);
 
     // ---- linear_mean2 + running mean -> dst slot
@@ -1193,25 +1184,16 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       }
     }
     RSTAMP(6);
-    // arrive; then the next step's candidate grid (this wave's own tables: nobody else's data); then wait
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
-#else
-#if UIS_RS_FLAG_HANDOFF
-    rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 3u);
-#else
-    xcd_arrive(st, cluster, s_ctl);
-#endif
-    if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden);
-#if UIS_RS_FLAG_HANDOFF
-    if (rs_flag_wait_all(st, flags_c, 3u * (uint32_t)s + 3u)) s_ctl[0] = 1;  // (every wave, every step: see there)
-#else
-    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
-#endif
-#endif
-#if defined(UIS_RS_SHADOW_BEFORE)
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-#endif
+    // publish; then the next step's candidate grid (this wave's own tables: nobody else's data); then
+    // wait -- every wave, every step, for all 32 producers (rs_flag_wait_all)
+    {
+      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 3u);
+      uint32_t pk = 0u;
+      auto peek = [&]() { pk = rs_flag_peek_all(flags_c); };
+      if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden, peek);
+      else peek();
+      if (!rs_flag_ready_all(pk, 3u * (uint32_t)s + 3u) && rs_flag_wait_all(st, flags_c, 3u * (uint32_t)s + 3u)) s_ctl[0] = 1;
+    }
     RSTAMP(7);
   }
 #if defined(UIS_RESIDENT_TIMING)
