@@ -395,6 +395,19 @@ def test_random_weights_many_clusters(oracle_lib):
   assert ref['max_clusters'].max() > 16
 
 
+def test_free_switching_model_on_the_one_launch_decode(oracle_lib):
+  """The single-wave select's prune keeps what scores at or below the worst 'stay' candidate; a
+  model that switches speakers as readily as it stays (transition_bias 0.5, a flat observation
+  noise) leaves long short lists -- beyond 16, 32 and 64 survivors: every counting pass of the
+  short list and the fall-back rounds -- with beam 16 and 8 utterances per cluster."""
+  from uisrnn_amd import weights  # pylint: disable=import-outside-toplevel
+  for seed, sigma2, alpha in ((21, 4.0, 1.0), (22, 0.5, 8.0), (23, 50.0, 0.3)):
+    params = weights.init_params(256, 512, 1, sigma2=sigma2, transition_bias=0.5, crp_alpha=alpha, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    seqs = [0.3 * rng.standard_normal((n, 256)) for n in (60, 48, 33, 60, 7, 52, 41, 60, 29)]
+    _compare(params, seqs, 16, 1, 2, oracle_lib)
+
+
 def test_cluster_cap_is_reported(oracle_lib):
   params, rng = _many_cluster_case()
   seqs = [rng.standard_normal((40, 64)), rng.standard_normal((3, 64))]

@@ -994,6 +994,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
             (double)tc[80] / (double)maxT, (double)tc[81] / (double)maxT, (double)tc[82] / (double)maxT, (double)tc[83] / (double)maxT);
   }
 #endif
+#if defined(UIS_RS_COUNT_PATHS)
+  if (rs) {
+    unsigned long long tc[96];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[rs short lists] selects with <= 16 / <= 32 / <= 64 / more survivors: %llu %llu %llu %llu\n", tc[88], tc[89], tc[90], tc[91]);
+  }
+#endif
 #if defined(UIS_RESIDENT_TIMING)
   if (resident) {
     unsigned long long tc[88];

@@ -6,30 +6,33 @@
 // and arithmetic rules as select_fast_body; results are bit-identical (tests/test_gpu_parity.py
 // runs this path, the owner-select path and the launch-per-step path against the oracle).
 //
-// Why.  A decode step is a latency chain, not a throughput problem: with one workgroup per
-// utterance running the select (k_decode_resident) a step crosses the XCD four times -- select ->
-// GRU -> linear_mean1 -> linear_mean2 -> select -- and the first crossing alone (row descriptors
-// published, barrier, descriptors staged) costs ~2.4 us on top of a 6 us select that 24 of the 32
-// CUs sit out.  Here EVERY workgroup of an XCD keeps the beam tables of all of the cluster's (at
-// most 8) utterances in LDS and wave w decides utterance w, so the step's row list exists in every
-// workgroup without being exchanged: three hand-offs per step, no row reservation, no descriptor
-// staging.  What makes that affordable is a select whose critical path is short enough for one
-// wave:
+// Why.  All utterances advance in lock-step and a step needs the step before it: with one
+// workgroup per utterance running the select (k_decode_resident) a step crosses the XCD four times
+// -- select -> GRU -> linear_mean1 -> linear_mean2 -> select -- and the first crossing alone (row
+// descriptors published, barrier, descriptors staged) costs ~2.4 us on top of a 6 us select that
+// 24 of the 32 CUs sit out.  Here EVERY workgroup of an XCD keeps the beam tables of all of the
+// cluster's (at most 8) utterances in LDS and wave w decides utterance w, so the step's row list
+// exists in every workgroup without being exchanged: three hand-offs per step, no row reservation,
+// no descriptor staging.  What makes that affordable is a select that fits one wave:
 //   * its only heavy input -- the weighted MSE of the frame against every live cluster mean --
 //     arrives as one float per cluster for the clusters the previous step did not rewrite (the
-//     utterance's owner rank computes them one step ahead, inside the barrier after the GRU stage:
-//     mse_tab, double buffered by step parity) and is computed by the wave itself only for the at
-//     most beam_size clusters the previous step DID rewrite; everything is requested in one round
-//     trip;
-//   * the prior terms come from LDS (log tables; per-hypothesis log denominators are stored with
-//     the tables when a hypothesis is created);
-//   * candidates sit on a (hypothesis, cluster) grid -- no prefix sums, no candidate table;
-//   * the prune is `keep` rounds of a wave-wide minimum over 32-bit order-preserving score keys
-//     (DPP row reduction + four readlanes), ties to the lowest grid position = the lowest
-//     (hypothesis, cluster) -- the order of the 64-bit keys of select_fast_body;
-//   * everything nobody waits for -- the next step's tables, live masks, back-pointers -- runs
-//     AFTER the GRU stage's operand loads are in flight (rs_back, called from the dense stage's
-//     after-issue hook).
+//     cluster's workgroups compute them one step ahead, round robin, between two stages: mse_tab,
+//     double buffered by step parity) and as sixteen tile sums for the at most beam_size clusters
+//     the previous step DID rewrite (emitted by the linear_mean2 epilogue that wrote the new
+//     mean: mse_part); everything is requested in one round trip (rs_front_loads);
+//   * the prior terms come from LDS (log tables), the candidate grid -- position b * Kcur + c, no
+//     prefix sums, no candidate table -- is prepared a step ahead (rs_prep);
+//   * the prune keeps what scores at or below the worst "stay" candidate (a wave-wide maximum by
+//     DPP), compacts the survivors in grid order and lets every survivor count the ones that beat
+//     it against broadcast LDS reads of the list; ties go to the lowest grid position = the
+//     lowest (hypothesis, cluster), the order of the 64-bit keys of select_fast_body; row
+//     de-duplication is an LDS minimum per source slot -- no cross-lane loops anywhere;
+//   * everything nobody waits for -- the next step's tables, live masks, back-pointers (rs_back),
+//     the early MSEs, the next candidate grid -- runs between a stage's publishing its output and
+//     the wave's first look at its producers' phase words;
+//   * the stages hand over through per-producer phase words, not barriers (rs_flag_publish /
+//     rs_flag_wait): a consumer wave polls the four workgroups that produce its K-slice, the
+//     step's last hand-off all 32.
 #pragma once
 
 // 1: k_decode_rs is the default wherever it applies (UIS_FLAG_OWNER_SELECT keeps k_decode_resident);
@@ -467,6 +470,9 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
              v2 = key2 != UIS_RS_NOKEY && key2 <= thr;
   const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
   const int n0 = __popcll(m0), n1 = __popcll(m1), nsv = n0 + n1 + __popcll(m2);
+#if defined(UIS_RS_COUNT_PATHS)  // diagnostic: how long the short lists are (workgroup 0's copies; uis_decoder.hip prints them)
+  if (!FULL && blockIdx.x == 0 && lane == 0) atomicAdd(&st.counters[88 + (nsv <= 16 ? 0 : nsv <= 32 ? 1 : nsv <= 64 ? 2 : 3)], 1ull);
+#endif
   if (nsv <= 64) {
     uint32_t* sck = reinterpret_cast<uint32_t*>(scr + L.sc_ckey);
     int* sce = reinterpret_cast<int*>(scr + L.sc_ce);
