@@ -90,7 +90,12 @@ struct Scratch {
 #define UIS_WINDOW_WIDE_NT 512   // (1024 measured the same)
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
 #define UIS_STREAM_RESIDENT_MIN_STEPS 4  // uis_stream_push: steps per push from which the one-launch kernel is used
-#define UIS_H2D_CHUNKS 4     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection
+#ifndef UIS_H2D_CHUNKS
+#define UIS_H2D_CHUNKS 2     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection (1 / 2 / 3 / 4 pieces measured: 1.505 / 1.517 / 1.424 / 1.43 M frames/s from pinned buffers at configs[1])
+#endif
+#ifndef UIS_H2D_MIN_FRAMES
+#define UIS_H2D_MIN_FRAMES 4096  // ... of at least this many frames each
+#endif
 
 struct GraphCache {
   hipGraphExec_t exec = nullptr;
@@ -777,7 +782,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     ~Drain() { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
   } drain_on_exit{h};
   if (F > 0 && h_frames) {
-    const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / 4096));
+    const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / UIS_H2D_MIN_FRAMES));
     while ((int)h->h2d_done.size() < n_chunks) {
       hipEvent_t e;
       HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
