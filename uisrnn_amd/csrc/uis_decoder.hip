@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -479,11 +480,40 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
   return UIS_OK;
 }
 
-// float64 -> float32 of rows [f0, f1) of the packed frame matrix, read from the caller's
-// per-utterance arrays (the reference casts once with torch's .float(), round to nearest even,
-// uisrnn/uisrnn.py:524-526; so does a C++ double -> float conversion), by a few host threads.
-void cast_rows(const double* const* utt, const int64_t* offsets, int n_utt, int D, int64_t f0, int64_t f1, float* dst) {
-  auto work = [&](int64_t r0, int64_t r1) {
+// float64 -> float32 of the packed frame matrix, read from the caller's per-utterance arrays (the
+// reference casts once with torch's .float(), round to nearest even, uisrnn/uisrnn.py:524-526; so
+// does a C++ double -> float conversion), by a few host threads -- one team for a whole decode:
+// the threads are started once and take blocks of rows in order; the caller asks for a prefix of the
+// rows (`wait_rows`), helping with blocks while it waits, and hands each finished piece to the copy
+// engine while the team is already in the next.
+struct CastTeam {
+  static constexpr int64_t kBlockRows = 512;
+  const double* const* utt; const int64_t* offsets; int n_utt, D; int64_t F; float* dst;
+  int64_t nblocks = 0;
+  std::atomic<int64_t> next{0};
+  std::vector<std::atomic<unsigned char>> done;
+  std::vector<std::thread> pool;
+  CastTeam(const double* const* utt_, const int64_t* offsets_, int n_utt_, int D_, int64_t F_, float* dst_)
+      : utt(utt_), offsets(offsets_), n_utt(n_utt_), D(D_), F(F_), dst(dst_), nblocks((F_ + kBlockRows - 1) / kBlockRows),
+        done((size_t)((F_ + kBlockRows - 1) / kBlockRows)) {
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(1, F * D / (1 << 17)));  // >= 1 MB of input per thread
+    try {
+      pool.reserve(nt);
+      for (unsigned k = 1; k < nt; ++k) pool.emplace_back([this]() { while (take()) {} });
+    } catch (...) {  // no more threads to be had: the caller's thread does what is left (wait_rows)
+    }
+  }
+  bool take() {  // one block, if there is one left
+    const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
+    if (b >= nblocks) return false;
+    cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows));
+    done[(size_t)b].store(1, std::memory_order_release);
+    return true;
+  }
+  void cast_block(int64_t r0, int64_t r1) {
     int u = (int)(std::upper_bound(offsets, offsets + n_utt + 1, r0) - offsets) - 1;  // the utterance holding row r0
     for (int64_t r = r0; r < r1;) {
       while (offsets[u + 1] <= r) ++u;  // (empty utterances)
@@ -494,23 +524,17 @@ void cast_rows(const double* const* utt, const int64_t* offsets, int n_utt, int 
       for (int64_t i = 0; i < n; ++i) d[i] = (float)src[i];
       r = e;
     }
-  };
-  const int64_t rows = f1 - f0;
-  unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
-  if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-  nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(1, rows * D / (1 << 17)));  // >= 1 MB of input per thread
-  if (nt <= 1) { work(f0, f1); return; }
-  std::vector<std::thread> pool;
-  unsigned started = 1;  // share 0 is this thread's
-  try {
-    pool.reserve(nt);
-    for (; started < nt; ++started) pool.emplace_back(work, f0 + rows * started / nt, f0 + rows * (started + 1) / nt);
-  } catch (...) {  // no more threads to be had: the shares that did not start are done here
   }
-  work(f0, f0 + rows / nt);
-  for (unsigned k = started; k < nt; ++k) work(f0 + rows * k / nt, f0 + rows * (k + 1) / nt);
-  for (auto& th : pool) th.join();
-}
+  void wait_rows(int64_t f1) {  // rows [0, f1) are cast when this returns
+    const int64_t b1 = (f1 + kBlockRows - 1) / kBlockRows;
+    for (int64_t b = 0; b < b1; ++b)
+      while (!done[(size_t)b].load(std::memory_order_acquire))
+        if (!take()) std::this_thread::yield();
+  }
+  ~CastTeam() {
+    for (auto& th : pool) th.join();
+  }
+};
 
 int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, int32_t n_utt,
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats,
@@ -789,9 +813,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       h->h2d_done.push_back(e);
     }
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
+    std::unique_ptr<CastTeam> team;  // (float64 utterances: cast into the pinned staging buffer, piece c+1 while piece c copies / projects)
+    if (h->src64) team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast));
     for (int c = 0; c < n_chunks; ++c) {
       const int64_t f0 = F * c / n_chunks, f1 = F * (c + 1) / n_chunks;
-      if (h->src64) cast_rows(h->src64, offsets, n_utt, m.D, f0, f1, h->h_cast);  // (while chunk c-1 copies / projects)
+      if (team) team->wait_rows(f1);
       HIPCHK(hipMemcpyAsync(const_cast<float*>(d_frames) + (size_t)f0 * m.D, h_frames + (size_t)f0 * m.D,
                             (size_t)(f1 - f0) * m.D * 4, hipMemcpyHostToDevice, h->copy_stream));
       HIPCHK(hipEventRecord(h->h2d_done[c], h->copy_stream));
