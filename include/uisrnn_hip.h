@@ -133,6 +133,10 @@ typedef struct uis_decode_opts {
                                     placement had changed.  The call must then fall back to the
                                     launch-per-step path by itself -- and stay there for this
                                     handle -- or, with UIS_FLAG_RESIDENT, fail with UIS_ERR_HIP */
+#define UIS_FLAG_TEST_STALL 0x4000u /* test hook (k_decode_rs): one workgroup stops publishing its phase
+                                    word after a few steps, as if it had died.  The waves that wait for
+                                    it give up after ~1 s, the launch ends, and the call falls back to
+                                    the launch-per-step path (with UIS_FLAG_RESIDENT: UIS_ERR_HIP) */
 #define UIS_FLAG_PROFILE    0x4u /* launch every kernel with start/stop HIP events on the
                                     decode stream (hipExtLaunchKernelGGL: the dispatch's
                                     own begin/end timestamps) and fill uis_stats.kernel_* */

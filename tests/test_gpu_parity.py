@@ -256,6 +256,30 @@ def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):
                                  flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_TEST_MISPLACED)
 
 
+def test_one_launch_decode_gives_up_on_a_silent_workgroup(oracle_lib):
+  """The hand-offs of k_decode_rs are polls of words other workgroups write; UIS_FLAG_TEST_STALL
+  makes one workgroup stop writing its word after three steps.  The waves that wait for it must give
+  up (about a second), every workgroup must leave the launch, and the call must come back with the
+  launch-per-step path's answer -- or, when the one-launch decode was demanded, with an error."""
+  import time
+  params = synth.tracker_params(256, 512, 1, seed=9)
+  seqs, _ = synth.make_utterances(9150, 10, [40, 12, 33, 64, 5, 21, 50, 17, 30, 8], 256)
+  ref = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=8)
+  frames, offsets = oracle_lib.pack(seqs)
+  dec = _capi.Decoder(params)
+  t0 = time.time()
+  out = dec.decode(frames, offsets, 10, 1, 2, flags=_capi.UIS_FLAG_TEST_STALL, want_beam_scores=True)
+  assert time.time() - t0 < 20.0
+  assert out['status'] == 0
+  for u in range(len(seqs)):
+    assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u])
+  assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  st = dec.decode(frames, offsets, 10, 1, 2, flags=_capi.UIS_FLAG_PROFILE)['stats']
+  assert st['kernel_launches']['select'] > 0          # this handle now stays on the per-step path
+  with pytest.raises(_capi.HipLibraryError, match='timed out'):
+    _capi.Decoder(params).decode(frames, offsets, 10, 1, 2, flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_TEST_STALL)
+
+
 def test_quirk7_zero_first_difference_on_the_device(oracle_lib):
   """weighted_mse_loss returns inf when the FIRST squared difference is exactly 0
   (uisrnn/loss_func.py:36,41: nnz counts the first column only).  Engineered on the decode

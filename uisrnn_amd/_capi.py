@@ -32,6 +32,7 @@ UIS_FLAG_GENERIC_SELECT = 0x8
 UIS_FLAG_RESIDENT = 0x40
 UIS_FLAG_STEPWISE = 0x80
 UIS_FLAG_TEST_MISPLACED = 0x100
+UIS_FLAG_TEST_STALL = 0x4000
 UIS_FLAG_SMALL_TILES = 0x200
 UIS_FLAG_PERSISTENT = 0x400
 UIS_FLAG_OWNER_SELECT = 0x800

@@ -977,6 +977,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   uint32_t* const flags_c = reinterpret_cast<uint32_t*>(st.rx_nrows) + cluster * 32;
   const __amdgpu_buffer_rsrc_t rs_flags =
       __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
+  // UIS_FLAG_TEST_STALL: one workgroup publishes phases below 8 only (it goes silent after two steps)
+  const uint32_t live_mask = ((st.flags & 0x4000u) != 0u && cluster == 0 && rank == 5) ? 7u : 0xffffffffu;
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
   long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // for); the first look at the producers' words is requested from inside it, so that its round
     // trip is over when the wave gets there; then wait
     {
-      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 1u);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 1u) & live_mask);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
       if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win, peek);
@@ -1125,7 +1127,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // publish; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
     // its share of every utterance's; visible to all behind the step's last hand-off); then wait
     {
-      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 2u);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 2u) & live_mask);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
       if (has_u && (long)s + 1 < T_w) rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w, peek);
@@ -1193,7 +1195,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // publish; then the next step's candidate grid (this wave's own tables: nobody else's data); then
     // wait -- every wave, every step, for all 32 producers (rs_flag_wait_all)
     {
-      rs_flag_publish(flags_c, rank, 3u * (uint32_t)s + 3u);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 3u) & live_mask);
       uint32_t pk = 0u;
       auto peek = [&]() { pk = rs_flag_peek_all(flags_c); };
       if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden, peek);
