@@ -45,12 +45,12 @@ def up_to_date():
   return all(os.path.getmtime(d) <= out_m for d in DEPENDS)
 
 
-def build(force=False, verbose=False, defines=(), output=None):
-  """Compile the library.  `defines` / `output` build tuning variants for A/B runs."""
+def build(force=False, verbose=False, defines=(), output=None, extra_flags=()):
+  """Compile the library.  `defines` / `output` / `extra_flags` build tuning variants for A/B runs."""
   output = output or OUTPUT
   if output == OUTPUT and not force and up_to_date():
     return OUTPUT
-  cmd = [hipcc()] + FLAGS + ['-D' + d for d in defines] + [
+  cmd = [hipcc()] + FLAGS + list(extra_flags) + ['-D' + d for d in defines] + [
       '-I', os.path.join(_ROOT, 'include'), '-I', os.path.join(_HERE, 'csrc'),
   ] + SOURCES + ['-o', output]
   if verbose:
