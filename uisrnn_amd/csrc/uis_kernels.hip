@@ -1168,6 +1168,18 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {  //
   return __ffsll((long long)mask) - 1;
 }
 
+// inclusive prefix sum over the wave: row_shr 1, 2, 4, 8 inside each row of 16 lanes (zeros shifted
+// in), then the totals of the rows before this one
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+
 struct FastLds {
   int off_wgt, off_slot, off_blk, off_K, off_last, off_sum, off_score, off_nb, set_stride;
   int off_base, off_live, off_livelist, off_mse, off_cnt, off_key, off_win, off_wscore, off_misc, off_pcnt, off_cand;
@@ -1345,16 +1357,11 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const long frame = st.foff ? (long)st.foff[u] + step : off0 + (step % N);
   if (PARTS & 1) {
     // candidate offsets: exclusive scan of K_b + 1 over the beam, by wave 0 (B <= 64)
-    if (wave == 0) {  // nb readlane broadcasts (scalar path) instead of a log-step shuffle scan
+    if (wave == 0) {  // DPP row scans + three row totals (a readlane broadcast per hypothesis cost nb scalar round trips)
       const int v = lane < nb ? myK + 1 : 0;
-      int excl = 0, total = 0;
-      for (int j2 = 0; j2 < nb; ++j2) {
-        const int kj = __builtin_amdgcn_readlane(v, j2);
-        if (lane > j2) excl += kj;
-        total += kj;
-      }
-      if (lane < nb) sbase[lane] = excl;
-      if (lane == 0) sbase[nb] = total;
+      const int incl = wave_incl_scan_i32(v);
+      if (lane < nb) sbase[lane] = incl - v;
+      if (lane == 63) sbase[nb] = incl;
     }
     __syncthreads();  // (1) tables staged
     TSTAMP(0);
@@ -1574,10 +1581,14 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   }
   int lead = r;
   if (!nodedup) {
-    for (int r2 = keep - 1; r2 >= 0; --r2) {  // lowest rank with the same source wins
-      const int s2 = __builtin_amdgcn_readlane(src, r2);
-      if (isw && s2 == src) lead = r2;
-    }
+    // lowest rank with the same source wins: an LDS minimum per source slot, in the MSE area (dead
+    // since the scores) -- every winner resets its cell first; one wave, LDS in program order
+    uint32_t* cell = src >= 0 ? reinterpret_cast<uint32_t*>(smse) + src : reinterpret_cast<uint32_t*>(smisc) + 4;
+    if (isw) *cell = 0xffffffffu;
+    asm volatile("" ::: "memory");
+    if (isw) __hip_atomic_fetch_min(cell, (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    asm volatile("" ::: "memory");
+    if (isw) lead = (int)*cell;
   }
   const bool is_lead = isw && lead == r;
   const unsigned long long lmask = __ballot(is_lead);
