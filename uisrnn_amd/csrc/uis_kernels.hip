@@ -1163,11 +1163,10 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
 // ballots and shuffles, and the row-counter atomic is issued as soon as the row count is known
 // so its round trip overlaps the table writes.
 
-__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {  // n-th (0-based) set bit
-  for (int i = 0; i < n; ++i) mask &= mask - 1;
-  return __ffsll((long long)mask) - 1;
+// set bits of a wave mask below this lane (v_mbcnt: two instructions)
+__device__ __forceinline__ int wave_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-
 // inclusive prefix sum over the wave: row_shr 1, 2, 4, 8 inside each row of 16 lanes (zeros shifted
 // in), then the totals of the rows before this one
 __device__ __forceinline__ int wave_incl_scan_i32(int v) {
@@ -1593,22 +1592,27 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
   const bool is_lead = isw && lead == r;
   const unsigned long long lmask = __ballot(is_lead);
   const int nlead = __popcll(lmask);
-  const int ord = __popcll(lmask & ((1ull << lane) - 1ull));
+  const int ord = wave_below(lmask);
   // reserve the rnn rows now; the returned position is needed only at the very end
   int row_base = 0;
   if (lane == 0) row_base = atomicAdd(sink.count, nlead);
-  // the ord-th free slot (not referenced by the current beam), in slot order
+  // the ord-th free slot (not referenced by the current beam), in slot order: every free slot knows
+  // its own rank among the free ones (bits below it + the chunks before) and files itself under it
+  // (in the key area, dead since the ranking; the other waves still read the winners' list)
   int dst = -1;
   {
-    int want = is_lead ? ord : -1;
-    for (int base = 0; base < S; base += 64) {
+    int* sfree = reinterpret_cast<int*>(skey);
+    int before = 0;
+    for (int base = 0; base < S && before < nlead; base += 64) {
       const int sl = base + lane;
-      const unsigned long long fm = __ballot(sl < S && slive[sl] == 0);
-      const int cnt = __popcll(fm);
-      if (want >= 0 && want < cnt) { dst = base + nth_set_bit(fm, want); want = -1; }
-      else if (want >= cnt) want -= cnt;
-      if (__ballot(want >= 0) == 0ull) break;
+      const bool fr = sl < S && slive[sl] == 0;
+      const unsigned long long fm = __ballot(fr);
+      const int rk = before + wave_below(fm);
+      if (fr && rk < nlead) sfree[rk] = sl;
+      before += __popcll(fm);
     }
+    asm volatile("" ::: "memory");
+    if (is_lead && ord < before) dst = sfree[ord];
   }
   {
     const int dl = __shfl(dst, lead, 64);
