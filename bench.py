@@ -22,22 +22,27 @@ run when fewer than N HIP devices are visible.  Every rank pins itself to its sh
 host cores (the library's float64 -> float32 cast threads follow the affinity mask).
 
 What the ONE JSON line (rank 0) says, field by field:
-  value                 frames/s of the whole job with the frame stream and the label buffer
-                        resident in HBM when the clock starts (the bench contract's definition);
-                        value_device is the same number under an explicit name
-  value_host_buffers    the same passes through uis_decode from PINNED float32 host memory:
-                        H2D of the frames and D2H of the labels inside the clock
-  value_predict_f64     the same passes through uis_decode_f64 from the list of float64 arrays
-                        UISRNN.predict receives (cast + H2D + decode + D2H inside the clock)
+  value                 frames/s of the whole job through the entry UISRNN.predict uses
+                        (uis_decode_f64: the list of float64 arrays the caller holds; cast + H2D of
+                        the frames + decode + D2H of the labels inside the clock) -- the quantity
+                        SURVEY.md 8(d) defines, on EVERY rank when N > 1.  `--timed` picks another
+                        leg for the timed region (profiling); the line says which (`value_leg`)
+  value_predict_f64     the same number under an explicit name
+  value_host_buffers    the same passes through uis_decode from PINNED float32 host memory
+                        (H2D of the frames and D2H of the labels inside the clock)
+  value_device          the same passes with the frame stream and the label buffer resident in
+                        HBM when the clock starts (uis_decode_device): no PCIe in the clock
   setup_passes/_ms      untimed decodes before the warm-up (cluster cap, control-word placement)
   per_rank_ms           min / max over ranks of a rank's own time per step
-  roofline              the dominant kernel, timed with HIP events on the decode stream:
+  roofline              the dominant kernel (named by the library: uis_stats.decode_kernel), timed
+                        with HIP events on the decode stream:
                         `frac` = what the MFMA pipes EXECUTED (rows after de-duplication) / peak,
                         never above 1; `effective` = the algorithmic rows (one CoreRNN step per
                         surviving hypothesis) / peak -- de-duplication's credit
   cpu_baseline          the CPU oracle (oracle/, a port of the reference algorithm) timed on this
                         box's host cores on a bounded sample (the GPU labels are checked against
-                        it); the reference's own measured rates (dev container, google/uis-rnn
+                        it; N > 1: rank 0 runs it after the closing barrier, on its share of the
+                        cores); the reference's own measured rates (dev container, google/uis-rnn
                         cannot travel) as reference_* scalars
   extra_configs         configs[2], the configs[3] share and configs[4] at their stated sizes,
                         a few passes each, with frac and a parity check against the oracle
@@ -102,20 +107,28 @@ def bytes_per_step(cfg, clusters=4):
   return 4 * dim * (1 + beam * clusters + 2 * beam) + 8 * cfg['rnn_depth'] * hid * beam + 8 * beam
 
 
-def committed_traffic(kernel):
+def committed_traffic(kernel, avg_launch_us=None):
   """HBM bytes per launch of `kernel` from the newest committed PMC run (profiles/), or None.
 
   PMC counters cannot be read from inside the benchmark process; they are collected with
   rocprofv3 in separate passes (tools/gpu_pmc.sh) and committed.  FETCH_SIZE is doubled
-  (gfx950 counts 64 B per 128-B request for wide coalesced reads).
+  (gfx950 counts 64 B per 128-B request for wide coalesced reads).  The record carries the
+  kernel's launch duration at the time it was taken; `stale` says whether today's duration has
+  moved more than 10 % away from it (the kernel changed: collect the counters again).
   """
   import glob
+  base = kernel.split('<')[0]
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
   for path in reversed(files):
     try:
-      entry = json.load(open(path))['kernels'][kernel]
-      return {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
-              'source': os.path.relpath(path, ROOT)}
+      entry = json.load(open(path))['kernels'][base]
+      out = {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
+             'source': os.path.relpath(path, ROOT)}
+      then = entry.get('avg_launch_us')
+      if then and avg_launch_us:
+        out['avg_launch_us_then'] = then
+        out['stale'] = bool(abs(avg_launch_us - then) > 0.10 * then)
+      return out
     except (KeyError, ValueError, OSError):
       continue
   return None
@@ -151,6 +164,10 @@ def parse(argv=None):
                   help='trained = tests/golden/trained_d{256,512}.uisrnn (the reference\'s fit, '
                        'SURVEY.md 8d); tracker = closed-form weights (uisrnn_amd.synth); '
                        'auto = trained where it applies')
+  ap.add_argument('--timed', default='predict_f64', choices=['predict_f64', 'host_buffers', 'device'],
+                  help='which leg the timed region (and `value`) is: predict_f64 = uis_decode_f64 from the '
+                       'float64 arrays predict() receives (default, SURVEY.md 8d); host_buffers = uis_decode '
+                       'from pinned float32; device = uis_decode_device, everything resident in HBM')
   ap.add_argument('--no_cpu_baseline', action='store_true')
   ap.add_argument('--no_host_buffers', action='store_true',
                   help='skip the PCIe-inclusive passes (value_host_buffers, value_predict_f64)')
@@ -305,15 +322,19 @@ class Workload:
       self.cap *= 2
 
   def setup(self, sync_fn):
-    """Untimed decodes before anything is measured: the first settles the cluster cap, the next
-    four are the decoder's trials of its control-word placement for this shape.
-    Returns (passes, total ms)."""
-    # (k_decode_rs -- at most 8 utterances per XCD -- has no placement trials: two passes)
-    small = self.n_utt <= 64 and self.dim <= 256 and self.beam <= 16 and self.look == 1 and not self.args.flags & 0x800
-    passes = (2 if small else 5) if self.rank_frames <= 2_000_000 else 1
+    """Untimed decodes before anything is measured.  Returns (passes, total ms).
+
+    The first pass settles the cluster cap and says which kernel the library runs for this shape
+    (uis_stats.decode_kernel); k_decode_rs and the launch-per-step path have no placement trials
+    (two passes), the other one-launch kernels try four placements of their control words on the
+    next decodes (five passes)."""
     sync_fn()
     t0 = time.perf_counter()
-    for _ in range(passes):
+    first = self.decode_once(self.args.flags)
+    name = first['stats']['decode_kernel']
+    small = name == 'k_decode_rs' or name.startswith('stepwise')
+    passes = (2 if small else 5) if self.rank_frames <= 2_000_000 else 1
+    for _ in range(passes - 1):
       self.decode_once(self.args.flags)
     sync_fn()
     return passes, 1e3 * (time.perf_counter() - t0)
@@ -333,15 +354,7 @@ class Workload:
       # ONE launch = the whole beam search.  Algorithmic work of the launch: every surviving
       # hypothesis of every step takes the hidden-side GRU matvec (3H x H), linear_mean1
       # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
-      n_cu = (self.torch.cuda.get_device_properties(self.d_frames.device).multi_processor_count
-              if self.d_frames.is_cuda else 256)
-      ncl = max(n_cu // 32, 1)
-      if self.n_utt > n_cu - n_cu % 32 and not self.args.flags & 0x200:
-        kernel = 'k_decode_big'       # more utterances than workgroups: a wave per row tile
-      elif (self.n_utt <= 8 * ncl and dim <= 256 and self.beam <= 16 and not self.args.flags & 0x800):
-        kernel = 'k_decode_rs'        # at most 8 utterances per XCD: the replicated select
-      else:
-        kernel = 'k_decode_resident'
+      kernel = prof['decode_kernel']  # named by the library (uis_stats.decode_kernel): its dispatch rule, not a copy of it
       kclass = 'gru'
       per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
       flop_algo = per_row * prof['rnn_rows_nodedup']
@@ -352,11 +365,7 @@ class Workload:
       # hidden-side matvecs (3H x H MACs per surviving hypothesis / prefix)
       kclass = max(('gru', 'head1', 'head2', 'select', 'expand', 'upper_in'),
                    key=lambda k: prof['kernel_ms'][k])
-      level = self.beam
-      for j in range(1, self.look):
-        level = min(level * (self.cap + j), 32768)
-      cap_rows = 0 if self.args.flags & 0x200 else self.n_utt * (self.beam if self.look == 1 else level)
-      fam = 'k_wt' if hid in (256, 512) and cap_rows > 1280 else ('k_big' if cap_rows > 2048 else 'k_dense')
+      fam = prof['decode_kernel'].split(':')[-1]  # 'stepwise:k_wt' -> the dense kernels' family, from the library
       kernel = {'gru': fam + '_gru', 'head1': fam + '_head1' if fam != 'k_wt' else 'k_wt_head<1>',
                 'head2': fam + '_head2' if fam != 'k_wt' else 'k_wt_head<2>',
                 'select': 'k_select_fast', 'expand': 'k_window', 'upper_in': 'k_dense_upper_in'}[kclass]
@@ -378,7 +387,7 @@ class Workload:
         # the algorithmic rows (one CoreRNN step per surviving hypothesis) over the same
         # time: de-duplication's credit (8 f1); may exceed 1
         'effective': {'tflops': round(effective, 3), 'frac': round(effective / PEAK_F32_MFMA_TFLOPS, 4)},
-        'traffic': committed_traffic(kernel),
+        'traffic': committed_traffic(kernel, avg_us),
         'avg_launch_us': round(avg_us, 3), 'launches': k_launches,
         'algorithmic_bytes_per_launch': algo_bytes,
         'rows_per_step_algorithmic': round(prof['rnn_rows_nodedup'] / max(n_steps, 1), 1),
@@ -514,56 +523,81 @@ def main(argv=None):
       w.d_labels = torch.empty(width, dtype=torch.int32, device=dev)
   gathered = (torch.empty(world * max(width, 1), dtype=torch.int32, device=gather_dev) if use_dist else None)
 
-  def one_step():
-    w.decode_once(args.flags)
-    if use_dist:  # the final gather: the only collective of the path (RCCL over xGMI)
-      src = w.d_labels[:max(width, 1)]
+  # ---- the three legs of one pass (all end with the labels of this rank's utterances):
+  #   predict_f64   uis_decode_f64 from the float64 arrays predict() receives (cast + H2D + decode + D2H)
+  #   host_buffers  uis_decode from pinned float32 (H2D + decode + D2H)
+  #   device        uis_decode_device, frames and labels resident in HBM
+  host = {}
+  if w.n_utt and not args.no_host_buffers:
+    pin = (lambda t: t.pin_memory()) if on_gpu else (lambda t: t)
+    host['frames'] = pin(torch.from_numpy(w.frames))
+    host['labels'] = pin(torch.empty(max(w.rank_frames, 1), dtype=torch.int32))
+    host['scores'] = pin(torch.empty(w.n_utt, dtype=torch.float32))
+
+  def gather(src):  # the final gather: the only collective of the path (RCCL over xGMI)
+    if use_dist:
+      src = src[:max(width, 1)]
       dist.all_gather_into_tensor(gathered, src if args.backend == 'nccl' else src.cpu())
+
+  def device_step():
+    w.decode_once(args.flags)
+    gather(w.d_labels)
+
+  def host_step():
+    rc = w.decoder.decode_host(host['frames'].data_ptr(), w.offsets, w.beam, w.look, tau,
+                               host['labels'].data_ptr(), host['scores'].data_ptr(),
+                               max_clusters=w.cap, flags=args.flags)
+    if rc['status'] != 0:
+      raise RuntimeError('host-buffer decode hit the cluster cap')
+    if use_dist:  # the labels came back to the host (that is the leg): up again for the gather
+      w.d_labels[:w.rank_frames].copy_(host['labels'][:w.rank_frames], non_blocking=True)
+      gather(w.d_labels)
+
+  f64_out = {}
+  def f64_step():
+    f64_out['r'] = w.decoder.decode_f64(w.seqs, w.beam, w.look, tau, max_clusters=w.cap, flags=args.flags)
+    if f64_out['r']['status'] != 0:
+      raise RuntimeError('float64-list decode hit the cluster cap')
+    if use_dist:
+      w.d_labels[:w.rank_frames].copy_(torch.from_numpy(f64_out['r']['labels']), non_blocking=True)
+      gather(w.d_labels)
+
+  legs = {'device': device_step}
+  if host:
+    legs['host_buffers'] = host_step
+    legs['predict_f64'] = f64_step
+  timed_leg = args.timed if args.timed in legs else 'device'   # (--no_host_buffers, or a rank without utterances)
 
   setup_passes, setup_ms = w.setup(sync_fn)
   w.timing = True
   per_rank = []
-  elapsed = timed_region(one_step, sync_fn, steps, warmup, dist, gather_dev, per_rank)
+  elapsed = timed_region(legs[timed_leg], sync_fn, steps, warmup, dist, gather_dev, per_rank)
   ms_per_step = 1e3 * elapsed / max(steps, 1)
   value = w.job_frames * steps / elapsed
+  rates = {timed_leg: value}
+  # ---- the other legs, same passes, every rank (a multi-GPU line carries all three rates too)
+  n_other = max(steps // 2, 1)
+  for name in ('device', 'host_buffers', 'predict_f64'):
+    if name in legs and name not in rates:
+      el = timed_region(legs[name], sync_fn, n_other, 1, dist, gather_dev)
+      rates[name] = w.job_frames * n_other / el
+  if host:  # the three legs decoded the same utterances: same labels
+    dev_labels = w.d_labels[:w.rank_frames].cpu().numpy()
+    if w.rank_frames and not (np.array_equal(host['labels'].numpy()[:w.rank_frames], dev_labels) and
+                              np.array_equal(f64_out['r']['labels'], dev_labels)):
+      raise RuntimeError('the device-buffer, host-buffer and float64-list decodes disagree')
   stats = w.last['stats'] if w.last else {}
 
   result = None
   if rank == 0:
-    # ---- PCIe-inclusive rates: host buffers in, labels out, same passes
-    host_rate = f64_rate = None
-    if not args.no_host_buffers and on_gpu and w.n_utt and world == 1:
-      pin_frames = torch.from_numpy(w.frames).pin_memory()
-      pin_labels = torch.empty(w.rank_frames, dtype=torch.int32).pin_memory()
-      pin_scores = torch.empty(w.n_utt, dtype=torch.float32).pin_memory()
-      def host_step():
-        rc = w.decoder.decode_host(pin_frames.data_ptr(), w.offsets, w.beam, w.look, tau,
-                                   pin_labels.data_ptr(), pin_scores.data_ptr(),
-                                   max_clusters=w.cap, flags=args.flags)
-        if rc['status'] != 0:
-          raise RuntimeError('host-buffer decode hit the cluster cap')
-      n_host = max(steps // 2, 1)
-      el = timed_region(host_step, sync_fn, n_host, 1)
-      host_rate = w.rank_frames * n_host / el
-      if not np.array_equal(pin_labels.numpy(), w.d_labels[:w.rank_frames].cpu().numpy()):
-        raise RuntimeError('host-buffer decode and device-buffer decode disagree')
-      # ... and the entry UISRNN.predict uses: the list of float64 arrays as the caller holds them
-      f64_out = {}
-      def f64_step():
-        f64_out['r'] = w.decoder.decode_f64(w.seqs, w.beam, w.look, tau, max_clusters=w.cap, flags=args.flags)
-        if f64_out['r']['status'] != 0:
-          raise RuntimeError('float64-list decode hit the cluster cap')
-      el = timed_region(f64_step, sync_fn, n_host, 1)
-      f64_rate = w.rank_frames * n_host / el
-      if not np.array_equal(f64_out['r']['labels'], pin_labels.numpy()):
-        raise RuntimeError('float64-list decode and host-buffer decode disagree')
-
-    roofline = w.roofline(value / world)
+    roofline = w.roofline(rates['device'] / world)  # (the path fractions are the HBM-resident leg's)
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
     cpu = None
-    if not args.no_cpu_baseline and world == 1:  # (N > 1: the other ranks would wait at the barrier)
-      cores = os.cpu_count() or 1
-      threads = min(cores, 64)
+    if not args.no_cpu_baseline and on_gpu:
+      # (N > 1: the timed regions are closed; the other ranks wait at the final barrier while rank 0
+      # times the oracle on ITS share of the host cores)
+      cores = rank_cores if world > 1 else (os.cpu_count() or 1)
+      threads = max(min(cores, 64), 1)
       sample = args.cpu_sample or min(w.n_utt, max(threads, 1))
       if w.look > 1:
         sample = min(sample, 8)
@@ -601,11 +635,17 @@ def main(argv=None):
         'data': 'synthetic',
         'config': dict(cfg, parallelism='utterance-sharded x{}'.format(world),
                        max_clusters=w.cap),
-        'value_definition': 'frame stream and label buffer resident in HBM when the clock starts '
-                            '(uis_decode_device); the PCIe-inclusive rates of the same passes follow',
-        'value_device': round(value, 1),
-        'value_host_buffers': round(host_rate, 1) if host_rate else None,
-        'value_predict_f64': round(f64_rate, 1) if f64_rate else None,
+        'value_leg': timed_leg,
+        'value_definition': {
+            'predict_f64': 'uis_decode_f64 -- the entry UISRNN.predict uses: float64 arrays in, cast + H2D of '
+                           'the frames + decode + D2H of the labels inside the clock (SURVEY.md 8d), every rank',
+            'host_buffers': 'uis_decode from pinned float32: H2D of the frames + decode + D2H of the labels '
+                            'inside the clock',
+            'device': 'uis_decode_device: frame stream and label buffer resident in HBM when the clock starts',
+        }[timed_leg],
+        'value_predict_f64': round(rates['predict_f64'], 1) if 'predict_f64' in rates else None,
+        'value_host_buffers': round(rates['host_buffers'], 1) if 'host_buffers' in rates else None,
+        'value_device': round(rates['device'], 1) if 'device' in rates else None,
         'setup_passes': setup_passes, 'setup_ms': round(setup_ms, 1),
         'per_rank_ms': {'min': round(1e3 * min(per_rank) / steps, 3), 'max': round(1e3 * max(per_rank) / steps, 3)},
         'rank_host_cores': rank_cores,

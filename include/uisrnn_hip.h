@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UIS_ABI_VERSION 4
+#define UIS_ABI_VERSION 5
 
 typedef enum uis_status {
   UIS_OK = 0,
@@ -125,7 +125,7 @@ typedef struct uis_decode_opts {
                                     single wave); A/B switch, results are bit-identical either way */
 #define UIS_FLAG_REPLICATED_SELECT 0x1000u /* one-launch decode: REQUIRE-if-applicable the replicated select
                                     (k_decode_rs) where it is not the default (A/B switch)         */
-#define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook (look_ahead 1): keep every candidate score of every step --
+#define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */
 #define UIS_FLAG_TEST_MISPLACED 0x100u /* test hook: one workgroup of the one-launch decode reports
@@ -153,7 +153,22 @@ typedef struct uis_stats {
   int64_t kernel_launches[UIS_N_KERNELS];
   int32_t n_overflow;                 /* utterances that hit UIS_ERR_CLUSTER_CAP    */
   int32_t n_streams;                  /* utterance groups used                       */
+  int32_t decode_kernel;              /* UIS_DK_*: the kernel family that ran the decode steps */
+  int32_t reserved1;
 } uis_stats;
+
+/* uis_stats.decode_kernel: which kernels ran the decode steps (the dispatch rule lives in the
+ * library, uis_decoder.hip: callers that want to NAME the kernel read it here) */
+enum {
+  UIS_DK_NONE = 0,
+  UIS_DK_STEPWISE = 1,   /* launch per step: k_select* / k_window + the dense kernels below   */
+  UIS_DK_RS = 2,         /* one launch, replicated single-wave select (k_decode_rs)           */
+  UIS_DK_RESIDENT = 3,   /* one launch, owner select (k_decode_resident)                      */
+  UIS_DK_BIG = 4,        /* one launch, a wave per row tile (k_decode_big)                    */
+  UIS_DK_BIG_WS = 5      /* ... with a rank's selects running concurrently (k_decode_big<WS>) */
+};
+/* ... and, in bits 8..15 for UIS_DK_STEPWISE, the dense kernels' family */
+enum { UIS_DF_DENSE = 1 /* k_dense_* split-K */, UIS_DF_BIG = 2 /* k_big_* */, UIS_DF_WT = 3 /* k_wt_* */ };
 
 /* kernel classes for uis_stats.kernel_ms */
 enum {
@@ -239,13 +254,23 @@ int32_t uis_decode_device(uis_handle* h, const float* d_frames, const int64_t* o
 int32_t uis_last_decode_info(uis_handle* h, int32_t* overflow_out, float* beam_scores_out);
 
 /*
- * After a decode with UIS_FLAG_DEBUG_SCORES (look_ahead 1): the candidate scores of every step,
- *   scores_out[((step * n_utt + u) * beam_size + b) * (max_clusters + 1) + c]
- * = what _calculate_score (uisrnn/uisrnn.py:455-477) returns for hypothesis b of utterance u at
- * decode step `step` (0 .. test_iteration * longest utterance - 1) at cluster c, +inf where the
- * reference's padded score_set (uisrnn.py:534-545) holds +inf: clusters past K_b, hypotheses past
- * the live beam, steps past the utterance's end.  `capacity` = floats available at scores_out;
- * returns UIS_ERR_INVALID_ARG when the last decode kept none or the buffer is too small.
+ * The sizes uis_last_decode_info copies with: n_utt and beam_size of this handle's last
+ * uis_decode* call (0 / 0 when that call was refused before it started, e.g. UIS_ERR_UNSUPPORTED
+ * for its options -- a caller must size its buffers from here, not from what it asked for).
+ */
+int32_t uis_last_decode_shape(uis_handle* h, int32_t* n_utt_out, int32_t* beam_size_out);
+
+/*
+ * After a decode with UIS_FLAG_DEBUG_SCORES: the candidate scores of every window (look_ahead 1: of
+ * every decode step),
+ *   scores_out[(((w * n_utt + u) * beam_size + b) * C + c_1) * C ... + c_L],   C = max_clusters + 1
+ * = what _calculate_score (uisrnn/uisrnn.py:455-477) returns for hypothesis b of utterance u in
+ * window w (0 .. ceil(test_iteration * longest utterance / look_ahead) - 1) for the assignment
+ * tuple (c_1 .. c_L), +inf where the reference's padded score_set (uisrnn.py:534-545) holds +inf:
+ * clusters past K_b, hypotheses past the live beam, windows past the utterance's end, tuples
+ * through a non-finite prefix.  A ragged last window of Lw < L frames has its scores at index 0 of
+ * the missing dimensions.  `capacity` = floats available at scores_out; returns
+ * UIS_ERR_INVALID_ARG when the last decode kept none or the buffer is too small.
  */
 int32_t uis_debug_scores(uis_handle* h, float* scores_out, int64_t capacity);
 

@@ -34,6 +34,9 @@ SCORE_CASES = [
     ('d32_lookahead3', 2, 9, 3, 2, 1, 8),  # look_ahead 2 with a ragged last window
     ('d20_h24_depth3', 0, 10, 5, 1, 2, 8),
     ('tracker_d256', 0, 16, 10, 1, 2, 8),  # the benchmark shape (D = 256, H = 512, beam 10)
+    # BASELINE configs[2]'s shape: the model the reference trained (make_trained.py), beam 50,
+    # look_ahead 2, max_clusters 12 -> arrays [windows, 50, 13, 13]; 8 frames x test_iteration 2
+    ('trained_d256_l2_n40', 1, 8, 50, 2, 2, 13),
 ]
 
 
@@ -88,7 +91,7 @@ def main():
   uisrnn = make_golden.import_reference()
   store = {'n_cases': np.int64(len(SCORE_CASES))}
   for i, (name, utt, keep, beam, look, tau, cmax) in enumerate(SCORE_CASES):
-    case = golden_util.load_case(name)
+    case = golden_util.load_trained(name) if name.startswith('trained_') else golden_util.load_case(name)
     seq = np.asarray(case['seqs'][utt], dtype=np.float64)[:keep]
     arr, labels, calls = record_scores(uisrnn, case['params'], seq, beam, look, tau, cmax)
     store['case_{}'.format(i)] = np.array([name], dtype='U32')

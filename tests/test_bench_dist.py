@@ -81,14 +81,23 @@ _MAIN_SCRIPT = textwrap.dedent('''
         rows = steps * (len(offsets) - 1) * 3
         names = _capi.KERNEL_NAMES
         return {{'status': 0, 'stats': {{'n_steps': steps, 'decode_ms': 1.0, 'n_streams': 1,
-                 'rnn_rows': rows, 'rnn_rows_nodedup': 2 * rows,
+                 'rnn_rows': rows, 'rnn_rows_nodedup': 2 * rows, 'decode_kernel': 'k_decode_rs',
                  'kernel_ms': {{k: (0.5 if k == 'gru' else 0.0) for k in names}},
                  'kernel_launches': {{k: (1 if k == 'gru' else 0) for k in names}}}}}}
+      def decode_host(self, frames_ptr, offsets, beam_size, look_ahead, test_iteration, labels_ptr,
+                      scores_ptr, max_clusters=0, flags=0):
+        return self.decode_device(frames_ptr, offsets, beam_size, look_ahead, test_iteration, labels_ptr,
+                                  scores_ptr, max_clusters, flags)
+      def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+        assert all(s.dtype == np.float64 for s in seqs)
+        n = sum(s.shape[0] for s in seqs)
+        self.calls += 1
+        return {{'status': 0, 'labels': np.full(n, int(os.environ['RANK']) + 7, dtype=np.int32)}}
     _capi.Decoder = StandInDecoder
     import bench
     res = bench.main(['--gpus', '2', '--device', 'cpu', '--backend', 'gloo', '--utterances', '3',
                       '--frames', '24', '--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--ragged',
-                      '--model', 'tracker'])
+                      '--model', 'tracker'] + {extra!r})
     if int(os.environ['RANK']) == 0:
       assert res is not None
     else:
@@ -96,12 +105,19 @@ _MAIN_SCRIPT = textwrap.dedent('''
 ''')
 
 
-def test_bench_main_world_2_gloo_with_a_stand_in_decoder(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('extra', [[], ['--config', '3'], ['--timed', 'device']],
+                         ids=['config1_predict_f64', 'config3_ragged', 'timed_device'])
+def test_bench_main_world_2_gloo_with_a_stand_in_decoder(tmp_path, extra):
   """bench.main() itself, two ranks over gloo: launch plumbing, per-rank core pinning, ragged
-  utterances dealt by shard_utterances, the padded label gather, the timed region, ONE JSON line
-  from rank 0 with the per-rank spread.  (The decode is a stand-in: no GPU here.)"""
+  utterances dealt by shard_utterances, the padded label gather, the timed region over the
+  float64-list leg on EVERY rank (the multi-GPU line is PCIe-inclusive), the other two legs, ONE
+  JSON line from rank 0 with the per-rank spread -- for configs[1] and for the configs[3] share
+  (`--config 3 --ragged`, the driver's 8-GPU workload).  (The decode is a stand-in: no GPU here.)"""
   script = tmp_path / 'main_rank.py'
-  script.write_text(_MAIN_SCRIPT.format(root=ROOT))
+  script.write_text(_MAIN_SCRIPT.format(root=ROOT, extra=extra))
   import json
   import socket
   out = None
@@ -128,6 +144,11 @@ def test_bench_main_world_2_gloo_with_a_stand_in_decoder(tmp_path):
   assert 'ragged' in rec['config']['workload']
   # whole-job frames: 6 utterances of 12..24 frames, 2 timed steps
   assert 6 * 12 * 2 / (rec['ms_per_step'] * 2e-3) <= rec['value'] <= 6 * 24 * 2 / (rec['ms_per_step'] * 2e-3) * 1.01
+  # `value` is the float64-list leg unless --timed says otherwise; all three rates are there
+  want = 'device' if '--timed' in extra else 'predict_f64'
+  assert rec['value_leg'] == want and rec['value'] == rec['value_' + want]
+  assert rec['value_predict_f64'] > 0 and rec['value_host_buffers'] > 0 and rec['value_device'] > 0
+  assert rec['roofline']['kernel'] == 'k_decode_rs'   # named by the (stand-in) library, not re-derived
 
 
 def test_gpus_flag_refuses_to_fold_ranks_onto_one_device():

@@ -619,37 +619,42 @@ def test_empty_inputs_through_the_c_abi():
 
 
 def test_calculate_score_arrays_on_the_device(oracle_lib):
-  """The device select's FULL candidate arrays (UIS_FLAG_DEBUG_SCORES) against what the
-  reference's _calculate_score returned (uisrnn/uisrnn.py:455-477; tests/golden/fn_scores.npz) and,
-  bit for bit, against the oracle's: every path that scores look_ahead-1 candidates."""
+  """The device's FULL candidate arrays (UIS_FLAG_DEBUG_SCORES) against what the reference's
+  _calculate_score returned (uisrnn/uisrnn.py:455-477; tests/golden/fn_scores.npz) and, bit for bit,
+  against the oracle's -- on every path that scores candidates: the four look_ahead-1 selects and,
+  for look_ahead >= 2, k_window's whole [beam, C, C] grid of a window (ragged last window and the
+  +inf padding included), not only the survivors."""
   data = np.load(golden_util.GOLDEN_DIR + '/fn_scores.npz')
-  checked = 0
+  checked = windows = 0
   for i in range(int(data['n_cases'])):
     name = str(data['case_{}'.format(i)][0])
     utt, keep, beam, look, tau, cmax = (int(v) for v in data['cfg_{}'.format(i)])
-    if look != 1:
-      continue
     ref = data['scores_{}'.format(i)]
-    case = golden_util.load_case(name)
+    case = golden_util.load_trained(name) if name.startswith('trained_') else golden_util.load_case(name)
     seq = np.asarray(case['seqs'][utt], dtype=np.float64)[:keep]
     ora = oracle_lib.candidate_scores(case['params'], seq, beam, look, tau, cmax)
     dec = _capi.Decoder(case['params'])
     frames, offsets = oracle_lib.pack([seq])
     kmax = cmax - 1
-    paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_OWNER_SELECT,
-             _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_GENERIC_SELECT]
+    if look == 1:
+      paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_OWNER_SELECT,
+               _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_GENERIC_SELECT]
+    else:
+      paths = [0, _capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_SMALL_TILES]
+    n_win = (tau * keep + look - 1) // look
     for fl in paths:
       out = dec.decode(frames, offsets, beam, look, tau, max_clusters=kmax,
                        flags=fl | _capi.UIS_FLAG_DEBUG_SCORES)
       assert out['status'] == 0
-      got = dec.debug_scores(tau * keep, 1, beam, kmax)[:, 0]
+      got = dec.debug_scores(n_win, 1, beam, kmax, look)[:, 0]
       assert got.shape == ref.shape
       assert np.array_equal(_bits(got), _bits(ora)), (name, fl)
       assert np.array_equal(np.isinf(got), np.isinf(ref))
       fin = np.isfinite(ref)
       np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-4)
       checked += 1
-  assert checked >= 12
+      windows += n_win if look > 1 else 0
+  assert checked >= 16 + 6 and windows >= 3 * (5 + 8)
 
 
 def test_level_capacity_names_the_utterances_and_keeps_the_others(oracle_lib):
@@ -672,3 +677,124 @@ def test_level_capacity_names_the_utterances_and_keeps_the_others(oracle_lib):
   assert info.value.results[1] is None
   ref = oracle_lib.decode(params, [calm], 200, 4, 1)
   assert info.value.results[0] == ref['labels'][0].tolist()
+
+
+def test_a_refused_decode_leaves_no_stale_flags_behind(oracle_lib):
+  """uis_last_decode_info after a decode that was refused for its OPTIONS must not hand out the
+  previous decode's arrays (a 100-utterance batch followed by a 1-utterance call with look_ahead 9
+  used to copy 100 flags into a buffer of one): the library reports the shape it holds
+  (uis_last_decode_shape: 0 x 0) and the Python surface raises the clean error."""
+  import uisrnn_amd
+  params = synth.tracker_params(64, 256, 1, seed=2)
+  seqs, _ = synth.make_utterances(4200, 100, 6, 64)
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model_args.observation_dim = 64
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 4, 2, 1
+  want = [l.tolist() for l in oracle_lib.decode(params, seqs, 4, 2, 1, n_threads=8)['labels']]
+  assert model.predict(seqs, inference_args) == want
+  dec = model._get_decoder()  # pylint: disable=protected-access
+  assert dec.last_overflow().shape == (100,)
+  inference_args.look_ahead = 9
+  with pytest.raises(_capi.HipLibraryError) as info:
+    model.predict(seqs[:1], inference_args)
+  assert info.value.status == _capi.UIS_ERR_UNSUPPORTED and not isinstance(info.value, uisrnn_amd.LookAheadWindowError)
+  assert dec.last_overflow().shape == (0,)
+  assert dec.last_overflow(3).tolist() == [0, 0, 0]
+  inference_args.look_ahead = 2
+  assert model.predict(seqs[:3], inference_args) == want[:3]
+
+
+def test_two_handles_decode_concurrently_on_one_device(oracle_lib):
+  """Two handles on device 0, driven from two host threads at once, both on the one-launch
+  replicated-select kernel (UIS_FLAG_RESIDENT: REQUIRE it -- a fallback to the launch-per-step path
+  would be an error here, not a silent success).  Each launch is cooperative and owns every CU, so
+  two of them cannot be resident together: the runtime has to run them one after the other, not
+  refuse or abort one.  This is what a launcher that folds several ranks onto one GPU would do."""
+  import threading
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  batches = [synth.make_utterances(5100 + 100 * k, 64, 40, 256)[0] for k in range(2)]
+  refs = [oracle_lib.decode(params, b, 10, 1, 2, n_threads=8) for b in batches]
+  decs = [_capi.Decoder(params, device=0) for _ in range(2)]
+  errors, kernels = [], [set(), set()]
+
+  def worker(k):
+    try:
+      frames, offsets = oracle_lib.pack(batches[k])
+      for _ in range(6):
+        out = decs[k].decode(frames, offsets, 10, 1, 2, flags=_capi.UIS_FLAG_RESIDENT, want_beam_scores=True)
+        assert out['status'] == 0
+        kernels[k].add(out['stats']['decode_kernel'])
+        for u in range(len(batches[k])):
+          assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], refs[k]['labels'][u])
+        assert np.array_equal(_bits(out['beam_scores']), _bits(refs[k]['beam_scores']))
+    except BaseException as e:  # pylint: disable=broad-except
+      errors.append((k, repr(e)))
+
+  threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join()
+  assert not errors, errors
+  assert kernels == [{'k_decode_rs'}, {'k_decode_rs'}], kernels
+
+
+def test_reference_probes_on_the_device():
+  """tests/golden/probes.json on the DEVICE path: which probe yields labels and which an empty beam.
+
+  The reference (uisrnn/uisrnn.py:531,546-549,561) raises ValueError / IndexError when its beam
+  empties and, with a NaN in the LAST frame, returns a label list one frame short (numpy sorts NaN
+  behind the +inf padding; DESIGN.md 1.1 -- a documented deviation: non-finite candidates are never
+  selected here).  Pinned on every select path: finite probes give the reference's labels, every
+  non-finite probe gives -1 labels from the C ABI and EmptyBeamError -- an instance of the type the
+  reference raised -- from predict()."""
+  import json
+  import os
+  import uisrnn_amd
+  with open(os.path.join(golden_util.GOLDEN_DIR, 'probes.json')) as f:
+    probes = json.load(f)
+  case = golden_util.load_case('tiny_d16')
+  params, seq = case['params'], np.asarray(case['seqs'][0], dtype=np.float64)
+  dec = _capi.Decoder(params)
+  m0, _ = dec.constants()
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model_args.observation_dim = params['observation_dim']
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 5, 1, 1
+
+  def edit(row, col, value):
+    q = seq.copy()
+    q[row, col] = value
+    return q
+  inputs = {
+      'clean': seq,
+      'first_component_equals_m0_frame4': edit(4, 0, np.float64(m0[0])),
+      'first_component_equals_m0_frame0': edit(0, 0, np.float64(m0[0])),
+      'nan_mid_frame': edit(3, 2, np.nan),
+      'nan_last_frame': edit(seq.shape[0] - 1, 2, np.nan),
+      'inf_first_frame': edit(0, 0, np.inf),
+  }
+  paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_GENERIC_SELECT]
+  for name, x in inputs.items():
+    rec = probes[name]
+    frames = x.astype(np.float32)
+    offsets = np.array([0, x.shape[0]], dtype=np.int64)
+    for fl in paths:
+      out = dec.decode(frames, offsets, 5, 1, 1, flags=fl)
+      assert out['status'] == 0
+      if 'labels' in rec and name != 'nan_last_frame':
+        assert out['labels'].tolist() == rec['labels'], (name, fl)
+      else:
+        assert set(out['labels'].tolist()) == {-1}, (name, fl)
+    if 'labels' in rec and name != 'nan_last_frame':
+      assert model.predict(x, inference_args) == rec['labels']
+    else:
+      with pytest.raises(uisrnn_amd.EmptyBeamError) as info:
+        model.predict(x, inference_args)
+      if 'raises' in rec:  # the reference's own exception type is one of EmptyBeamError's bases
+        assert isinstance(info.value, {'ValueError': ValueError, 'IndexError': IndexError}[rec['raises']])
+      else:                # nan_last_frame: the reference returned a list ONE FRAME SHORT (its accident)
+        assert len(rec['labels']) == x.shape[0] - 1

@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
   lib = _capi.load_library()
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.uis_abi_version() == _capi.UIS_ABI_VERSION == 4
+  assert lib.uis_abi_version() == _capi.UIS_ABI_VERSION == 5
   version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', open(
       os.path.join(ROOT, 'include', 'uis_numerics.h')).read()).group(1))
   assert lib.uis_numerics_version() == version
@@ -174,7 +174,8 @@ def test_struct_layouts_match_header():
   assert _capi.ModelDesc.transition_bias.offset == 96
   assert ctypes.sizeof(_capi.DecodeOpts) == 32
   assert _capi.Stats.kernel_ms.offset == 40
-  assert ctypes.sizeof(_capi.Stats) == 40 + 8 * 8 + 8 * 8 + 8
+  assert ctypes.sizeof(_capi.Stats) == 40 + 8 * 8 + 8 * 8 + 16
+  assert _capi.Stats.decode_kernel.offset == 40 + 8 * 8 + 8 * 8 + 8
 
 
 def test_c_abi_rejects_bad_arguments_without_a_device():

@@ -248,7 +248,7 @@ def test_calculate_score_arrays_match_reference(oracle_lib):
   not only the survivors' scores."""
   n_states = 0
   for name, utt, keep, beam, look, tau, cmax, ref, ref_labels in _score_cases():
-    case = golden_util.load_case(name)
+    case = golden_util.load_trained(name) if name.startswith('trained_') else golden_util.load_case(name)
     seq = np.asarray(case['seqs'][utt], dtype=np.float64)[:keep]
     got = oracle_lib.candidate_scores(case['params'], seq, beam, look, tau, cmax)
     assert got.shape == ref.shape

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuisrnn_hip.so')
 
 UIS_OK = 0
-UIS_ABI_VERSION = 4   # include/uisrnn_hip.h
+UIS_ABI_VERSION = 5   # include/uisrnn_hip.h
 UIS_ERR_INVALID_ARG = -1
 UIS_ERR_DIM_MISMATCH = -2
 UIS_ERR_NO_DEVICE = -3
@@ -42,6 +42,18 @@ UIS_FLAG_DEBUG_SCORES = 0x2000
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
                 'upper_in', 'expand')
+
+# uis_stats.decode_kernel (UIS_DK_* | UIS_DF_* << 8): the kernel family that ran the decode steps
+DECODE_KERNELS = {0: 'none', 1: 'stepwise', 2: 'k_decode_rs', 3: 'k_decode_resident', 4: 'k_decode_big',
+                  5: 'k_decode_big<WS>'}
+DENSE_FAMILIES = {0: '', 1: 'k_dense', 2: 'k_big', 3: 'k_wt'}
+
+
+def decode_kernel_name(code):
+  name = DECODE_KERNELS.get(code & 0xff, 'unknown')
+  fam = DENSE_FAMILIES.get((code >> 8) & 0xff, '')
+  return name + (':' + fam if fam else '')
+
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _fpp = ctypes.POINTER(_fp)
@@ -95,6 +107,8 @@ class Stats(ctypes.Structure):
       ('kernel_launches', ctypes.c_int64 * UIS_N_KERNELS),
       ('n_overflow', ctypes.c_int32),
       ('n_streams', ctypes.c_int32),
+      ('decode_kernel', ctypes.c_int32),
+      ('reserved1', ctypes.c_int32),
   ]
 
   def as_dict(self):
@@ -110,6 +124,7 @@ class Stats(ctypes.Structure):
             n: self.kernel_launches[i] for i, n in enumerate(KERNEL_NAMES)},
         'n_overflow': self.n_overflow,
         'n_streams': self.n_streams,
+        'decode_kernel': decode_kernel_name(self.decode_kernel),
     }
 
 
@@ -235,6 +250,8 @@ def load_library(path=None):
       i32p, _fp, ctypes.POINTER(Stats)]
   lib.uis_last_decode_info.restype = i32
   lib.uis_last_decode_info.argtypes = [ctypes.c_void_p, i32p, _fp]
+  lib.uis_last_decode_shape.restype = i32
+  lib.uis_last_decode_shape.argtypes = [ctypes.c_void_p, i32p, i32p]
   lib.uis_debug_scores.restype = i32
   lib.uis_debug_scores.argtypes = [ctypes.c_void_p, _fp, ctypes.c_int64]
   lib.uis_model_constants.restype = i32
@@ -267,7 +284,8 @@ def load_library(path=None):
 
 EXPORTED_SYMBOLS = (
     'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
-    'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info', 'uis_debug_scores',
+    'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info', 'uis_last_decode_shape',
+    'uis_debug_scores',
     'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',
     'uis_stream_labels', 'uis_stream_end', 'uis_eval_accuracy', 'uis_eval_accuracy_device',
     'uis_eval_last_decode', 'uis_host_alloc', 'uis_host_free', 'uis_last_error')
@@ -419,19 +437,33 @@ class Decoder:
       out['beam_scores'] = beam_scores
     return out
 
-  def last_overflow(self, n_utt):
+  def last_overflow(self, n_utt=None):
     """Per-utterance flags of the last decode: bit 0 = a survivor hit the cluster cap, bit 1 = an
-    intermediate level of a look-ahead window was full (uis_last_decode_info)."""
-    overflow = np.zeros(max(int(n_utt), 1), dtype=np.int32)
+    intermediate level of a look-ahead window was full (uis_last_decode_info).
+
+    The buffer is sized from the library (uis_last_decode_shape), never from the caller's idea of
+    the batch: a decode that was refused before it started leaves zero utterances behind, and the
+    result is then an empty array.  `n_utt`, if given, only pads / cuts the returned array."""
+    n_lib, beam = ctypes.c_int32(0), ctypes.c_int32(0)
+    self._check(self._lib.uis_last_decode_shape(self._handle, ctypes.byref(n_lib), ctypes.byref(beam)),
+                'uis_last_decode_shape')
+    overflow = np.zeros(max(int(n_lib.value), 1), dtype=np.int32)
     self._check(self._lib.uis_last_decode_info(
         self._handle, overflow.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), None), 'uis_last_decode_info')
-    return overflow[:int(n_utt)]
+    overflow = overflow[:int(n_lib.value)]
+    if n_utt is not None and int(n_utt) != overflow.shape[0]:
+      padded = np.zeros(int(n_utt), dtype=np.int32)
+      padded[:min(int(n_utt), overflow.shape[0])] = overflow[:int(n_utt)]
+      return padded
+    return overflow
 
-  def debug_scores(self, n_steps, n_utt, beam_size, max_clusters):
+  def debug_scores(self, n_windows, n_utt, beam_size, max_clusters, look_ahead=1):
     """The candidate scores of the last decode (flags included UIS_FLAG_DEBUG_SCORES):
-    float32 [n_steps, n_utt, beam_size, max_clusters + 1], +inf where _calculate_score's padded
-    array (uisrnn/uisrnn.py:534-545) holds +inf."""
-    out = np.empty((int(n_steps), int(n_utt), int(beam_size), int(max_clusters) + 1), dtype=np.float32)
+    float32 [n_windows, n_utt, beam_size] + [max_clusters + 1] * look_ahead, +inf where
+    _calculate_score's padded array (uisrnn/uisrnn.py:534-545) holds +inf.  n_windows =
+    ceil(test_iteration * longest utterance / look_ahead)."""
+    out = np.empty([int(n_windows), int(n_utt), int(beam_size)] + [int(max_clusters) + 1] * int(look_ahead),
+                   dtype=np.float32)
     self._check(self._lib.uis_debug_scores(self._handle, out.ctypes.data_as(_fp), out.size), 'uis_debug_scores')
     return out
 

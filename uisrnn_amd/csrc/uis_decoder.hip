@@ -347,15 +347,27 @@ struct Launcher {
   } while (0)
 
 // One batched CoreRNN evaluation over the rows emitted for step parity `par`.
+// Which family of dense kernels the launch-per-step path runs for a step of at most `max_rows`
+// rnn rows (UIS_DF_*; uis_stats.decode_kernel reports it).
+int dense_family(const uis_handle* h, uint32_t flags, long max_rows) {
+  const DevModel& m = h->m;
+  if (max_rows > UIS_WT_ROWS && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64)
+    return UIS_DF_WT;
+  if (max_rows > UIS_WIDE_TILE_ROWS && (m.Hp / 16) % 4 == 0 && (m.Dp / 16) % 4 == 0 && !(flags & UIS_FLAG_SMALL_TILES))
+    return UIS_DF_BIG;
+  return UIS_DF_DENSE;
+}
+
 int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, long max_rows) {
   const DevModel& m = h->m;
   const int mr = (int)max_rows;
   const bool wide = max_rows > UIS_WIDE_TILE_ROWS;  // tile shape, see uis_kernels.hip
+  const int family = dense_family(h, st.flags, max_rows);
   // thousands of rows: the big-tile kernels (4 row tiles x several feature tiles per workgroup,
   // full-K chains per wave) where the feature-tile counts divide
   // thousands of rows and hidden size 256 / 512: weights in LDS, a wave per row tile (k_wt_*)
   // (measured crossover against the 1x1 split-K tiles: row capacity 1280 about equal, 1920 +11 %)
-  if (max_rows > UIS_WT_ROWS && (m.Hp == 512 || m.Hp == 256) && m.Dp % 16 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES) && h->n_cu >= 64) {
+  if (family == UIS_DF_WT) {
     const int nft = m.Hp / 16, nft2 = m.Dp / 16;
     const int ng1 = wt_groups(h->n_cu, nft);
     const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
@@ -380,7 +392,7 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
 #undef UIS_WT_HEAD
     return UIS_OK;
   }
-  if (wide && (m.Hp / 16) % 4 == 0 && (m.Dp / 16) % 4 == 0 && !(st.flags & UIS_FLAG_SMALL_TILES)) {
+  if (family == UIS_DF_BIG) {
     for (int l = 0; l < m.depth; ++l) {
       if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
       LAUNCH(UIS_K_GRU, k_big_gru<2>, dim3(big_grid_blocks(mr, m.Hp / 16, 2)), dim3(256), 0, m, st, par, l);
@@ -540,6 +552,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                 const uis_decode_opts* opts, int32_t* d_labels, float* d_scores, uis_stats* stats,
                 const float* h_frames = nullptr) {
   if (!h || !offsets || !opts || n_utt < 0) return fail(UIS_ERR_INVALID_ARG, "null handle/offsets/opts or negative n_utt");
+  // (whatever refuses this decode below: uis_last_decode_info must not hand out the PREVIOUS decode's arrays)
+  h->last_U = 0; h->last_B = 0;
+  h->last_overflow.clear(); h->last_beam_scores.clear();
   if (h->stream_state.active) return fail(UIS_ERR_INVALID_ARG, "a streaming session is open on this handle (uis_stream_end first)");
   const DevModel& m = h->m;
   const int B = opts->beam_size, L = opts->look_ahead, tau = opts->test_iteration;
@@ -640,8 +655,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if (m.D != m.Dp) ENSURE(xpad, (size_t)std::max<int64_t>(F, 1) * m.Dp * 4);
   ENSURE(gi0, (size_t)std::max<int64_t>(F, 1) * m.G * 4);
   ENSURE(mse0, (size_t)std::max<int64_t>(F, 1) * 4);
-  ENSURE(logblk, (size_t)(maxT + 2) * 8);
-  ENSURE(logden, (size_t)(maxT + 2) * 8);
+  // (k_decode_rs / k_decode_big<WS> copy the first UIS_RS_LOGTAB entries into LDS whatever the decode's length)
+  const int64_t n_log = std::max<int64_t>(maxT + 2, UIS_RS_LOGTAB);
+  ENSURE(logblk, (size_t)n_log * 8);
+  ENSURE(logden, (size_t)n_log * 8);
   ENSURE(pool_mean, (size_t)U * S * m.Dp * 4);
   ENSURE(pool_hid, ((size_t)U * S + 1) * m.depth * m.Hp * 4);  // + the slot k_decode_resident keeps h1 in
   ENSURE(pool_cnt, (size_t)U * S * 4);
@@ -694,8 +711,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const size_t mse_tab_bytes = ((size_t)2 * U * S * 4 + 255) & ~(size_t)255;
   if (rs) ENSURE(mse_tab, mse_tab_bytes + (size_t)nclq * rx_stride * 32 * 4);
   const bool dbg = (opts->flags & UIS_FLAG_DEBUG_SCORES) != 0;
-  if (dbg && L != 1) return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DEBUG_SCORES needs look_ahead 1");
-  const size_t dbg_floats = dbg ? (size_t)maxT * U * B * (Kmax + 1) : 0;
+  // one array per window: [windows][U][B][Kmax + 1] ^ look_ahead
+  double dbg_want = dbg ? (double)((maxT + L - 1) / L) * U * B : 0.0;
+  for (int k = 0; k < L; ++k) dbg_want *= (double)(Kmax + 1);
+  if (dbg_want > 1e9) return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_DEBUG_SCORES: more than 1e9 candidate scores (a test hook for small decodes)");
+  const size_t dbg_floats = (size_t)dbg_want;
   if (dbg) ENSURE(dbg_scores, std::max<size_t>(dbg_floats, 1) * 4);
   h->dbg_floats = 0;
   if (L > 1) {
@@ -752,8 +772,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   uint32_t* const ctl = reinterpret_cast<uint32_t*>(h->cluster_ctl.as<char>() + ctl_off);
 
   // ---- per-decode tables
-  std::vector<double> logblk(maxT + 2), logden(maxT + 2);
-  for (int64_t n = 0; n < maxT + 2; ++n) {
+  std::vector<double> logblk(n_log), logden(n_log);
+  for (int64_t n = 0; n < n_log; ++n) {
     logblk[n] = n > 0 ? std::log((double)n) : 0.0;      // np.log(block_counts[cluster]), uisrnn.py:418-419
     logden[n] = std::log((double)n + h->alpha);          // np.log(sum(block_counts) + crp_alpha)
   }
@@ -891,6 +911,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   }
 
   // ---- lock-step decode of every group on its own stream
+  int decode_kernel = UIS_DK_STEPWISE | (dense_family(h, opts->flags, (long)plan[0].st.max_rows) << 8);
   for (int g = 0; g < G; ++g) {
     GroupPlan& gp = plan[g];
     hipStream_t sg = h->gstreams[g];
@@ -917,6 +938,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                                             : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
+      decode_kernel = rs ? UIS_DK_RS : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
 #define UIS_BIGWS_CASE(HPV, DPV)                                                                                      \
   if (m.Hp == HPV && m.Dp == DPV && big_ws) {                                                                        \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_big<HPV, DPV, true>),                        \
@@ -1050,7 +1072,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
             (double)tc[75] * 0.01 / (double)maxT);
   }
 #endif
-  if (resident && tn.sig != 0 && tn.phase <= 4) {  // the decode's device time goes to the placement it ran with
+  if (resident && !rs && tn.sig != 0 && tn.phase <= 4 && !getenv("UIS_NO_CTL_TUNE")) {  // the decode's device time goes to the placement it ran with
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
     if (tn.phase >= 1) tn.ms[tn.phase - 1] = ms;
@@ -1078,6 +1100,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     }
     stats->n_overflow = n_over;
     stats->n_streams = G;
+    stats->decode_kernel = decode_kernel;
     if (profile) {
       for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
         float t = 0.0f;
@@ -1334,6 +1357,13 @@ UIS_EXPORT int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in
   HIPCHK(hipMemcpy(ho.data(), d_o, ho.size() * 4, hipMemcpyDeviceToHost));
   memcpy(mean_out, mo.data(), (size_t)m.D * 4);
   for (int l = 0; l < m.depth; ++l) memcpy(h_out + (size_t)l * m.H, ho.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+  return UIS_OK;
+}
+
+UIS_EXPORT int32_t uis_last_decode_shape(uis_handle* h, int32_t* n_utt_out, int32_t* beam_size_out) {
+  if (!h) return fail(UIS_ERR_INVALID_ARG, "null handle");
+  if (n_utt_out) *n_utt_out = h->last_U;
+  if (beam_size_out) *beam_size_out = h->last_B;
   return UIS_OK;
 }
 

@@ -3406,6 +3406,17 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     cscore[i] = sc;
     const bool fin = uis_isfinite(sc);
     key[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
+    if (st.dbg_scores && last) {
+      // UIS_FLAG_DEBUG_SCORES: the window's _calculate_score array (uisrnn.py:455-477) -- the score
+      // of the whole assignment tuple (c_1 .. c_Lw) of beam hypothesis `origin`, at
+      // [window][utterance][origin][c_1] .. [c_L] (a ragged last window: index 0 in the missing
+      // dimensions, as numpy lays a lower-dimensional array into predict_single's score_set)
+      const int origin = in.origin ? in.origin[b] : b;
+      size_t idx = ((size_t)win * st.U + u) * B + origin;
+      for (int k = 0; k < L; ++k)
+        idx = idx * (size_t)(Kmax + 1) + (size_t)(k < j ? (int)in.path[(size_t)b * L + k] : (k == j ? c : 0));
+      st.dbg_scores[idx] = sc;
+    }
   }
   __syncthreads();
 

@@ -208,12 +208,25 @@ class UISRNN:
       except _capi.HipLibraryError as err:
         if err.status != _capi.UIS_ERR_UNSUPPORTED or args.look_ahead < 2:
           raise
-        level_full = [u for k, u in enumerate(pending) if decoder.last_overflow(len(pending))[k] & 2]
+        # a look-ahead window of some utterances held more assignment prefixes than a level has
+        # room for (bit 1 of their flags).  The flags come from the library, sized by the library:
+        # a decode that was refused for its OPTIONS (look_ahead > 8, beam_size > 256) never
+        # started and leaves no flags behind -- that error goes up as it is.
+        flags_now = decoder.last_overflow()
+        if flags_now.shape[0] != len(pending):
+          raise
+        level_full = [u for k, u in enumerate(pending) if flags_now[k] & 2]
         if not level_full or len(level_full) == len(pending):
           raise
         # name the utterances, and decode the others again on their own: their results are valid
         rest = [u for u in pending if u not in level_full]
-        partial = self._decode_batch([sequences[u] for u in rest], args, flags, device, decoder)
+        try:
+          partial = self._decode_batch([sequences[u] for u in rest], args, flags, device, decoder)
+        except LookAheadWindowError as inner:
+          # (an utterance of `rest` that first hit the cluster cap and then, with twice the room, a
+          # full level: its indices are relative to `rest` -- hand them up in the caller's numbering)
+          partial = inner.results
+          level_full = sorted(level_full + [rest[k] for k in inner.utterances])
         for u, labels in zip(rest, partial):
           results[u] = labels
         exc = LookAheadWindowError('{} (utterances {})'.format(err, level_full))
