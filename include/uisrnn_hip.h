@@ -167,7 +167,9 @@ enum {
   UIS_DK_BIG = 4,        /* one launch, a wave per row tile (k_decode_big)                    */
   UIS_DK_BIG_WS = 5      /* ... with a rank's selects running concurrently (k_decode_big<WS>) */
 };
-/* ... and, in bits 8..15 for UIS_DK_STEPWISE, the dense kernels' family */
+/* ... in bits 16..23 for UIS_DK_RS its instantiation: 1 base, 2 base with the shape of BASELINE configs[1] as
+ * compile-time constants, 3 two utterances per wave (9 .. 16 per XCD), 4 wide (beam_size <= 32 / observation
+ * dim 512); and, in bits 8..15 for UIS_DK_STEPWISE, the dense kernels' family */
 enum { UIS_DF_DENSE = 1 /* k_dense_* split-K */, UIS_DF_BIG = 2 /* k_big_* */, UIS_DF_WT = 3 /* k_wt_* */ };
 
 /* kernel classes for uis_stats.kernel_ms */

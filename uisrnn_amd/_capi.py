@@ -49,10 +49,13 @@ DECODE_KERNELS = {0: 'none', 1: 'stepwise', 2: 'k_decode_rs', 3: 'k_decode_resid
 DENSE_FAMILIES = {0: '', 1: 'k_dense', 2: 'k_big', 3: 'k_wt'}
 
 
+RS_VARIANTS = {0: '', 1: '', 2: '', 3: '<2 per wave>', 4: '<wide>', 5: '<2 per wave>', 6: '<wide>'}
+
+
 def decode_kernel_name(code):
   name = DECODE_KERNELS.get(code & 0xff, 'unknown')
   fam = DENSE_FAMILIES.get((code >> 8) & 0xff, '')
-  return name + (':' + fam if fam else '')
+  return name + RS_VARIANTS.get((code >> 16) & 0xff, '') + (':' + fam if fam else '')
 
 
 _fp = ctypes.POINTER(ctypes.c_float)

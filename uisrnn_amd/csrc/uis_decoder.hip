@@ -702,14 +702,32 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const size_t ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
   static const size_t ctl_place[4] = {0, 8192, (size_t)1 << 20, ((size_t)1 << 20) + 8192};
   ENSURE(cluster_ctl, ctl_place[3] + ((ctl_words * 4 + 4095) & ~(size_t)4095));
-  // the one-launch decode with the REPLICATED select (k_decode_rs, uis_select_rs.hip): at most 8
-  // utterances per cluster, one per wave in every workgroup; the default where it applies
-  const bool rs = resident && !(opts->flags & UIS_FLAG_OWNER_SELECT) &&
-                  (UIS_RS_DEFAULT || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) && m.Dp <= 256 &&
-                  rs_select_ok(B, Kmax, S, U, ncl, (long)maxT) &&
-                  resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+  // the one-launch decode with the REPLICATED select (k_decode_rs, uis_select_rs.hip): every workgroup of
+  // an XCD decides all of the cluster's utterances, one wave each; the default where it applies.
+  // Its instantiations (shape classes), in the order tried:
+  //   RS_BASE   beam_size <= 16, <= 192 candidates, observation dim <= 256, at most 8 utterances per XCD
+  //   RS_C1     ... with beam_size 10 / max_clusters 16 as compile-time constants (BASELINE configs[1])
+  //   RS_UPW2   ... 9 .. 16 utterances per XCD: two utterances per wave
+  //   RS_WIDE   beam_size <= 32, <= 256 candidates, observation dim 256 or 512 (configs[4]), at most 8 per XCD
+  enum { RS_NONE = 0, RS_BASE, RS_C1, RS_UPW2, RS_WIDE, RS_UPW2_C1, RS_WIDE_C4 };
+  int rs_kind = RS_NONE;
+  if (resident && !(opts->flags & UIS_FLAG_OWNER_SELECT) && (UIS_RS_DEFAULT || (opts->flags & UIS_FLAG_REPLICATED_SELECT))) {
+    const int per_xcd = (U + ncl - 1) / ncl;
+    const bool base_shape = m.Dp <= 256 && rs_select_ok(B, Kmax, S, (long)maxT, 3);
+    if (base_shape && per_xcd <= UIS_RS_UTT && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024)
+      rs_kind = (m.Hp == 512 && m.Dp == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1")) ? RS_C1 : RS_BASE;
+    else if (base_shape && per_xcd <= 2 * UIS_RS_UTT && m.Hp == 512 && m.Dp == 256 &&
+             ((UIS_RS_UPW2_DEFAULT && !getenv("UIS_RS_NO_UPW2")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
+             resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 2, true) <= 160 * 1024)
+      rs_kind = (B == 10 && Kmax == 16 && getenv("UIS_RS_UPW2_C1")) ? RS_UPW2_C1 : RS_UPW2;
+    else if (per_xcd <= UIS_RS_UTT && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) && !getenv("UIS_RS_NO_WIDE") &&
+             rs_select_ok(B, Kmax, S, (long)maxT, 4) && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 1, true) <= 160 * 1024)
+      rs_kind = (m.Dp == 512 && B == 20 && Kmax == 11 && getenv("UIS_RS_WIDE_C4")) ? RS_WIDE_C4 : RS_WIDE;
+  }
+  const bool rs = rs_kind != RS_NONE;
   const size_t mse_tab_bytes = ((size_t)2 * U * S * 4 + 255) & ~(size_t)255;
-  if (rs) ENSURE(mse_tab, mse_tab_bytes + (size_t)nclq * rx_stride * 32 * 4);
+  const size_t mse_part_bytes = (size_t)nclq * rx_stride * rs_part_stride(m.Dp) * 4;
+  if (rs) ENSURE(mse_tab, mse_tab_bytes + mse_part_bytes);
   const bool dbg = (opts->flags & UIS_FLAG_DEBUG_SCORES) != 0;
   // one array per window: [windows][U][B][Kmax + 1] ^ look_ahead
   double dbg_want = dbg ? (double)((maxT + L - 1) / L) * U * B : 0.0;
@@ -789,7 +807,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemsetAsync(ctl, 0, ctl_words * 4, h->stream));
   if (dbg && dbg_floats) HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->dbg_scores.p), 0x7f800000, dbg_floats, h->stream));
   if (rs)  // tiles a model does not have stay +0 in every row's partial sums
-    HIPCHK(hipMemsetAsync(h->mse_tab.as<char>() + mse_tab_bytes, 0, (size_t)nclq * rx_stride * 32 * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->mse_tab.as<char>() + mse_tab_bytes, 0, mse_part_bytes, h->stream));
   // once per decode: pad (only when D is not a multiple of 16), gi0 = W_ih0 x + b_ih0, mse0.
   // Host frames (uis_decode) arrive in chunks on the copy stream; chunk i's kernels overlap the
   // H2D of chunk i+1 (true overlap needs pinned host memory, uis_host_alloc).
@@ -925,20 +943,22 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // more utterances than workgroups: the variant whose dense stages give a wave a whole row tile
       // (k_decode_big: +6 % at 288 utterances, +17 % at 768 / 1024; up to 256 the LDS-resident beam of
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
-      const bool big = U > 32 * ncl && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
+      const int big_from = getenv("UIS_BIG_MIN_U") ? atoi(getenv("UIS_BIG_MIN_U")) : 32 * ncl + 1;  // (experiments: where k_decode_big takes over)
+      const bool big = U >= big_from && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
                        big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
       // ... with the selects of a rank's utterances running concurrently, one wave each (k_decode_big<.., true>),
       // where the single-wave select applies; UIS_FLAG_OWNER_SELECT keeps them one after the other
       const int per_rank = (((U + ncl - 1) / ncl) + 31) / 32;
       const bool big_ws = big && !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
-                          rs_select_ok(B, Kmax, S, 1, 1, (long)maxT) &&
+                          rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
                           big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
-      const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
+      const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_kind == RS_UPW2 ? 2 : 1,
+                                                                             rs_kind == RS_UPW2 || rs_kind == RS_WIDE)
                                             : big_ws ? big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
                                             : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
-      decode_kernel = rs ? UIS_DK_RS : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
+      decode_kernel = rs ? (UIS_DK_RS | (rs_kind << 16)) : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
 #define UIS_BIGWS_CASE(HPV, DPV)                                                                                      \
   if (m.Hp == HPV && m.Dp == DPV && big_ws) {                                                                        \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_big<HPV, DPV, true>),                        \
@@ -952,18 +972,25 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_BIGWS_CASE(256, 256)
       UIS_BIGWS_CASE(256, 128)
 #undef UIS_BIGWS_CASE
-#define UIS_RS_CASE(HPV, DPV)                                                                                         \
-  if (m.Hp == HPV && m.Dp == DPV && rs) {                                                                            \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_rs<HPV, DPV>),                               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
-    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_rs<HPV, DPV>, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m,   \
-                                 gp.st)))                                                                            \
+#define UIS_RS_CASE(KIND, HPV, DPV, ...)                                                                              \
+  if (m.Hp == HPV && m.Dp == DPV && rs_kind == KIND) {                                                               \
+    void (*kern)(DevModel, DecodeState) = &k_decode_rs<HPV, DPV, __VA_ARGS__>;                                      \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
       return rc;                                                                                                     \
   }
-      UIS_RS_CASE(512, 256)
-      UIS_RS_CASE(512, 128)
-      UIS_RS_CASE(256, 256)
-      UIS_RS_CASE(256, 128)
+      //          kind      HP   DP   NPOS UPW CB  CK  SPLIT2
+      UIS_RS_CASE(RS_BASE, 512, 256, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_BASE, 512, 128, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_BASE, 256, 256, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_BASE, 256, 128, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_C1, 512, 256, 3, 1, 10, 16, false)
+      UIS_RS_CASE(RS_UPW2, 512, 256, 3, 2, 0, 0, true)
+      UIS_RS_CASE(RS_UPW2_C1, 512, 256, 3, 2, 10, 16, true)
+      UIS_RS_CASE(RS_WIDE, 512, 256, 4, 1, 0, 0, true)
+      UIS_RS_CASE(RS_WIDE, 512, 512, 4, 1, 0, 0, true)
+      UIS_RS_CASE(RS_WIDE_C4, 512, 512, 4, 1, 20, 11, true)
 #undef UIS_RS_CASE
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
   if (m.Hp == HPV && m.Dp == DPV && !rs && !big_ws) {                                                                \

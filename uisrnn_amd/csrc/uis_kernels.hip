@@ -2987,8 +2987,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       RsWin win;
       win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
       if (act_w) {
-        const RsPrep prep = rs_prep<true>(m, st, RL, s, pers_w, scr_w, ws_lblk, ws_lden, []() {});
-        win = rs_front<DP, true>(m, st, RL, u_w, s, frame_w, pers_w, scr_w, nullptr, prep, nullptr, ws_swgt);
+        const RsDims dm{st.B, st.Kmax, S};
+        const RsPrep<3> prep = rs_prep<true, 3>(m, st, RL, dm, s, pers_w, scr_w, ws_lblk, ws_lden, []() {});
+        win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s, frame_w, pers_w, scr_w, nullptr, prep, nullptr, ws_swgt);
         int row_base = 0;
         if (lane == 0 && win.nlead > 0) row_base = atomicAdd(sink.count, win.nlead);
         row_base = __shfl(row_base, 0, 64);
@@ -3000,7 +3001,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       RSTAMP(0);
       xcd_arrive(st, cluster, s_ctl);
       if (act_w) {
-        rs_back(m, st, RL, u_w, s, off0_w, pers_w, true, win, []() {});
+        rs_back<3>(m, st, RL, RsDims{st.B, st.Kmax, S}, u_w, s, off0_w, pers_w, true, win, []() {});
         fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
       }
       if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;

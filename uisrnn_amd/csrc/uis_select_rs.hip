@@ -40,12 +40,23 @@
 #ifndef UIS_RS_DEFAULT
 #define UIS_RS_DEFAULT 1
 #endif
-#define UIS_RS_UTT 8        // utterances per cluster (one per wave)
-#define UIS_RS_MAXB 16      // beam_size
+// 1: two utterances per wave (9 .. 16 utterances per XCD) is the default where it applies; 0: only with
+// UIS_FLAG_REPLICATED_SELECT (k_decode_resident keeps those batches)
+#ifndef UIS_RS_UPW2_DEFAULT
+#define UIS_RS_UPW2_DEFAULT 1
+#endif
+#define UIS_RS_UTT 8        // waves per workgroup = utterance slots per cluster and UPW (utterances per wave)
 #define UIS_RS_MAXS 256     // slots per utterance (four 64-bit masks)
-#define UIS_RS_MAXC 192     // grid positions: beam_size * (max_clusters + 1) (three per lane)
 #define UIS_RS_LOGTAB 128   // entries of the LDS copies of the log tables (larger counts: global)
 #define UIS_RS_NOKEY 0xffffffffu
+// NPOS = candidate-grid positions per lane (template parameter of the select): 3 -> at most 192
+// candidates (beam_size * (max_clusters + 1)) and beam_size <= 16; 4 -> 256 and beam_size <= 32
+__host__ __device__ constexpr int rs_max_beam(int npos) { return npos <= 3 ? 16 : 32; }
+__host__ __device__ constexpr int rs_max_grid(int npos) { return 64 * npos; }
+
+// beam_size, max_clusters, slots per utterance: run-time values, or compile-time constants in the
+// instantiations built for one shape (every RsLds offset then folds into the instruction stream)
+struct RsDims { int B, Kmax, S; };
 
 struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
@@ -60,7 +71,7 @@ struct RsLds {
   int off_newlist;                           // int32 [1 + B] count, slots written by the previous step
   int off_stats;                             // u64 [4]      decode statistics (the owner flushes them at the end)
   int persist_stride;
-  // per wave, scratch (lives in the split-K area: the select's front part and the dense stages
+  // per utterance slot, scratch (lives in the split-K area: the select's front part and the dense stages
   // never overlap; rs_back, which runs inside the GRU stage, only touches the persistent blocks)
   int sc_mse;                                // float [S]
   int sc_dst;                                // int32 [B]    the ord-th free slot
@@ -98,24 +109,33 @@ __host__ __device__ inline RsLds rs_lds_layout(int B, int Kmax, int S) {
   return l;
 }
 
-__host__ __device__ inline bool rs_select_ok(int B, int Kmax, int S, int U, int ncl, long max_steps) {
-  return B <= UIS_RS_MAXB && B * (Kmax + 1) <= UIS_RS_MAXC && S <= UIS_RS_MAXS && U <= UIS_RS_UTT * ncl &&
-         max_steps < 65535;
+// the single-wave select applies (NPOS grid positions per lane)
+__host__ __device__ inline bool rs_select_ok(int B, int Kmax, int S, long max_steps, int npos = 3) {
+  return B <= rs_max_beam(npos) && B * (Kmax + 1) <= rs_max_grid(npos) && S <= UIS_RS_MAXS && max_steps < 65535;
 }
 
-// row-tile descriptors built locally: enough tiles for every utterance's beam_size rows
-__host__ __device__ inline int rs_head_tiles(int B) { return (UIS_RS_UTT * B + 15) / 16; }
+// floats per row of mse_part: the 16-feature tiles' partial sums, then the squared first difference
+__host__ __device__ constexpr int rs_part_stride(int Dp) { return Dp <= 256 ? 32 : 48; }
+__host__ __device__ constexpr int rs_part_first(int Dp) { return Dp <= 256 ? 16 : 32; }
 
-// LDS of k_decode_rs: 1 / (2 sigma^2) | log tables | the utterances' persistent blocks | split-K
-// partial tiles (the waves' select scratch lives in the same bytes) | control words | the rank's
-// linear_mean1 / linear_mean2 weight tiles | this step's row descriptors (built locally)
-__host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+// row-tile descriptors built locally: enough tiles for every utterance slot's beam_size rows
+__host__ __device__ inline int rs_head_tiles(int B, int upw) { return (UIS_RS_UTT * upw * B + 15) / 16; }
+
+// bytes of the split-K partial tiles: all three GRU gates of RC row tiles from eight waves at once,
+// or -- SPLIT2, the instantiations whose tables need the room -- two gates, then the third
+__host__ __device__ inline size_t rs_spart_bytes(bool split2) { return (size_t)UIS_KSPLIT * UIS_RES_RC * (split2 ? 2 : 3) * 256 * 4; }
+
+// LDS of k_decode_rs: 1 / (2 sigma^2) | log tables | the utterance slots' persistent blocks | split-K
+// partial tiles (the slots' select scratch lives in the same bytes) | control words | the rank's
+// linear_mean1 / linear_mean2 weight tiles | this step's row descriptors (built locally) | frames
+__host__ __device__ inline size_t resident_rs_lds_bytes(int Hp, int Dp, int B, int Kmax, int S, int upw = 1, bool split2 = false) {
   const RsLds L = rs_lds_layout(B, Kmax, S);
-  const size_t spart = (size_t)UIS_KSPLIT * UIS_RES_RC * 3 * 256 * 4;
-  const size_t scratch = (size_t)UIS_RS_UTT * L.scratch_stride;
-  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)UIS_RS_UTT * L.persist_stride +
-         (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B) * 16 * 16 +
-         (size_t)2 * UIS_RS_UTT * 8;
+  const int slots = UIS_RS_UTT * upw;
+  const size_t spart = rs_spart_bytes(split2);
+  const size_t scratch = (size_t)slots * L.scratch_stride;
+  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)slots * L.persist_stride +
+         (spart > scratch ? spart : scratch) + 128 + (size_t)2 * (Hp / 16) * 64 * 16 + (size_t)rs_head_tiles(B, upw) * 16 * 16 +
+         (size_t)2 * slots * 8;
 }
 
 // ceil(2^20 / d) for 1 <= d < 4096 without the integer-division sequence: the float quotient of
@@ -155,29 +175,45 @@ __device__ __forceinline__ int rs_wave_max_i32(int v) {  // small non-negative v
   return (int)~rs_wave_min_u32(~(uint32_t)v);
 }
 
-// Weighted MSE of the frame (xv: this lane's four float4 chunks) against the mean whose chunks are
-// in mv, by the 16 lanes of a quarter wave in the canonical tree (include/uis_numerics.h): lane p
-// holds d = 4 * (p + 16 k), k = 0..3.  Lane p == 0 returns the value.  DP <= 256.
+// Weighted MSE of the frame (xv: this lane's float4 chunks) against the mean whose chunks are in mv, by
+// the 16 lanes of a quarter wave in the canonical tree (include/uis_numerics.h): lane p holds
+// d = 256 c + 4 * (p + 16 k), k = 0..3, of 256-float block c (index 4 c + k).  Lane p == 0 returns the
+// value.  DP <= 512: one or two blocks.
 template <int DP>
-__device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&mv)[4], const f32x4 (&xv)[4], const float* swgt,
-                                               int p) {
-  f32x4 wv[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int d = 4 * (p + 16 * k);
-    wv[k] = d < DP ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
+__device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&mv)[4 * ((DP + 255) / 256)],
+                                               const f32x4 (&xv)[4 * ((DP + 255) / 256)], const float* swgt, int p) {
+  constexpr int NB = (DP + 255) / 256;
   float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  mse16_block(mv, xv, wv, A);  // (chunks past DP are zero-filled)
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    f32x4 wv[4], mc[4], xc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = 256 * c + 4 * (p + 16 * k);
+      wv[k] = d < DP ? *reinterpret_cast<const f32x4*>(swgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      mc[k] = mv[4 * c + k];
+      xc[k] = xv[4 * c + k];
+    }
+    mse16_block(mc, xc, wv, A);  // (chunks past DP are zero-filled)
+  }
   const float d0 = mv[0][0] - xv[0][0];  // meaningful on lane p == 0 (d = 0): the only lane whose value is stored
   return uis_mse_finish(mse16_total(A), d0 * d0, m.D);
 }
 template <int DP>
-__device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, size_t slot_index, int p, f32x4 (&mv)[4]) {
+__device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, size_t slot_index, int p,
+                                               f32x4 (&mv)[4 * ((DP + 255) / 256)]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int d = 4 * (p + 16 * k);
+  for (int k = 0; k < 4 * ((DP + 255) / 256); ++k) {
+    const int d = 256 * (k >> 2) + 4 * (p + 16 * (k & 3));
     mv[k] = d < DP ? load_sc1(rs_mean, (uint32_t)((slot_index * DP + d) * 4)) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+}
+template <int DP>
+__device__ __forceinline__ void rs_load_frame16(const float* xrow, int p, f32x4 (&xv)[4 * ((DP + 255) / 256)]) {
+#pragma unroll
+  for (int k = 0; k < 4 * ((DP + 255) / 256); ++k) {
+    const int d = 256 * (k >> 2) + 4 * (p + 16 * (k & 3));
+    xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
 }
 
@@ -204,25 +240,26 @@ __device__ __forceinline__ void rs_lds_fence() { asm volatile("" ::: "memory"); 
 // PREP: everything about a step's candidates that needs nothing but the utterance's tables -- the
 // candidate grid with each candidate's slot, prior and hypothesis score, the live / new slot masks,
 // the first beam_size free slots.  Runs one step ahead, inside the previous step's last barrier.
-// The grid: position e = b * Kcur + c (hypothesis b, cluster c <= K_b), three positions per lane.
+// The grid: position e = b * Kcur + c (hypothesis b, cluster c <= K_b), NPOS positions per lane.
+template <int NPOS>
 struct RsPrep {
   int nb, nch, C, nn;                 // wave-uniform
   int Kcur, kmagic;
   unsigned long long old0, old1, old2, old3;  // live slots the previous step left alone (their MSEs are published); FULL: every live slot
-  int cslot0, cslot1, cslot2;         // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
+  int cslot[NPOS];                    // >= 0: slot whose MSE the candidate takes; -1: fresh cluster; -2: no candidate
   int stay;                           // bit k: the candidate at position lane + 64 k keeps its hypothesis' last cluster
-  double pr0, pr1, pr2;
-  float bs0, bs1, bs2;
+  double pr[NPOS];
+  float bs[NPOS];
 };
 
-template <bool FULL = false, typename Mid>
-__device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& st, const RsLds& L, int step,
-                                          const unsigned char* pers, unsigned char* scr, const double* s_lblk,
-                                          const double* s_lden, Mid mid) {
+template <bool FULL = false, int NPOS = 3, typename Mid>
+__device__ __forceinline__ RsPrep<NPOS> rs_prep(const DevModel& m, const DecodeState& st, const RsLds& L, const RsDims dm, int step,
+                                                const unsigned char* pers, unsigned char* scr, const double* s_lblk,
+                                                const double* s_lden, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
-  const int B = st.B, Kmax = st.Kmax, S = st.S;
+  const int B = dm.B, Kmax = dm.Kmax, S = dm.S;
   const int par = step & 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   const u32x4* shyp = reinterpret_cast<const u32x4*>(set_cur + L.off_hyp);
@@ -232,7 +269,7 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
   const int* snewlist = reinterpret_cast<const int*>(pers + L.off_newlist);
   int* sdst = reinterpret_cast<int*>(scr + L.sc_dst);
-  RsPrep P;
+  RsPrep<NPOS> P;
   P.nb = shdr[0]; P.Kcur = shdr[1]; P.kmagic = shdr[2];
   P.nn = snewlist[0];
   const int nb = P.nb, Kcur = P.Kcur, kmagic = P.kmagic;
@@ -263,10 +300,9 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
     for (int i = lane; i <= S; i += 64) slead[i] = 0xffffffffu;
   }
   P.nch = (nb * Kcur + 63) >> 6;
-  P.cslot0 = P.cslot1 = P.cslot2 = -2;
-  P.pr0 = P.pr1 = P.pr2 = 0.0;
-  P.bs0 = P.bs1 = P.bs2 = 0.0f;
   P.stay = 0;
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) { P.cslot[k] = -2; P.pr[k] = 0.0; P.bs[k] = 0.0f; }
   auto prep_at = [&](int e, int k, int& cslot, double& prior, float& base) {
     const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
     if (b < nb) {
@@ -295,25 +331,27 @@ __device__ __forceinline__ RsPrep rs_prep(const DevModel& m, const DecodeState& 
     }
   };
   mid();  // (the caller's early load)
-  prep_at(lane, 0, P.cslot0, P.pr0, P.bs0);
-  if (P.nch > 1) prep_at(lane + 64, 1, P.cslot1, P.pr1, P.bs1);
-  if (P.nch > 2) prep_at(lane + 128, 2, P.cslot2, P.pr2, P.bs2);
-  P.C = __popcll(__ballot(P.cslot0 != -2)) + __popcll(__ballot(P.cslot1 != -2)) + __popcll(__ballot(P.cslot2 != -2));
+  P.C = 0;
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    if (k == 0 || P.nch > k) prep_at(lane + 64 * k, k, P.cslot[k], P.pr[k], P.bs[k]);
+    P.C += __popcll(__ballot(P.cslot[k] != -2));
+  }
   return P;
 }
 
 // FRONT: the MSEs, scores, prune, winners, rows -- what the step's dense stages wait for.  One wave
 // (all 64 lanes), utterance u, decode step `step` whose frame is row `frame` of the stream.  pers =
-// the utterance's persistent block, scr = this wave's scratch (rs_prep left the free slots there).
+// the utterance's persistent block, scr = its scratch (rs_prep left the free slots there).
 // `part0` = where the partial sums of the rows this utterance emitted in the previous step start
 // (the i-th slot of its new-slot list was written by its i-th row).
 // FULL: the wave computes the MSE of the frame against EVERY live cluster mean itself (no published
 // values, no partial sums: k_decode_big, where a wave owns its utterance alone); P.old* then lists all
 // live slots and `swgt_full` is 1 / (2 sigma^2) in LDS.
-template <int DP, bool FULL = false>
-__device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long frame,
-                                          unsigned char* pers, unsigned char* scr, const float* part0, const RsPrep& P,
-                                          unsigned long long* ph, const float* swgt_full = nullptr) {
+template <int DP, bool FULL = false, int NPOS = 3>
+__device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, const RsDims dm, int u, int step,
+                                          long frame, unsigned char* pers, unsigned char* scr, const float* part0,
+                                          const RsPrep<NPOS>& P, unsigned long long* ph, const float* swgt_full = nullptr) {
   // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
   // it would have to stay live -- spilled -- across the dense stages)
   int lane_ = threadIdx.x & 63;
@@ -325,7 +363,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 #else
 #define PSTAMP(k) do {} while (0)
 #endif
-  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int B = dm.B, Kmax = dm.Kmax, S = dm.S, U = st.U;
   const int par = step & 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   const u32x4* shyp = reinterpret_cast<const u32x4*>(set_cur + L.off_hyp);
@@ -336,9 +374,6 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const int* sdst = reinterpret_cast<const int*>(scr + L.sc_dst);
 
   const int Kcur = P.Kcur, kmagic = P.kmagic, nch = P.nch, C = P.C, nn = P.nn;
-  const int cslot0 = P.cslot0, cslot1 = P.cslot1, cslot2 = P.cslot2;
-  const double pr0 = P.pr0, pr1 = P.pr1, pr2 = P.pr2;
-  const float bs0 = P.bs0, bs1 = P.bs1, bs2 = P.bs2;
   const unsigned long long old[4] = {P.old0, P.old1, P.old2, P.old3};
   const float mse_new = st.mse0[frame];
   if (FULL) {
@@ -356,18 +391,14 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     }
     rs_lds_fence();
     if (n > 0) {
+      constexpr int NV = 4 * ((DP + 255) / 256);
       const __amdgpu_buffer_rsrc_t rs_mean =
           __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
       const int grp = lane >> 4, p = lane & 15;
-      const float* xrow = st.x + (size_t)frame * DP;
-      f32x4 xv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int d = 4 * (p + 16 * k);
-        xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      }
+      f32x4 xv[NV];
+      rs_load_frame16<DP>(st.x + (size_t)frame * DP, p, xv);
       for (int i0 = 0; i0 < n; i0 += 8) {
-        f32x4 mv[2][4];
+        f32x4 mv[2][NV];
         int sl[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -385,7 +416,8 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   } else {
   // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
   // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
-  // (sixteen floats + the squared first difference per cluster: lane i takes new cluster i)
+  // (one float per 16-feature tile + the squared first difference per cluster: lane i takes new cluster i)
+  constexpr int PSTR = rs_part_stride(DP), PV = DP <= 256 ? 4 : 8;
   float vold[4];
   {
     const float* tab = st.mse_tab + ((size_t)par * U + u) * S;
@@ -395,7 +427,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
       if ((old[k] >> lane) & 1ull) vold[k] = load_f32_sc1(tab + lane + 64 * k);
     }
   }
-  f32x4 pv[4];
+  f32x4 pv[PV];
   float pfirst = 0.0f;
   int nsl = 0;
   if (lane < nn) {
@@ -403,8 +435,8 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
         __builtin_amdgcn_make_buffer_rsrc((void*)part0, (short)0, 0x7fffffff, 0x00020000);
     nsl = snewlist[1 + lane];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * 128 + 16 * k));
-    pfirst = load_f32_sc1(part0 + lane * 32 + 16);
+    for (int k = 0; k < PV; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * PSTR * 4 + 16 * k));
+    pfirst = load_f32_sc1(part0 + lane * PSTR + rs_part_first(DP));
   }
   PSTAMP(0);
   // ---- the MSEs: the published values first (they arrive first), then the rewritten clusters
@@ -414,7 +446,13 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   if (lane < nn) {
     float A[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { A[4 * k] = pv[k][0]; A[4 * k + 1] = pv[k][1]; A[4 * k + 2] = pv[k][2]; A[4 * k + 3] = pv[k][3]; }
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // uis_numerics.h: accumulator p = tile p (+ tile p + 16, left to right)
+        A[4 * k + e] = PV == 4 ? pv[k][e] : pv[k][e] + pv[(k + 4) & (PV - 1)][e];
+      }
+    }
     smse[nsl] = uis_mse_finish(uis_mse_acc_sum(A), pfirst, m.D);
   }
   }
@@ -422,29 +460,31 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   PSTAMP(1);
 
   // ---- candidate scores
-  uint32_t key0 = UIS_RS_NOKEY, key1 = UIS_RS_NOKEY, key2 = UIS_RS_NOKEY;
-  float sc0 = 0.0f, sc1 = 0.0f, sc2 = 0.0f;
-  auto score_at = [&](int cslot, double prior, float base, uint32_t& key, float& sc) {
-    if (cslot != -2) {
-      const float mse = cslot >= 0 ? smse[cslot] : mse_new;
-      sc = base + uis_step_loss(mse, prior);
-      if (uis_isfinite(sc)) key = uis_score_key(sc);
+  uint32_t key[NPOS];
+  float sc[NPOS];
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    key[k] = UIS_RS_NOKEY;
+    sc[k] = 0.0f;
+    if ((k == 0 || nch > k) && P.cslot[k] != -2) {
+      const float mse = P.cslot[k] >= 0 ? smse[P.cslot[k]] : mse_new;
+      sc[k] = P.bs[k] + uis_step_loss(mse, P.pr[k]);
+      if (uis_isfinite(sc[k])) key[k] = uis_score_key(sc[k]);
     }
-  };
-  score_at(cslot0, pr0, bs0, key0, sc0);
-  if (nch > 1) score_at(cslot1, pr1, bs1, key1, sc1);
-  if (nch > 2) score_at(cslot2, pr2, bs2, key2, sc2);
-  if (st.dbg_scores) {  // UIS_FLAG_DEBUG_SCORES: the step's _calculate_score arrays
-    auto keep_at = [&](int e, int cslot, float sc) {
-      const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
-      if (cslot != -2) st.dbg_scores[(((size_t)step * U + u) * B + b) * (Kmax + 1) + c] = sc;
-    };
-    keep_at(lane, cslot0, sc0);
-    if (nch > 1) keep_at(lane + 64, cslot1, sc1);
-    if (nch > 2) keep_at(lane + 128, cslot2, sc2);
   }
-  const int nfin = __popcll(__ballot(key0 != UIS_RS_NOKEY)) + __popcll(__ballot(key1 != UIS_RS_NOKEY)) +
-                   __popcll(__ballot(key2 != UIS_RS_NOKEY));
+  if (st.dbg_scores) {  // UIS_FLAG_DEBUG_SCORES: the step's _calculate_score arrays
+#pragma unroll
+    for (int k = 0; k < NPOS; ++k) {
+      if ((k == 0 || nch > k) && P.cslot[k] != -2) {
+        const int e = lane + 64 * k;
+        const int b = (int)(((unsigned)e * (unsigned)kmagic) >> 20), c = e - b * Kcur;
+        st.dbg_scores[(((size_t)step * U + u) * B + b) * (Kmax + 1) + c] = sc[k];
+      }
+    }
+  }
+  int nfin = 0;
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) nfin += __popcll(__ballot(key[k] != UIS_RS_NOKEY));
   const int keep = nfin < B ? nfin : B;
   PSTAMP(2);
 
@@ -457,19 +497,27 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   float win_sc = 0.0f;
   uint32_t thr = UIS_RS_NOKEY;
   {
-    const bool s0 = (P.stay & 1) != 0, s1 = (P.stay & 2) != 0, s2 = (P.stay & 4) != 0;
-    const int nstay = __popcll(__ballot(s0)) + __popcll(__ballot(s1)) + __popcll(__ballot(s2));
-    if (nstay >= B) {
-      uint32_t wk = s0 ? key0 : 0u;
-      wk = s1 && key1 > wk ? key1 : wk;
-      wk = s2 && key2 > wk ? key2 : wk;
-      thr = ~rs_wave_min_u32(~wk);  // the worst of them (a non-finite one: no threshold)
+    int nstay = 0;
+    uint32_t wk = 0u;
+#pragma unroll
+    for (int k = 0; k < NPOS; ++k) {
+      const bool sk = ((P.stay >> k) & 1) != 0;
+      nstay += __popcll(__ballot(sk));
+      wk = sk && key[k] > wk ? key[k] : wk;
     }
+    if (nstay >= B) thr = ~rs_wave_min_u32(~wk);  // the worst of them (a non-finite one: no threshold)
   }
-  const bool v0 = key0 != UIS_RS_NOKEY && key0 <= thr, v1 = key1 != UIS_RS_NOKEY && key1 <= thr,
-             v2 = key2 != UIS_RS_NOKEY && key2 <= thr;
-  const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1), m2 = __ballot(v2);
-  const int n0 = __popcll(m0), n1 = __popcll(m1), nsv = n0 + n1 + __popcll(m2);
+  bool v[NPOS];
+  unsigned long long vm[NPOS];
+  int nbefore[NPOS + 1];
+  nbefore[0] = 0;
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    v[k] = key[k] != UIS_RS_NOKEY && key[k] <= thr;
+    vm[k] = __ballot(v[k]);
+    nbefore[k + 1] = nbefore[k] + __popcll(vm[k]);
+  }
+  const int nsv = nbefore[NPOS];
 #if defined(UIS_RS_COUNT_PATHS)  // diagnostic: how long the short lists are (workgroup 0's copies; uis_decoder.hip prints them)
   if (!FULL && blockIdx.x == 0 && lane == 0) atomicAdd(&st.counters[88 + (nsv <= 16 ? 0 : nsv <= 32 ? 1 : nsv <= 64 ? 2 : 3)], 1ull);
 #endif
@@ -477,9 +525,9 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     uint32_t* sck = reinterpret_cast<uint32_t*>(scr + L.sc_ckey);
     int* sce = reinterpret_cast<int*>(scr + L.sc_ce);
     float* scs = reinterpret_cast<float*>(scr + L.sc_csc);
-    if (v0) { const int q = rs_below(m0); sck[q] = key0; sce[q] = lane; scs[q] = sc0; }
-    if (v1) { const int q = n0 + rs_below(m1); sck[q] = key1; sce[q] = lane + 64; scs[q] = sc1; }
-    if (v2) { const int q = n0 + n1 + rs_below(m2); sck[q] = key2; sce[q] = lane + 128; scs[q] = sc2; }
+#pragma unroll
+    for (int k = 0; k < NPOS; ++k)
+      if (v[k]) { const int q = nbefore[k] + rs_below(vm[k]); sck[q] = key[k]; sce[q] = lane + 64 * k; scs[q] = sc[k]; }
     if (lane >= nsv) sck[lane] = UIS_RS_NOKEY;  // (beats nobody)
     rs_lds_fence();
     const bool mine = lane < nsv;
@@ -505,41 +553,33 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
     if (nsv > 16) count16(16);
     if (nsv > 32) { count16(32); if (nsv > 48) count16(48); }
     // entry -> lane `rank` of the winners: a forward permute (the others send to lane 63, which is
-    // never a winner: keep <= 16)
+    // never a winner: keep <= 32)
     const int to = (mine && rank < keep) ? rank : 63;
     win_e = __builtin_amdgcn_ds_permute(to << 2, ce);
     win_sc = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(to << 2, __builtin_bit_cast(int, cs)));
   } else {
     // (more than 64 survivors -- a model that switches freely, a beam not yet full: `keep` rounds of
-    // the wave-wide minimum)
+    // the wave-wide minimum; among equal keys the lowest grid position: chunk k before k + 1, lowest lane first)
     for (int r = 0; r < keep; ++r) {
-      uint32_t loc = key0 < key1 ? key0 : key1;
-      loc = loc < key2 ? loc : key2;
+      uint32_t loc = key[0];
+#pragma unroll
+      for (int k = 1; k < NPOS; ++k) loc = loc < key[k] ? loc : key[k];
       const uint32_t mn = rs_wave_min_u32(loc);
-      unsigned long long mk = __ballot(key0 == mn);
-      int l, e;
-      float s;
-      if (mk) {
-        l = __ffsll((long long)mk) - 1;
-        e = l;
-        s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc0), l));
-        if (lane == l) key0 = UIS_RS_NOKEY;
-      } else {
-        mk = __ballot(key1 == mn);
-        if (mk) {
-          l = __ffsll((long long)mk) - 1;
-          e = l + 64;
-          s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc1), l));
-          if (lane == l) key1 = UIS_RS_NOKEY;
-        } else {
-          mk = __ballot(key2 == mn);
-          l = __ffsll((long long)mk) - 1;
-          e = l + 128;
-          s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc2), l));
-          if (lane == l) key2 = UIS_RS_NOKEY;
+      int e = 0;
+      float sv = 0.0f;
+      bool found = false;
+#pragma unroll
+      for (int k = 0; k < NPOS; ++k) {
+        const unsigned long long mk = __ballot(key[k] == mn);
+        if (!found && mk) {
+          const int l = __ffsll((long long)mk) - 1;
+          e = l + 64 * k;
+          sv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sc[k]), l));
+          if (lane == l) key[k] = UIS_RS_NOKEY;
+          found = true;
         }
       }
-      if (lane == r) { win_e = e; win_sc = s; }
+      if (lane == r) { win_e = e; win_sc = sv; }
     }
   }
   PSTAMP(3);
@@ -591,13 +631,13 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
 
 // BACK: the next step's tables, masks and counts, the back-pointers -- nothing anybody waits for.
 // `owner`: this workgroup writes what outlives the step to memory.
-template <typename Mid>
-__device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step, long off0,
-                                        unsigned char* pers, bool owner, const RsWin& w, Mid mid) {
+template <int NPOS = 3, typename Mid>
+__device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st, const RsLds& L, const RsDims dm, int u, int step,
+                                        long off0, unsigned char* pers, bool owner, const RsWin& w, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
-  const int B = st.B, Kmax = st.Kmax, S = st.S, U = st.U;
+  const int B = dm.B, Kmax = dm.Kmax, S = dm.S, U = st.U;
   const int par = step & 1, nxt = par ^ 1;
   const unsigned char* const set_cur = pers + par * L.set_stride;
   unsigned char* const set_nxt = pers + nxt * L.set_stride;
@@ -638,14 +678,15 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
   rs_lds_fence();
   const int Kmaxseen = rs_wave_max_i32(Knew_w);
   {
-    // every entry of every winner: four lanes per winner (B <= 16), lane q of them takes the
-    // clusters q, q + 4, ...; the changed entry from the winner's record, the unchanged ones from
-    // the parent's row (BeamState(source), uisrnn.py:66-69)
-    const int rr = lane >> 2, q = lane & 3;
+    // every entry of every winner: LPW lanes per winner (four with beam_size <= 16, two up to 32), lane q
+    // of them takes the clusters q, q + LPW, ...; the changed entry from the winner's record, the
+    // unchanged ones from the parent's row (BeamState(source), uisrnn.py:66-69)
+    constexpr int LPW = 64 / rs_max_beam(NPOS);
+    const int rr = lane / LPW, q = lane % LPW;
     const unsigned ia = (unsigned)__shfl((int)w.a, rr, 64), ib = (unsigned)__shfl((int)info_b, rr, 64);
     const int Knew = __shfl(Knew_w, rr, 64);
     const int rb = (int)(ia & 0xffu), rc = (int)((ia >> 8) & 0xfffu);
-    for (int c2 = q; c2 < Kmaxseen; c2 += 4) {
+    for (int c2 = q; c2 < Kmaxseen; c2 += LPW) {
       if (rr < w.keep && c2 < Knew) {
         const uint32_t en = c2 == rc ? ib : sent[rb * Kmax + c2];  // slot | block count << 16
         nent[rr * Kmax + c2] = en;
@@ -693,17 +734,17 @@ __device__ __forceinline__ void rs_back(const DevModel& m, const DecodeState& st
 // handful, in one round trip, between the arrival at the barrier behind the GRU stage and the wait
 // (it needs nobody else's data of this step: those means were final a step ago).
 template <int DP, typename Mid>
-__device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeState& st, const RsLds& L, int u, int step,
-                                             long frame_next, const unsigned char* pers, unsigned char* scr, const float* swgt,
+__device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeState& st, const RsLds& L, const RsDims dm, int u, int step,
+                                             long frame_next, const unsigned char* pers, const float* swgt,
                                              int rank, int w, Mid mid) {
   int lane_ = threadIdx.x & 63;
   asm volatile("" : "+v"(lane_));
   const int lane = lane_;
-  const int S = st.S, U = st.U;
+  const int S = dm.S, U = st.U;
   const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers + L.off_live);
   const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers + L.off_new);
   // (the list lives in rs_back's byte-flag area, free between two steps' table updates -- NOT in the
-  // wave's scratch: that aliases the split-K tiles, which a faster wave of this workgroup may
+  // slot's scratch: that aliases the split-K tiles, which a faster wave of this workgroup may
   // already be writing for the next stage; slots are < 256)
   unsigned char* s_list = const_cast<unsigned char*>(pers) + L.off_flag;
   int n = 0, before = 0;
@@ -723,21 +764,17 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
   mid();  // (the caller's early load: queued ahead of the means)
   if (n == 0) return;
   rs_lds_fence();
+  constexpr int NV = 4 * ((DP + 255) / 256);
   const __amdgpu_buffer_rsrc_t rs_mean =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   const int grp = lane >> 4, p = lane & 15;
-  const float* xrow = st.x + (size_t)frame_next * DP;
-  f32x4 xv[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int d = 4 * (p + 16 * k);
-    xv[k] = d < DP ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
+  f32x4 xv[NV];
+  rs_load_frame16<DP>(st.x + (size_t)frame_next * DP, p, xv);
   float* tab = st.mse_tab + ((size_t)((step + 1) & 1) * U + u) * S;
   for (int i0 = 0; i0 < n; i0 += 4) {
     const int i = i0 + grp;
     const int sl = (int)s_list[i < n ? i : 0];
-    f32x4 mv[4];
+    f32x4 mv[NV];
     rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
     const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
     if (p == 0 && i < n) tab[sl] = v;
@@ -746,10 +783,13 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
 
 // resident_tile_nv without the workgroup barrier that ends the pass: the caller places it (and may
 // put work that needs no other wave's partial tiles in front of it).
-template <int NG, int PER, int RC, int NV, int KBS, typename After>
+// SPLIT2 (NG == 3): the partial tiles of gates 0 and 1 first ([wave][RC][2][256]); barrier; `mid`
+// -- the caller combines those two; barrier; gate 2 into the same bytes ([wave][RC][1][256]): two
+// thirds of the LDS for two more workgroup barriers per pass.
+template <int NG, int PER, int RC, int NV, int KBS, bool SPLIT2, typename After, typename Mid>
 __device__ __forceinline__ void rs_tile_nv(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
                                            __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], float* spart,
-                                           After after_issue) {
+                                           After after_issue, Mid mid) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4;
   f32x4 bv[NG];  // oldest in the vmcnt queue: the chain's first operand
 #pragma unroll
@@ -775,20 +815,35 @@ __device__ __forceinline__ void rs_tile_nv(const f32x4 (&wr)[NG][PER], const flo
 #pragma unroll
         for (int g = 0; g < NG; ++g)
           acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[g][kb][e], b[r][kb][e], acc[r][g], 0, 0, 0);
+  if constexpr (!SPLIT2) {
 #pragma unroll
-  for (int r = 0; r < NV; ++r)
+    for (int r = 0; r < NV; ++r)
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-      *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
+      for (int g = 0; g < NG; ++g)
+        *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * NG + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
+  } else {
+    static_assert(!SPLIT2 || NG == 3, "the GRU's three gates");
+#pragma unroll
+    for (int r = 0; r < NV; ++r)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        *reinterpret_cast<f32x4*>(spart + ((size_t)((w * RC + r) * 2 + g) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][g];
+    __syncthreads();
+    mid();
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NV; ++r)
+      *reinterpret_cast<f32x4*>(spart + ((size_t)(w * RC + r) * 256) + (lane & 15) * 16 + 4 * q) = acc[r][NG - 1];
+  }
 }
-template <int NG, int PER, int RC, int KBS, typename After>
+template <int NG, int PER, int RC, int KBS, bool SPLIT2, typename After, typename Mid>
 __device__ __forceinline__ void rs_tile(const f32x4 (&wr)[NG][PER], const float* __restrict__ bias, int gate_stride,
                                         __amdgpu_buffer_rsrc_t rsrc, const uint32_t (&boff)[RC], int nvalid, float* spart,
-                                        After after_issue) {
+                                        After after_issue, Mid mid) {
   static_assert(RC == 3, "dispatch below");
-  if (nvalid >= 3) rs_tile_nv<NG, PER, RC, 3, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
-  else if (nvalid == 2) rs_tile_nv<NG, PER, RC, 2, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
-  else rs_tile_nv<NG, PER, RC, 1, KBS>(wr, bias, gate_stride, rsrc, boff, spart, after_issue);
+  if (nvalid >= 3) rs_tile_nv<NG, PER, RC, 3, KBS, SPLIT2>(wr, bias, gate_stride, rsrc, boff, spart, after_issue, mid);
+  else if (nvalid == 2) rs_tile_nv<NG, PER, RC, 2, KBS, SPLIT2>(wr, bias, gate_stride, rsrc, boff, spart, after_issue, mid);
+  else rs_tile_nv<NG, PER, RC, 1, KBS, SPLIT2>(wr, bias, gate_stride, rsrc, boff, spart, after_issue, mid);
 }
 
 // Hand-offs between dense stages without a cluster-wide barrier.  What a consumer wave reads in
@@ -899,36 +954,48 @@ __device__ __forceinline__ bool rs_xcd_wait(const DecodeState& st, int cluster, 
 
 // The one-launch decode with the replicated select (see the top of this file).  Same grid, same
 // weight residency, same dense stages and arithmetic as k_decode_resident; three in-launch
-// barriers per step instead of four, no row reservation, no descriptor staging.
-template <int HP, int DP>
+// hand-offs per step instead of four barriers, no row reservation, no descriptor staging.
+// Template parameters beyond the model's padded sizes (the shape classes):
+//   NPOS    candidate-grid positions per lane: 3 (beam_size <= 16, <= 192 candidates) or 4 (<= 32, <= 256)
+//   UPW     utterances per wave: 1 (at most 8 utterances per XCD) or 2 (16: wave w decides slots w and w + 8,
+//           one after the other)
+//   CB, CK  beam_size and max_clusters as compile-time constants (0: run-time values) -- the instantiation
+//           of a shape whose LDS layout then folds into the instruction stream
+//   SPLIT2  the GRU's split-K partial tiles in two rounds (rs_tile_nv): 24 KB of LDS for the larger tables
+template <int HP, int DP, int NPOS = 3, int UPW = 1, int CB = 0, int CK = 0, bool SPLIT2 = false>
 __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;
   constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;
   constexpr int EPT = (RC + 1) / 2;
-  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32 && PER * UIS_KSPLIT == NKB && DP <= 256, "shapes");
+  constexpr int SLOTS = UIS_RS_UTT * UPW;
+  constexpr int PSTR = rs_part_stride(DP);
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32 && PER * UIS_KSPLIT == NKB && DP <= 512, "shapes");
+  static_assert(UPW == 1 || UPW == 2, "utterances per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);  // the wave's number, known to be uniform (scalar addresses)
   const int ncl = st.ncl;
   const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
-  const int U = st.U, S = st.S, B = st.B;
-  const RsLds L = rs_lds_layout(B, st.Kmax, S);
+  const int U = st.U;
+  const RsDims dm{CB ? CB : st.B, CB ? CK : st.Kmax, CB ? CB * CK + CB : st.S};
+  const int S = dm.S, B = dm.B;
+  const RsLds L = rs_lds_layout(dm.B, dm.Kmax, dm.S);
   float* swgt = reinterpret_cast<float*>(smem_raw);
   double* s_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
   double* s_lden = s_lblk + UIS_RS_LOGTAB;
   unsigned char* s_pers = reinterpret_cast<unsigned char*>(s_lden + UIS_RS_LOGTAB);
-  float* spart = reinterpret_cast<float*>(s_pers + (size_t)UIS_RS_UTT * L.persist_stride);
+  float* spart = reinterpret_cast<float*>(s_pers + (size_t)SLOTS * L.persist_stride);
   unsigned char* s_scr = reinterpret_cast<unsigned char*>(spart);
-  const size_t spart_bytes = (size_t)UIS_KSPLIT * RC * 3 * 256 * 4 > (size_t)UIS_RS_UTT * L.scratch_stride
-                                 ? (size_t)UIS_KSPLIT * RC * 3 * 256 * 4 : (size_t)UIS_RS_UTT * L.scratch_stride;
-  int* s_ctl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(spart) + spart_bytes);  // [0] abort [1] steps [2] arrived [8..15] rows per wave
+  const size_t spart_bytes = rs_spart_bytes(SPLIT2) > (size_t)SLOTS * L.scratch_stride ? rs_spart_bytes(SPLIT2)
+                                                                                        : (size_t)SLOTS * L.scratch_stride;
+  int* s_ctl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(spart) + spart_bytes);  // [0] abort [1] steps [2] arrived [8 .. 8 + SLOTS) rows per slot
   f32x4* s_w1 = reinterpret_cast<f32x4*>(s_ctl + 32);
   f32x4* s_w2 = s_w1 + NKB * 64;
-  const int head_tiles = rs_head_tiles(B);
+  const int head_tiles = rs_head_tiles(B, UPW);
   u32x4* s_head = reinterpret_cast<u32x4*>(s_w2 + NKB * 64);
-  long* s_wframe = reinterpret_cast<long*>(s_head + head_tiles * 16);  // [8] this step's frame of every wave's utterance
-  long* s_wnext = s_wframe + UIS_RS_UTT;                               // [8] ... and the next step's
+  long* s_wframe = reinterpret_cast<long*>(s_head + head_tiles * 16);  // [SLOTS] this step's frame of every slot's utterance
+  long* s_wnext = s_wframe + SLOTS;                                    // [SLOTS] ... and the next step's
 
   uint32_t xcc = 0;
   if (t == 0) {
@@ -940,32 +1007,45 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   for (int i = t; i < DP; i += 512) swgt[i] = m.wgt[i];
   for (int i = t; i < UIS_RS_LOGTAB; i += 512) { s_lblk[i] = st.logblk[i]; s_lden[i] = st.logden[i]; }
   for (int i = t; i < head_tiles * 16; i += 512) s_head[i] = u32x4{0u, 0u, 0u, 0u};
-  if (t < UIS_RS_UTT) { s_wframe[t] = 0; s_wnext[t] = 0; }
-  // ---- this wave's utterance: slot w of the cluster
-  const int u_w = cluster + ncl * w;
-  const bool has_u = w < UIS_RS_UTT && u_w < U;
-  unsigned char* const pers_w = s_pers + (size_t)(w < UIS_RS_UTT ? w : 0) * L.persist_stride;
-  unsigned char* const scr_w = s_scr + (size_t)(w < UIS_RS_UTT ? w : 0) * L.scratch_stride;
-  long off0_w = 0, N_w = 0;
-  if (has_u) { off0_w = (long)st.off[u_w]; N_w = (long)st.off[u_w + 1] - off0_w; }
-  const long T_w = (long)st.tau * N_w;
-  // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
-  for (int i = lane; i < L.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = 0;
+  if (t < SLOTS) { s_wframe[t] = 0; s_wnext[t] = 0; }
+  // ---- this wave's utterances: slots w (and w + 8) of the cluster
+  int u_w[UPW];
+  bool has_u[UPW];
+  unsigned char* pers_w[UPW];
+  unsigned char* scr_w[UPW];
+  long off0_w[UPW], N_w[UPW], T_w[UPW], fpos_w[UPW];
+  int prev_base[UPW];  // first row of the slot's utterance in the previous step's row list
+#pragma unroll
+  for (int q = 0; q < UPW; ++q) {
+    const int slot = w + UIS_RS_UTT * q;
+    u_w[q] = cluster + ncl * slot;
+    has_u[q] = u_w[q] < U;
+    pers_w[q] = s_pers + (size_t)slot * L.persist_stride;
+    scr_w[q] = s_scr + (size_t)slot * L.scratch_stride;
+    off0_w[q] = 0; N_w[q] = 0; fpos_w[q] = 0; prev_base[q] = 0;
+    if (has_u[q]) { off0_w[q] = (long)st.off[u_w[q]]; N_w[q] = (long)st.off[u_w[q] + 1] - off0_w[q]; }
+    T_w[q] = (long)st.tau * N_w[q];
+    // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
+    for (int i = lane; i < L.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w[q])[i] = 0;
+  }
   __syncthreads();
   if (lane == 0) {
-    int* hdr = reinterpret_cast<int*>(pers_w + L.off_hdr);
-    hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
-    reinterpret_cast<int*>(pers_w + L.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+      int* hdr = reinterpret_cast<int*>(pers_w[q] + L.off_hdr);
+      hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
+      reinterpret_cast<int*>(pers_w[q] + L.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
+    }
   }
   {
     int myT = 0;
-    if (has_u && lane == 0) myT = (int)T_w;
+#pragma unroll
+    for (int q = 0; q < UPW; ++q)
+      if (has_u[q] && lane == 0 && (int)T_w[q] > myT) myT = (int)T_w[q];
     if (myT > 0) atomicMax(&s_ctl[1], myT);
   }
   __syncthreads();
   const int nsteps = s_ctl[1];
-  // the owner of utterance slot r is rank r: it alone writes that utterance's lasting outputs
-  const bool owner_wg = rank < UIS_RS_UTT && cluster + ncl * rank < U;
 
   f32x4 wg[3][PER];
   const int ft1 = rank / SH1, tpar1 = rank % SH1;
@@ -993,9 +1073,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const uint32_t live_mask = ((st.flags & 0x4000u) != 0u && cluster == 0 && rank == 5) ? 7u : 0xffffffffu;
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
-  long fpos_w = 0;  // step % N of this wave's utterance, kept incrementally
-  float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * 32;  // this cluster's rows of partial sums
-  int prev_base = 0;  // first row of this wave's utterance in the previous step's row list
+  float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * PSTR;  // this cluster's rows of partial sums
   __syncthreads();
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1004,38 +1082,61 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   unsigned long long ft_acc[4] = {0, 0, 0, 0}, rt_prev2 = rt_prev;
 #endif
 
-  RsPrep prep = rs_prep(m, st, L, 0, pers_w, scr_w, s_lblk, s_lden, []() {});  // (later steps: inside the previous step's last hand-off)
+  RsPrep<NPOS> prep[UPW];  // (later steps: prepared inside the previous step's last hand-off)
+#pragma unroll
+  for (int q = 0; q < UPW; ++q) prep[q] = rs_prep<false, NPOS>(m, st, L, dm, 0, pers_w[q], scr_w[q], s_lblk, s_lden, []() {});
   for (int s = 0; s < nsteps; ++s) {
-    // ---- select, replicated: wave w decides utterance slot w; every workgroup gets the same rows
-    RsWin win;
-    win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
-    const bool act_w = has_u && (long)s < T_w;
-    const long frame_w = off0_w + fpos_w;
-    if (act_w) {
+    // ---- select, replicated: wave w decides utterance slot w (then w + 8); every workgroup gets the same rows
+    RsWin win[UPW];
+    bool act_w[UPW];
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+      win[q].keep = 0; win[q].C = 0; win[q].nlead = 0; win[q].a = 0u; win[q].b = 0u; win[q].c = 0u; win[q].score = 0.0f;
+      act_w[q] = has_u[q] && (long)s < T_w[q];
+      const long frame_w = off0_w[q] + fpos_w[q];
+      if (act_w[q]) {
 #if defined(UIS_RESIDENT_TIMING)
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, prep, (blockIdx.x == 0 && w == 0) ? ph_acc : nullptr);
+        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], part_c + (size_t)prev_base[q] * PSTR,
+                                           prep[q], (blockIdx.x == 0 && w == 0 && q == 0) ? ph_acc : nullptr);
 #else
-      win = rs_front<DP>(m, st, L, u_w, s, frame_w, pers_w, scr_w, part_c + (size_t)prev_base * 32, prep, nullptr);
+        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], part_c + (size_t)prev_base[q] * PSTR,
+                                           prep[q], nullptr);
 #endif
+      }
+      if (lane == 0) {
+        const int slot = w + UIS_RS_UTT * q;
+        s_ctl[8 + slot] = win[q].nlead;
+        s_wframe[slot] = frame_w;
+        s_wnext[slot] = off0_w[q] + (fpos_w[q] + 1 == N_w[q] ? 0 : fpos_w[q] + 1);  // (after the last step: some frame of the utterance, unused)
+      }
     }
     RSTAMP(0);
-    if (lane == 0) {
-      s_ctl[8 + w] = win.nlead;
-      s_wframe[w] = frame_w;
-      s_wnext[w] = off0_w + (fpos_w + 1 == N_w ? 0 : fpos_w + 1);  // (after the last step: some frame of the utterance, unused)
-    }
     __syncthreads();
     if (s_ctl[0]) return;  // a hand-off of the previous step gave up (cl_abort tells the host): all waves leave here
-    int base = 0, nrows = 0;
+    int nrows = 0;
+    {
+      int base[UPW];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int c = s_ctl[8 + k]; if (k < w) base += c; nrows += c; }
-    if (win.is_lead()) {
-      // (the wave's number rides in the top bits of the frame count: the row's frame is s_wframe[that])
-      s_head[base + win.ord()] = u32x4{(unsigned)u_w, (unsigned)win.src(), (unsigned)win.dst(), (unsigned)win.nprev() | ((unsigned)w << 16)};
+      for (int q = 0; q < UPW; ++q) base[q] = 0;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        const int c = s_ctl[8 + k];
+#pragma unroll
+        for (int q = 0; q < UPW; ++q) if (k < w + UIS_RS_UTT * q) base[q] += c;
+        nrows += c;
+      }
+#pragma unroll
+      for (int q = 0; q < UPW; ++q) {
+        if (win[q].is_lead()) {
+          // (the slot's number rides in the top bits of the frame count: the row's frame is s_wframe[that])
+          s_head[base[q] + win[q].ord()] = u32x4{(unsigned)u_w[q], (unsigned)win[q].src(), (unsigned)win[q].dst(),
+                                                 (unsigned)win[q].nprev() | ((unsigned)(w + UIS_RS_UTT * q) << 16)};
+        }
+        prev_base[q] = base[q];
+      }
     }
     __syncthreads();
     const int nrt = (nrows + 15) >> 4;
-    prev_base = base;
     RSTAMP(1);
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot
@@ -1052,6 +1153,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
         const int j = ft1 * 16 + (t & 15);
         RowHead re[EPT];
         float gir[EPT], giz[EPT], gin[EPT], hprev[EPT];
+        float ghr[EPT], ghz[EPT];
         bool ework[EPT];
         auto epilogue_operands = [&]() {
 #pragma unroll
@@ -1063,26 +1165,40 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             // EVERYTHING in flight -- these gi0 rows, first touched here, come from HBM -- before
             // the stage's first MFMA; a thread without a row fetches row 0's operands instead)
             re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);
-            const long frame = s_wframe[((unsigned)re[k].nprev >> 16) & 7u];
+            const long frame = s_wframe[((unsigned)re[k].nprev >> 16) & (unsigned)(SLOTS - 1)];
             re[k].nprev &= 0xffff;
             const float* gi = st.gi0 + (size_t)frame * m.G;
             gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
             hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
           }
         };
+        auto combine_rz = [&]() {  // SPLIT2: gates r and z while gate n's partial tiles wait in registers
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) {
+            if (!ework[k]) continue;
+            const int r = (t >> 8) + 2 * k, e = t & 255;
+            ghr[k] = splitk_combine<RC, 2>(spart, r, 0, e);
+            ghz[k] = splitk_combine<RC, 2>(spart, r, 1, e);
+          }
+        };
         FSTAMP(0);
-        rs_tile<3, PER, RC, 64>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
-                                epilogue_operands);
+        rs_tile<3, PER, RC, 64, SPLIT2>(wg, m.bhh[0] + ft1 * 16, HP, rs_hid, boff, my1 - i0 < RC ? my1 - i0 : RC, spart,
+                                        epilogue_operands, combine_rz);
         __syncthreads();
         FSTAMP(1);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           if (!ework[k]) continue;
           const int r = (t >> 8) + 2 * k, e = t & 255;
-          const float ghr = splitk_combine<RC, 3>(spart, r, 0, e);
-          const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
-          const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
-          const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
+          float ghn;
+          if constexpr (SPLIT2) {
+            ghn = splitk_combine<RC, 1>(spart, r, 0, e);
+          } else {
+            ghr[k] = splitk_combine<RC, 3>(spart, r, 0, e);
+            ghz[k] = splitk_combine<RC, 3>(spart, r, 1, e);
+            ghn = splitk_combine<RC, 3>(spart, r, 2, e);
+          }
+          const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr[k], ghz[k], ghn, hprev[k]) : 0.0f;
           st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
           hst[((tile0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;
         }
@@ -1099,9 +1215,21 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 1u) & live_mask);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
-      if (act_w) rs_back(m, st, L, u_w, s, off0_w, pers_w, rank == w, win, peek);
-      else peek();
-      if (act_w) { fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1; }
+      bool peeked = false;
+#pragma unroll
+      for (int q = 0; q < UPW; ++q) {
+        if (act_w[q]) {
+          // (the owner of utterance slot r is rank r: it alone writes that utterance's lasting outputs)
+          if (q == UPW - 1 || !act_w[UPW - 1]) {
+            rs_back<NPOS>(m, st, L, dm, u_w[q], s, off0_w[q], pers_w[q], rank == w + UIS_RS_UTT * q, win[q], peek);
+            peeked = true;
+          } else {
+            rs_back<NPOS>(m, st, L, dm, u_w[q], s, off0_w[q], pers_w[q], rank == w + UIS_RS_UTT * q, win[q], []() {});
+          }
+          fpos_w[q] = fpos_w[q] + 1 == N_w[q] ? 0 : fpos_w[q] + 1;
+        }
+      }
+      if (!peeked) peek();
       if (nrt > tpar1 && !rs_flag_ready4(pk, 3u * (uint32_t)s + 1u) &&
           rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 1u))
         s_ctl[0] = 1;
@@ -1142,8 +1270,19 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 2u) & live_mask);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
-      if (has_u && (long)s + 1 < T_w) rs_early_mse<DP>(m, st, L, u_w, s, off0_w + fpos_w, pers_w, scr_w, swgt, rank, w, peek);
-      else peek();
+      bool peeked = false;
+#pragma unroll
+      for (int q = 0; q < UPW; ++q) {
+        if (has_u[q] && (long)s + 1 < T_w[q]) {
+          if (!peeked) {
+            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, off0_w[q] + fpos_w[q], pers_w[q], swgt, rank, w, peek);
+            peeked = true;
+          } else {
+            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, off0_w[q] + fpos_w[q], pers_w[q], swgt, rank, w, []() {});
+          }
+        }
+      }
+      if (!peeked) peek();
       if (nrt > tpar2 && !rs_flag_ready4(pk, 3u * (uint32_t)s + 2u) &&
           rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 2u))
         s_ctl[0] = 1;
@@ -1171,7 +1310,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
             ework[k] = r < RC && i0 + r < my_tiles && lrow < nrows;
             re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);  // (no branch around the load: see the GRU stage)
-            xn[k] = st.x[(size_t)s_wnext[((unsigned)re[k].nprev >> 16) & 7u] * DP + f];  // the NEXT frame of the row's utterance
+            xn[k] = st.x[(size_t)s_wnext[((unsigned)re[k].nprev >> 16) & (unsigned)(SLOTS - 1)] * DP + f];  // the NEXT frame of the row's utterance
             re[k].nprev &= 0xffff;
             old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + (re[k].src >= 0 ? re[k].src : 0)) * m.Dp + f);
           }
@@ -1197,8 +1336,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           q = q + dpp_perm<0x141>(q);  // row_half_mirror: the neighbouring quad's sum
           q = q + dpp_perm<0x140>(q);  // row_mirror: the other half's
           const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
-          if ((t & 15) == 0) part_c[(size_t)lrow * 32 + ft2] = q;
-          if (f == 0) { const float d0 = v - xn[k]; part_c[(size_t)lrow * 32 + 16] = d0 * d0; }
+          if ((t & 15) == 0) part_c[(size_t)lrow * PSTR + ft2] = q;
+          if (f == 0) { const float d0 = v - xn[k]; part_c[(size_t)lrow * PSTR + rs_part_first(DP)] = d0 * d0; }
         }
         __syncthreads();
       }
@@ -1210,8 +1349,19 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 3u) & live_mask);
       uint32_t pk = 0u;
       auto peek = [&]() { pk = rs_flag_peek_all(flags_c); };
-      if (has_u && (long)s + 1 < T_w) prep = rs_prep(m, st, L, s + 1, pers_w, scr_w, s_lblk, s_lden, peek);
-      else peek();
+      bool peeked = false;
+#pragma unroll
+      for (int q = 0; q < UPW; ++q) {
+        if (has_u[q] && (long)s + 1 < T_w[q]) {
+          if (!peeked) {
+            prep[q] = rs_prep<false, NPOS>(m, st, L, dm, s + 1, pers_w[q], scr_w[q], s_lblk, s_lden, peek);
+            peeked = true;
+          } else {
+            prep[q] = rs_prep<false, NPOS>(m, st, L, dm, s + 1, pers_w[q], scr_w[q], s_lblk, s_lden, []() {});
+          }
+        }
+      }
+      if (!peeked) peek();
       if (!rs_flag_ready_all(pk, 3u * (uint32_t)s + 3u) && rs_flag_wait_all(st, flags_c, 3u * (uint32_t)s + 3u)) s_ctl[0] = 1;
     }
     RSTAMP(7);
@@ -1222,7 +1372,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   if (t == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = ph_acc[k];
   if (t == 0 && blockIdx.x == 31 * ncl) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
 #endif
-  if (owner_wg && t == 0) {  // this utterance's statistics
+  if (rank < SLOTS && cluster + ncl * rank < U && t == 0) {  // this utterance's statistics, by its owner rank
     const unsigned long long* acc =
         reinterpret_cast<const unsigned long long*>(s_pers + (size_t)rank * L.persist_stride + L.off_stats);
     atomicAdd(&st.counters[0], acc[0]);
