@@ -801,10 +801,13 @@ def test_reference_probes_on_the_device():
 
 
 def _decode_and_check(dec, params, seqs, beam, cap, oracle_lib, want_kernel, flags=0):
+  """`cap` = max_clusters, or None: what the oracle's survivors needed (at least 4)."""
   ref = oracle_lib.decode(params, seqs, beam, 1, 2, n_threads=8)
   frames, offsets = oracle_lib.pack(seqs)
+  if cap is None:
+    cap = max(int(ref['max_clusters'].max()), 4)
   out = dec.decode(frames, offsets, beam, 1, 2, max_clusters=cap, flags=flags, want_beam_scores=True)
-  assert out['status'] == 0 and not out['overflow'].any()
+  assert out['status'] == 0 and not out['overflow'].any(), (out['status'], cap, int(ref['max_clusters'].max()))
   assert out['stats']['decode_kernel'] == want_kernel, out['stats']['decode_kernel']
   for u in range(len(seqs)):
     assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), u
@@ -816,12 +819,15 @@ def _decode_and_check(dec, params, seqs, beam, cap, oracle_lib, want_kernel, fla
 def test_replicated_select_shape_classes(oracle_lib):
   """Every instantiation of k_decode_rs (uis_select_rs.hip), named by the library itself
   (uis_stats.decode_kernel), against the oracle bit for bit: the base class, the class with the
-  benchmark's beam / cluster cap as compile-time constants, the wide class (beam_size up to 32,
-  observation_dim 512: BASELINE configs[4]'s shape) -- ragged batches, with and without row
-  de-duplication, and with the one-launch decode REQUIRED (no silent fallback)."""
+  benchmark's beam / cluster cap as compile-time constants, two utterances per wave (9 .. 16 per
+  XCD), the wide class (beam_size up to 32, observation_dim 512: BASELINE configs[4]'s shape) --
+  ragged batches, with and without row de-duplication, and with the one-launch decode REQUIRED (no
+  silent fallback).  The last two classes are not the default for their shapes (they measured
+  slower than the owner-select kernel): UIS_FLAG_REPLICATED_SELECT asks for them."""
   res = _capi.UIS_FLAG_RESIDENT
+  rep = res | _capi.UIS_FLAG_REPLICATED_SELECT
   rng = np.random.default_rng(5)
-  # D = 256: base (cap 12), the fixed-shape instantiation (beam 10, cap 16), wide (beam 24 / 32)
+  # D = 256: base (cap 12), the fixed-shape instantiation (beam 10, cap 16), wide (beam 17 .. 32)
   params = synth.tracker_params(256, 512, 1, seed=3)
   dec = _capi.Decoder(params)
   lens = [int(n) for n in rng.integers(1, 70, size=61)]
@@ -829,40 +835,42 @@ def test_replicated_select_shape_classes(oracle_lib):
   _decode_and_check(dec, params, seqs, 10, 12, oracle_lib, 'k_decode_rs', res)
   _decode_and_check(dec, params, seqs, 10, 16, oracle_lib, 'k_decode_rs', res)
   _decode_and_check(dec, params, seqs, 10, 16, oracle_lib, 'k_decode_rs', res | _capi.UIS_FLAG_NO_DEDUP)
-  _decode_and_check(dec, params, seqs[:23], 24, 9, oracle_lib, 'k_decode_rs<wide>', res)
-  _decode_and_check(dec, params, seqs[:9], 32, 7, oracle_lib, 'k_decode_rs<wide>', res | _capi.UIS_FLAG_NO_DEDUP)
-  _decode_and_check(dec, params, seqs[:40], 17, 8, oracle_lib, 'k_decode_rs<wide>', res)
-  # 9 .. 16 utterances per XCD: two utterances per wave (UIS_FLAG_REPLICATED_SELECT asks for it whether or
-  # not it is the default for the batch size)
+  _decode_and_check(dec, params, seqs[:23], 24, None, oracle_lib, 'k_decode_rs<wide>', rep)
+  _decode_and_check(dec, params, seqs[:9], 32, None, oracle_lib, 'k_decode_rs<wide>', rep | _capi.UIS_FLAG_NO_DEDUP)
+  _decode_and_check(dec, params, seqs[:40], 17, None, oracle_lib, 'k_decode_rs<wide>', rep)
+  # 9 .. 16 utterances per XCD: two utterances per wave
   lens2 = [int(n) for n in rng.integers(1, 40, size=117)]
   seqs2, _ = synth.make_utterances(8700, len(lens2), lens2, 256)
-  rep = _capi.UIS_FLAG_REPLICATED_SELECT
-  _decode_and_check(dec, params, seqs2, 10, 16, oracle_lib, 'k_decode_rs<2 per wave>', res | rep)
-  _decode_and_check(dec, params, seqs2[:65], 10, 16, oracle_lib, 'k_decode_rs<2 per wave>', res | rep)
-  _decode_and_check(dec, params, seqs2[:128 - 11], 8, 12, oracle_lib, 'k_decode_rs<2 per wave>', res | rep | _capi.UIS_FLAG_NO_DEDUP)
+  _decode_and_check(dec, params, seqs2, 10, 16, oracle_lib, 'k_decode_rs<2 per wave>', rep)
+  _decode_and_check(dec, params, seqs2[:65], 10, 16, oracle_lib, 'k_decode_rs<2 per wave>', rep)
+  _decode_and_check(dec, params, seqs2[:128 - 11], 8, 12, oracle_lib, 'k_decode_rs<2 per wave>', rep | _capi.UIS_FLAG_NO_DEDUP)
+  _decode_and_check(dec, params, seqs2, 10, 16, oracle_lib, 'k_decode_resident', res)   # (the default for that batch size)
   # D = 512 (configs[4]: beam 20, cap 11), and a narrow beam on the same model
-  params5 = synth.tracker_params(512, 512, 1, seed=4)
+  # (the model the reference trained for that config: its survivors stay within the cap, as in bench.py)
+  import os
+  from uisrnn_amd import weights
+  params5 = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d512.uisrnn'))
   dec5 = _capi.Decoder(params5)
-  seqs5, _ = synth.make_utterances(8300, 64, lens[:64] + [33, 20, 5], 512)
-  _decode_and_check(dec5, params5, seqs5[:64], 20, 11, oracle_lib, 'k_decode_rs<wide>', res)
-  _decode_and_check(dec5, params5, seqs5[:30], 6, 16, oracle_lib, 'k_decode_rs<wide>', res)
-  _decode_and_check(dec5, params5, seqs5[:30], 20, 11, oracle_lib, 'k_decode_rs<wide>', res | _capi.UIS_FLAG_NO_DEDUP)
-  # the owner-select kernel stays reachable (A/B switch) on every one of these shapes
-  _decode_and_check(dec5, params5, seqs5[:30], 20, 11, oracle_lib, 'k_decode_resident', res | _capi.UIS_FLAG_OWNER_SELECT)
+  seqs5, _ = synth.make_utterances(8300, 64, lens[:61] + [33, 20, 5], 512)
+  _decode_and_check(dec5, params5, seqs5[:64], 20, 11, oracle_lib, 'k_decode_rs<wide>', rep)
+  _decode_and_check(dec5, params5, seqs5[:30], 6, 16, oracle_lib, 'k_decode_rs<wide>', rep)
+  _decode_and_check(dec5, params5, seqs5[:30], 20, 11, oracle_lib, 'k_decode_rs<wide>', rep | _capi.UIS_FLAG_NO_DEDUP)
+  # the owner-select kernel is the default on these shapes
+  _decode_and_check(dec5, params5, seqs5[:30], 20, 11, oracle_lib, 'k_decode_resident', res)
 
 
 def test_candidate_arrays_on_the_wide_select(oracle_lib):
   """UIS_FLAG_DEBUG_SCORES through the wide class of the single-wave select (four grid positions per
   lane): every candidate score of every step equals the oracle's, bit for bit."""
-  rng = np.random.default_rng(12)
-  params = synth.tracker_params(512, 512, 1, seed=4)
+  import os
+  from uisrnn_amd import weights
+  params = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d512.uisrnn'))
   seq = synth.make_utterances(8400, 1, 14, 512)[0][0]
   beam, kmax, tau = 20, 11, 2
   ora = oracle_lib.candidate_scores(params, seq, beam, 1, tau, kmax + 1)
   dec = _capi.Decoder(params)
   frames, offsets = oracle_lib.pack([seq])
-  out = dec.decode(frames, offsets, beam, 1, tau, max_clusters=kmax, flags=_capi.UIS_FLAG_DEBUG_SCORES | _capi.UIS_FLAG_RESIDENT)
+  out = dec.decode(frames, offsets, beam, 1, tau, max_clusters=kmax, flags=_capi.UIS_FLAG_DEBUG_SCORES | _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_REPLICATED_SELECT)
   assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_rs<wide>'
   got = dec.debug_scores(tau * seq.shape[0], 1, beam, kmax)[:, 0]
   assert np.array_equal(_bits(got), _bits(ora))
-  del rng

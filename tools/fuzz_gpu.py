@@ -28,8 +28,8 @@ def draw(rng):
     hid = int(rng.choice([250, 256, 500, 512]))
     depth = 1
     look = 1
-    beam = int(rng.integers(1, 21))
-    n_utt = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 64, 70]))
+    beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select
+    n_utt = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 64, 70, 100, 128]))
     max_len = 0  # set below from the oracle's budget
   else:
     dim = int(rng.integers(1, 80))
@@ -69,6 +69,8 @@ def main():
     dec = _capi.Decoder(params)
     tag = (dim, hid, depth, beam, look, tau, lengths, seed)
     flag_sets = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_OWNER_SELECT,
+                 _capi.UIS_FLAG_REPLICATED_SELECT,  # every class of k_decode_rs, also where it is not the default
+
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]
     for fl in flag_sets:

@@ -720,7 +720,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
              ((UIS_RS_UPW2_DEFAULT && !getenv("UIS_RS_NO_UPW2")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
              resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 2, true) <= 160 * 1024)
       rs_kind = (B == 10 && Kmax == 16 && getenv("UIS_RS_UPW2_C1")) ? RS_UPW2_C1 : RS_UPW2;
-    else if (per_xcd <= UIS_RS_UTT && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) && !getenv("UIS_RS_NO_WIDE") &&
+    else if (per_xcd <= UIS_RS_UTT && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) &&
+             ((UIS_RS_WIDE_DEFAULT && !getenv("UIS_RS_NO_WIDE")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
              rs_select_ok(B, Kmax, S, (long)maxT, 4) && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 1, true) <= 160 * 1024)
       rs_kind = (m.Dp == 512 && B == 20 && Kmax == 11 && getenv("UIS_RS_WIDE_C4")) ? RS_WIDE_C4 : RS_WIDE;
   }
@@ -1061,9 +1062,22 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
 
     const double launches = (double)maxT * U;
-    fprintf(stderr, "[select timing] cycles per workgroup-launch:");
-    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, (double)tc[16 + k] / launches);
-    fprintf(stderr, "\n");
+    if (L == 1) {
+      fprintf(stderr, "[select timing] cycles per workgroup-launch:");
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, (double)tc[16 + k] / launches);
+      fprintf(stderr, "\n");
+    } else {
+      static const char* names[7] = {"live+offsets", "mse", "scores", "expand/prune", "leaders+slots", "tables", "records+rows"};
+      for (int half = 0; half < 2; ++half) {
+        const unsigned long long* c = tc + (half ? 32 : 16);
+        const double n = (double)std::max<unsigned long long>(c[7], 1);
+        fprintf(stderr, "[window timing] %s sub-steps, us per workgroup-launch:", half ? "pruning" : "expanding");
+        double sum = 0.0;
+        for (int k = 0; k < 7; ++k) { fprintf(stderr, " %s=%.2f", names[k], (double)c[k] * 0.01 / n); sum += (double)c[k] * 0.01 / n; }
+        fprintf(stderr, " | total=%.2f; per launch: candidates=%.0f live=%.0f hypotheses in=%.0f rows=%.1f\n", sum, (double)c[8] / n,
+                (double)c[9] / n, (double)c[10] / n, (double)c[11] / n);
+      }
+    }
   }
 #endif
 #if defined(UIS_RESIDENT_PROBE)

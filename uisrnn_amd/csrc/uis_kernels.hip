@@ -3249,6 +3249,15 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
   return total;
 }
 
+// Diagnostic build (-DUIS_SELECT_TIMING): thread 0 of every workgroup adds the wall-clock ticks (10 ns)
+// of each phase to counters[16 + phase] (expanding sub-steps) / counters[32 + phase] (the pruning one)
+#if defined(UIS_SELECT_TIMING)
+#define WSTAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_now_ = wall_clock64(); \
+    atomicAdd(&st.counters[(last ? 32 : 16) + (k)], t_now_ - w_prev_); w_prev_ = t_now_; } } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#endif
+
 // NT threads per utterance: 256 for narrow beams, more when a level holds hundreds of hypotheses
 // (every phase is a scan or a count over the level's candidates)
 template <int NT>
@@ -3277,6 +3286,9 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   const HypView in = j == 0 ? beam_view(st, u, wpar) : level_view(st, u, (j - 1) & 1);
   const HypView out = last ? beam_view(st, u, wpar ^ 1) : level_view(st, u, j & 1);
   const int n_in = *in.n;
+#if defined(UIS_SELECT_TIMING)
+  unsigned long long w_prev_ = wall_clock64();
+#endif
 
   unsigned char* scr = st.scratch + (size_t)u * st.scratch_stride;
   const WindowScratch W = window_scratch_layout(S, NC, Kmax, B);
@@ -3311,6 +3323,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     if (live[sl]) livelist[atomicAdd(&lds_misc[0], 1)] = sl;
   __syncthreads();
   const int nlive = lds_misc[0];
+  WSTAMP(0);
 
   // ---- weighted MSE of the frame against every live cluster state (as k_select, phase A)
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
@@ -3382,6 +3395,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     }
   }
   __syncthreads();
+  WSTAMP(1);
 
   // ---- candidate scores
   const float mse_new = st.mse0[frame];
@@ -3420,6 +3434,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     }
   }
   __syncthreads();
+  WSTAMP(2);
 
   // ---- which candidates go on: all finite ones in order (expand) or the B best (prune)
   int keep;
@@ -3500,6 +3515,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     }
   }
   __syncthreads();
+  WSTAMP(3);
 
   // ---- source cluster state per survivor; one rnn row per distinct source (index S = fresh cluster)
   const bool nodedup = (st.flags & 1u) != 0;
@@ -3522,6 +3538,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   __syncthreads();
   for (int r = tid; r < keep; r += NT) if (leadv[r] != r) dstv[r] = dstv[leadv[r]];
   __syncthreads();
+  WSTAMP(4);
 
   // ---- write the next level / the next beam
   for (long e = tid; e < (long)keep * Kmax; e += NT) {
@@ -3540,6 +3557,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
       out.blk[(size_t)r * Kmax + c2] = blk;
     }
   }
+  WSTAMP(5);
   uint16_t* bp = st.bp16 + ((size_t)st.bp_base[u] + (size_t)win * B) * (L + 1);
   for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
@@ -3575,7 +3593,15 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
       st.rows[pos] = rr;
     }
   }
+  WSTAMP(6);
   if (tid == 0) {
+#if defined(UIS_SELECT_TIMING)
+    atomicAdd(&st.counters[(last ? 32 : 16) + 7], 1ull);                              // launches
+    atomicAdd(&st.counters[(last ? 32 : 16) + 8], (unsigned long long)C);             // candidates
+    atomicAdd(&st.counters[(last ? 32 : 16) + 9], (unsigned long long)nlive);         // live states
+    atomicAdd(&st.counters[(last ? 32 : 16) + 10], (unsigned long long)n_in);         // input hypotheses
+    atomicAdd(&st.counters[(last ? 32 : 16) + 11], (unsigned long long)nlead);        // rnn rows
+#endif
     *out.n = keep;
     st.utt_step[u] = step + 1;
     atomicAdd(&st.counters[0], (unsigned long long)nlead);

@@ -43,7 +43,11 @@
 // 1: two utterances per wave (9 .. 16 utterances per XCD) is the default where it applies; 0: only with
 // UIS_FLAG_REPLICATED_SELECT (k_decode_resident keeps those batches)
 #ifndef UIS_RS_UPW2_DEFAULT
-#define UIS_RS_UPW2_DEFAULT 1
+#define UIS_RS_UPW2_DEFAULT 0   // measured (profiles/r04_rs_shape_classes.txt): 1.20 / 1.40 / 1.60 M frames/s at 65 / 96 / 128 utterances against 1.37 / 1.67 / 1.94 M
+#endif
+// ... and the same switch for the wide class (beam_size 17 .. 32, observation dim 512)
+#ifndef UIS_RS_WIDE_DEFAULT
+#define UIS_RS_WIDE_DEFAULT 0   // measured: configs[4] 0.80 M against k_decode_resident's 0.84 M
 #endif
 #define UIS_RS_UTT 8        // waves per workgroup = utterance slots per cluster and UPW (utterances per wave)
 #define UIS_RS_MAXS 256     // slots per utterance (four 64-bit masks)
