@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +95,9 @@ struct Scratch {
 #define UIS_STREAM_RESIDENT_MIN_STEPS 4  // uis_stream_push: steps per push from which the one-launch kernel is used
 #ifndef UIS_H2D_CHUNKS
 #define UIS_H2D_CHUNKS 2     // uis_decode: host frames are copied in this many pieces, overlapped with the input projection (1 / 2 / 3 / 4 pieces measured: 1.505 / 1.517 / 1.424 / 1.43 M frames/s from pinned buffers at configs[1])
+#endif
+#ifndef UIS_F64_PIECES
+#define UIS_F64_PIECES 4     // uis_decode_f64: copies per projection chunk (the cast runs ahead of them)
 #endif
 #ifndef UIS_H2D_MIN_FRAMES
 #define UIS_H2D_MIN_FRAMES 4096  // ... of at least this many frames each
@@ -187,6 +192,7 @@ struct uis_handle {
   const double* const* src64 = nullptr;
   float* h_cast = nullptr;
   size_t h_cast_cap = 0;
+  void* cast_pool = nullptr;  // CastPool: the threads that cast (created by the first uis_decode_f64)
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -504,19 +510,14 @@ struct CastTeam {
   int64_t nblocks = 0;
   std::atomic<int64_t> next{0};
   std::vector<std::atomic<unsigned char>> done;
-  std::vector<std::thread> pool;
   CastTeam(const double* const* utt_, const int64_t* offsets_, int n_utt_, int D_, int64_t F_, float* dst_)
       : utt(utt_), offsets(offsets_), n_utt(n_utt_), D(D_), F(F_), dst(dst_), nblocks((F_ + kBlockRows - 1) / kBlockRows),
         done((size_t)((F_ + kBlockRows - 1) / kBlockRows)) {
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
-    unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
-    nt = (unsigned)std::min<int64_t>(nt, std::max<int64_t>(1, F * D / (1 << 17)));  // >= 1 MB of input per thread
-    try {
-      pool.reserve(nt);
-      for (unsigned k = 1; k < nt; ++k) pool.emplace_back([this]() { while (take()) {} });
-    } catch (...) {  // no more threads to be had: the caller's thread does what is left (wait_rows)
-    }
+  }
+  // how many threads are worth waking: >= 1 MB of input each
+  unsigned want_threads(unsigned have) const {
+    return (unsigned)std::min<int64_t>(have, std::max<int64_t>(1, F * D / (1 << 17)));
   }
   bool take() {  // one block, if there is one left
     const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
@@ -543,8 +544,66 @@ struct CastTeam {
       while (!done[(size_t)b].load(std::memory_order_acquire))
         if (!take()) std::this_thread::yield();
   }
-  ~CastTeam() {
-    for (auto& th : pool) th.join();
+};
+
+// The threads that cast: created once per handle (a decode used to spawn and join up to sixteen
+// std::threads of its own -- a third of a millisecond before the first block was cast), asleep on a
+// condition variable between decodes.  They follow the affinity mask of the thread that created the
+// pool (bench.py pins a rank to its share of the cores first).
+struct CastPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_idle;
+  CastTeam* job = nullptr;
+  uint64_t generation = 0;
+  unsigned wanted = 0, busy = 0;
+  bool quit = false;
+  void ensure_started() {
+    if (!threads.empty() || quit) return;
+    unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    try {
+      for (unsigned k = 1; k < nt; ++k) threads.emplace_back([this, k]() { worker(k); });
+    } catch (...) {  // no more threads to be had: the caller's thread does what is left (CastTeam::wait_rows)
+    }
+  }
+  void worker(unsigned index) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&]() { return quit || generation != seen; });
+      if (quit) return;
+      seen = generation;
+      CastTeam* j = job;
+      if (!j || index > wanted) continue;
+      ++busy;
+      lk.unlock();
+      while (j->take()) {}
+      lk.lock();
+      if (--busy == 0) cv_idle.notify_all();
+    }
+  }
+  void post(CastTeam* j) {
+    ensure_started();
+    std::lock_guard<std::mutex> lk(mu);
+    job = j;
+    wanted = j->want_threads((unsigned)threads.size() + 1) - 1;  // (the caller's thread is one of the team)
+    ++generation;
+    cv_work.notify_all();
+  }
+  void finish() {  // the job is about to go out of scope: nobody may still be inside it
+    std::unique_lock<std::mutex> lk(mu);
+    job = nullptr;
+    cv_idle.wait(lk, [&]() { return busy == 0; });
+  }
+  ~CastPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      job = nullptr;
+    }
+    cv_work.notify_all();
+    for (auto& th : threads) th.join();
   }
 };
 
@@ -715,15 +774,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     const int per_xcd = (U + ncl - 1) / ncl;
     const bool base_shape = m.Dp <= 256 && rs_select_ok(B, Kmax, S, (long)maxT, 3);
     if (base_shape && per_xcd <= UIS_RS_UTT && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024)
-      rs_kind = (m.Hp == 512 && m.Dp == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1")) ? RS_C1 : RS_BASE;
+      rs_kind = (m.Hp == 512 && m.Dp == 256 && m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1")) ? RS_C1 : RS_BASE;
     else if (base_shape && per_xcd <= 2 * UIS_RS_UTT && m.Hp == 512 && m.Dp == 256 &&
              ((UIS_RS_UPW2_DEFAULT && !getenv("UIS_RS_NO_UPW2")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
              resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 2, true) <= 160 * 1024)
-      rs_kind = (B == 10 && Kmax == 16 && getenv("UIS_RS_UPW2_C1")) ? RS_UPW2_C1 : RS_UPW2;
+      rs_kind = (m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && getenv("UIS_RS_UPW2_C1")) ? RS_UPW2_C1 : RS_UPW2;
     else if (per_xcd <= UIS_RS_UTT && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) &&
              ((UIS_RS_WIDE_DEFAULT && !getenv("UIS_RS_NO_WIDE")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
              rs_select_ok(B, Kmax, S, (long)maxT, 4) && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 1, true) <= 160 * 1024)
-      rs_kind = (m.Dp == 512 && B == 20 && Kmax == 11 && getenv("UIS_RS_WIDE_C4")) ? RS_WIDE_C4 : RS_WIDE;
+      rs_kind = (m.Dp == 512 && m.D == 512 && m.H == 512 && B == 20 && Kmax == 11 && getenv("UIS_RS_WIDE_C4")) ? RS_WIDE_C4 : RS_WIDE;
   }
   const bool rs = rs_kind != RS_NONE;
   const size_t mse_tab_bytes = ((size_t)2 * U * S * 4 + 255) & ~(size_t)255;
@@ -852,13 +911,29 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       h->h2d_done.push_back(e);
     }
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
-    std::unique_ptr<CastTeam> team;  // (float64 utterances: cast into the pinned staging buffer, piece c+1 while piece c copies / projects)
-    if (h->src64) team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast));
+    // float64 utterances: cast into the pinned staging buffer by the handle's pool (and this thread),
+    // piece p + 1 while piece p copies / projects.  A projection chunk then travels in several pieces,
+    // so that the first copy starts after an eighth of the cast, not half of it.
+    std::unique_ptr<CastTeam> team;
+    struct TeamGuard {  // nobody may still be inside the team when it goes out of scope
+      CastPool* pool = nullptr;
+      ~TeamGuard() { if (pool) pool->finish(); }
+    } team_guard;
+    if (h->src64) {
+      if (!h->cast_pool) h->cast_pool = new CastPool();
+      team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast));
+      team_guard.pool = static_cast<CastPool*>(h->cast_pool);
+      team_guard.pool->post(team.get());
+    }
+    const int pieces = team ? (int)std::max<int64_t>(1, std::min<int64_t>(UIS_F64_PIECES, (F / n_chunks) / 1024)) : 1;
     for (int c = 0; c < n_chunks; ++c) {
       const int64_t f0 = F * c / n_chunks, f1 = F * (c + 1) / n_chunks;
-      if (team) team->wait_rows(f1);
-      HIPCHK(hipMemcpyAsync(const_cast<float*>(d_frames) + (size_t)f0 * m.D, h_frames + (size_t)f0 * m.D,
-                            (size_t)(f1 - f0) * m.D * 4, hipMemcpyHostToDevice, h->copy_stream));
+      for (int pc = 0; pc < pieces; ++pc) {
+        const int64_t g0 = f0 + (f1 - f0) * pc / pieces, g1 = f0 + (f1 - f0) * (pc + 1) / pieces;
+        if (team) team->wait_rows(g1);
+        HIPCHK(hipMemcpyAsync(const_cast<float*>(d_frames) + (size_t)g0 * m.D, h_frames + (size_t)g0 * m.D,
+                              (size_t)(g1 - g0) * m.D * 4, hipMemcpyHostToDevice, h->copy_stream));
+      }
       HIPCHK(hipEventRecord(h->h2d_done[c], h->copy_stream));
       HIPCHK(hipStreamWaitEvent(h->stream, h->h2d_done[c], 0));
       if ((rc = pre_chunk(f0, f1))) return rc;
@@ -1228,6 +1303,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   for (hipEvent_t e : h->gdone) (void)hipEventDestroy(e);
   for (hipStream_t sg : h->gstreams) { (void)hipStreamSynchronize(sg); (void)hipStreamDestroy(sg); }
   for (hipEvent_t e : h->h2d_done) (void)hipEventDestroy(e);
+  if (h->cast_pool) { delete static_cast<CastPool*>(h->cast_pool); h->cast_pool = nullptr; }
   if (h->h_cast) (void)hipHostFree(h->h_cast);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1270,6 +1346,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   m.lp_stay = std::log(1.0 - d->transition_bias);  // np.log(1 - transition_bias), uisrnn.py:416
   m.lp_sw = std::log(d->transition_bias);
   m.l_alpha = std::log(d->crp_alpha);
+  m.lp_new = m.lp_sw + m.l_alpha;
   int rc;
   for (int l = 0; l < depth; ++l) {
     const int K = l == 0 ? D : H, Kp = l == 0 ? m.Dp : m.Hp;

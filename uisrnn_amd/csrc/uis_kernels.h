@@ -54,6 +54,7 @@ struct DevModel {
   const float* m0;     // [Dp]  mean of a fresh cluster before its first frame
   const float* h1;     // [depth][Hp] hidden of a fresh cluster before its first frame
   double lp_stay, lp_sw, l_alpha;
+  double lp_new;  // lp_sw + l_alpha, added once on the host (the same IEEE sum the kernels formed per candidate)
 };
 
 // Persistent streaming launch (UIS_FLAG_PERSISTENT sessions): k_decode_resident stays on the device

@@ -2987,9 +2987,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       RsWin win;
       win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
       if (act_w) {
-        const RsDims dm{st.B, st.Kmax, S};
+        const RsDims dm{st.B, st.Kmax, S, m.D};
         const RsPrep<3> prep = rs_prep<true, 3>(m, st, RL, dm, s, pers_w, scr_w, ws_lblk, ws_lden, []() {});
-        win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s, frame_w, pers_w, scr_w, nullptr, prep, nullptr, ws_swgt);
+        win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s, frame_w, pers_w, scr_w, rs_mean /* unused: FULL */, 0u, prep, nullptr, ws_swgt);
         int row_base = 0;
         if (lane == 0 && win.nlead > 0) row_base = atomicAdd(sink.count, win.nlead);
         row_base = __shfl(row_base, 0, 64);
@@ -3001,7 +3001,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       RSTAMP(0);
       xcd_arrive(st, cluster, s_ctl);
       if (act_w) {
-        rs_back<3>(m, st, RL, RsDims{st.B, st.Kmax, S}, u_w, s, off0_w, pers_w, true, win, []() {});
+        rs_back<3>(m, st, RL, RsDims{st.B, st.Kmax, S, m.D}, u_w, s, off0_w, pers_w, true, win, []() {});
         fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
       }
       if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
@@ -3217,9 +3217,11 @@ __host__ __device__ inline WindowScratch window_scratch_layout(int S, int NC, in
   w.total = o;
   return w;
 }
-// dynamic LDS to launch k_window with: the hot block if it fits next to the static LDS, else 0
+// dynamic LDS to launch k_window with: everything if it fits next to the static LDS (round 4: the
+// survivors' work arrays too -- every phase that went through them paid a global round trip), else
+// the hot block, else 0
 __host__ __device__ inline size_t window_lds_bytes(const WindowScratch& w) {
-  return w.hot_total <= 150 * 1024 ? w.hot_total : 0;
+  return w.total <= 150 * 1024 ? w.total : (w.hot_total <= 150 * 1024 ? w.hot_total : 0);
 }
 
 // Exclusive prefix sums over i in [0, n) of val(i) by NT threads (contiguous chunk each);
@@ -3249,6 +3251,7 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
   return total;
 }
 
+#define UIS_WINDOW_LOGTAB 128
 // Diagnostic build (-DUIS_SELECT_TIMING): thread 0 of every workgroup adds the wall-clock ticks (10 ns)
 // of each phase to counters[16 + phase] (expanding sub-steps) / counters[32 + phase] (the pruning one)
 #if defined(UIS_SELECT_TIMING)
@@ -3264,7 +3267,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int par) {
   constexpr int NW = NT / 64;
   __shared__ int lds4[2 * NW];  // (NW for the scans, 2 NW for the two-word reductions of the prune)
-  __shared__ int lds_misc[8];  // [0] nlive [1] nfinite
+  __shared__ int lds_misc[8];  // [0] nlive [1] nfinite [2..4] the prune's digit search
+  __shared__ int radix_hist[256];
+  __shared__ double s_logblk[UIS_WINDOW_LOGTAB];  // log(block count) for the small counts (larger ones: the global table)
   const int u = blockIdx.x, tid = threadIdx.x;
   const int B = st.B, Kmax = st.Kmax, S = st.S, L = st.L, NC = st.NC;
   const int step = st.utt_step[u];
@@ -3294,6 +3299,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   const WindowScratch W = window_scratch_layout(S, NC, Kmax, B);
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
   unsigned char* hot = window_lds_bytes(W) ? wlds : scr;  // same choice as the host's launch
+  unsigned char* warm = window_lds_bytes(W) == W.total ? wlds : scr;
   int* live = reinterpret_cast<int*>(hot + W.live);
   int* livelist = reinterpret_cast<int*>(hot + W.livelist);
   float* mse = reinterpret_cast<float*>(hot + W.mse);
@@ -3301,16 +3307,17 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   int* first = reinterpret_cast<int*>(hot + W.first);
   int* cbase = reinterpret_cast<int*>(hot + W.cbase);
   unsigned long long* key = reinterpret_cast<unsigned long long*>(hot + W.key);
-  float* cscore = reinterpret_cast<float*>(scr + W.cscore);
-  int* winv = reinterpret_cast<int*>(scr + W.win);
-  int* srcv = reinterpret_cast<int*>(scr + W.src);
-  int* dstv = reinterpret_cast<int*>(scr + W.dst);
-  int* leadv = reinterpret_cast<int*>(scr + W.lead);
-  int* ordv = reinterpret_cast<int*>(scr + W.ord);
-  int* freelist = reinterpret_cast<int*>(scr + W.freelist);
+  float* cscore = reinterpret_cast<float*>(warm + W.cscore);
+  int* winv = reinterpret_cast<int*>(warm + W.win);
+  int* srcv = reinterpret_cast<int*>(warm + W.src);
+  int* dstv = reinterpret_cast<int*>(warm + W.dst);
+  int* leadv = reinterpret_cast<int*>(warm + W.lead);
+  int* ordv = reinterpret_cast<int*>(warm + W.ord);
+  int* freelist = reinterpret_cast<int*>(warm + W.freelist);
 
   // ---- live cluster states of the input level, candidate offsets
   for (int sl = tid; sl <= S; sl += NT) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
+  if (tid < UIS_WINDOW_LOGTAB) s_logblk[tid] = st.logblk[tid];  // (the host fills at least UIS_RS_LOGTAB entries)
   if (tid < 8) lds_misc[tid] = 0;
   __syncthreads();
   for (int e = tid; e < n_in * Kmax; e += NT) {
@@ -3319,8 +3326,15 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   }
   const int C = block_scan<NT>(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
   if (tid == 0) cbase[n_in] = C;
-  for (int sl = tid; sl < S; sl += NT)
-    if (live[sl]) livelist[atomicAdd(&lds_misc[0], 1)] = sl;
+  for (int s0 = 0; s0 < S; s0 += NT) {  // (one reservation per wave, not per live slot: the list's order is free)
+    const int sl = s0 + tid;
+    const bool on = sl < S && live[sl] != 0;
+    const unsigned long long m = __ballot(on);
+    int base = 0;
+    if ((tid & 63) == 0 && m) base = atomicAdd(&lds_misc[0], __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (on) livelist[base + wave_below(m)] = sl;
+  }
   __syncthreads();
   const int nlive = lds_misc[0];
   WSTAMP(0);
@@ -3404,34 +3418,49 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cbase[mid] <= i) lo = mid; else hi = mid; }
     return lo;
   };
-  for (int i = tid; i < C; i += NT) {
-    const int b = node_of(i);
-    const int c = i - cbase[b];
-    const int Kb = in.K[b];
-    float ms; double prior;
-    if (c < Kb) {
-      ms = mse[in.slot[(size_t)b * Kmax + c]];
-      prior = (c == in.last[b]) ? m.lp_stay
-                                : (m.lp_sw + st.logblk[in.blk[(size_t)b * Kmax + c]]) - st.logden[in.sum[b]];
-    } else {
-      ms = mse_new;
-      prior = (m.lp_sw + m.l_alpha) - st.logden[in.sum[b]];
+  // a thread per input hypothesis (its table row fetched once), its K_b + 1 candidates in turn --
+  // not a thread per candidate, each finding its hypothesis by bisection and re-reading the row
+  for (int b = tid; b < n_in; b += NT) {
+    const int Kb = in.K[b], lastb = in.last[b], i0 = cbase[b];
+    const float base_score = in.score[b];
+    const double ld = st.logden[in.sum[b]];
+    const int origin = (st.dbg_scores && last) ? (in.origin ? in.origin[b] : b) : 0;
+    auto emit = [&](int c, float ms, double prior) {
+      const float sc = base_score + uis_step_loss(ms, prior);
+      const int i = i0 + c;
+      cscore[i] = sc;
+      const bool fin = uis_isfinite(sc);
+      key[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
+      if (st.dbg_scores && last) {
+        // UIS_FLAG_DEBUG_SCORES: the window's _calculate_score array (uisrnn.py:455-477) -- the score
+        // of the whole assignment tuple (c_1 .. c_Lw) of beam hypothesis `origin`, at
+        // [window][utterance][origin][c_1] .. [c_L] (a ragged last window: index 0 in the missing
+        // dimensions, as numpy lays a lower-dimensional array into predict_single's score_set)
+        size_t idx = ((size_t)win * st.U + u) * B + origin;
+        for (int k = 0; k < L; ++k)
+          idx = idx * (size_t)(Kmax + 1) + (size_t)(k < j ? (int)in.path[(size_t)b * L + k] : (k == j ? c : 0));
+        st.dbg_scores[idx] = sc;
+      }
+    };
+    // the row's clusters four at a time: slots and block counts requested together, then their logs
+    for (int c0 = 0; c0 < Kb; c0 += 4) {
+      int sl[4], bk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e < Kb ? c0 + e : c0;
+        sl[e] = in.slot[(size_t)b * Kmax + c];
+        bk[e] = in.blk[(size_t)b * Kmax + c];
+      }
+      double lb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lb[e] = bk[e] < UIS_WINDOW_LOGTAB ? s_logblk[bk[e]] : st.logblk[bk[e]];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        if (c < Kb) emit(c, mse[sl[e]], (c == lastb) ? m.lp_stay : (m.lp_sw + lb[e]) - ld);
+      }
     }
-    const float sc = in.score[b] + uis_step_loss(ms, prior);
-    cscore[i] = sc;
-    const bool fin = uis_isfinite(sc);
-    key[i] = fin ? (((unsigned long long)uis_score_key(sc) << 32) | (unsigned)i) : ~0ull;
-    if (st.dbg_scores && last) {
-      // UIS_FLAG_DEBUG_SCORES: the window's _calculate_score array (uisrnn.py:455-477) -- the score
-      // of the whole assignment tuple (c_1 .. c_Lw) of beam hypothesis `origin`, at
-      // [window][utterance][origin][c_1] .. [c_L] (a ragged last window: index 0 in the missing
-      // dimensions, as numpy lays a lower-dimensional array into predict_single's score_set)
-      const int origin = in.origin ? in.origin[b] : b;
-      size_t idx = ((size_t)win * st.U + u) * B + origin;
-      for (int k = 0; k < L; ++k)
-        idx = idx * (size_t)(Kmax + 1) + (size_t)(k < j ? (int)in.path[(size_t)b * L + k] : (k == j ? c : 0));
-      st.dbg_scores[idx] = sc;
-    }
+    emit(Kb, mse_new, (m.lp_sw + m.l_alpha) - ld);
   }
   __syncthreads();
   WSTAMP(2);
@@ -3486,12 +3515,50 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
       const int top = diff ? 31 - __builtin_clz(diff) : -1;      // the highest of them
       unsigned khi = top >= 31 ? 0u : (hi_and & ~((2u << top) - 1u));  // the common prefix above it
       if (top < 0) khi = hi_and;
-      for (int bit = top; bit >= 0; --bit) {
-        const unsigned t2 = khi | (1u << bit);
-        if (count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) < t2; }) <= keep - 1) khi = t2;
+      // The undecided bits top .. 0 eight at a time (round 4; one workgroup-wide count PER BIT before:
+      // ~22 counts of two barriers each were the largest phase of the pruning sub-step): a histogram of
+      // the next digit over the keys that still match the prefix, then the digit in which the
+      // keep-th smallest key lies.  n_lt = keys below the prefix so far.
+      int n_lt = 0, n_eq = nfin;
+      for (int bit = top; bit >= 0;) {
+        const int nbits = bit + 1 < 8 ? bit + 1 : 8, sh = bit + 1 - nbits, nbin = 1 << nbits;
+        for (int i = tid; i < nbin; i += NT) radix_hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < C; i += NT) {
+          const unsigned long long k = key[i];
+          const unsigned hi = (unsigned)(k >> 32);
+          // (bits above `bit` of every finite key that is still in play equal khi's)
+          if (k != ~0ull && (bit == 31 || (hi >> (bit + 1)) == (khi >> (bit + 1)))) atomicAdd(&radix_hist[(hi >> sh) & (unsigned)(nbin - 1)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {  // wave 0: lane l owns bins 4 l .. 4 l + 3
+          int c4[4], mine = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { c4[e] = 4 * tid + e < nbin ? radix_hist[4 * tid + e] : 0; mine += c4[e]; }
+          int incl = mine;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const int t2 = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += t2;
+          }
+          const unsigned long long reach = __ballot(n_lt + incl >= keep);   // (the last lane always does: keep <= the keys in play)
+          const int l = __ffsll((long long)reach) - 1;
+          if (tid == l) {
+            int below = incl - mine, d = 0, here = c4[0];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (d == e && n_lt + below + c4[e] < keep) { below += c4[e]; d = e + 1; here = c4[e + 1]; }
+            lds_misc[2] = 4 * tid + d;   // the digit
+            lds_misc[3] = below;         // keys in play with a smaller digit
+            lds_misc[4] = here;          // keys in play with this digit
+          }
+        }
+        __syncthreads();
+        khi |= (unsigned)lds_misc[2] << sh;
+        n_lt += lds_misc[3];
+        n_eq = lds_misc[4];
+        bit = sh - 1;
       }
-      const int n_lt = count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) < khi; });
-      const int n_eq = count_wg([&](unsigned long long k) { return (unsigned)(k >> 32) == khi; });
       const int need = keep - n_lt;                               // how many of the threshold score go on (>= 1)
       unsigned klo = 0xffffffffu;
       if (n_eq != need) {                                         // a tie at the threshold: lowest candidate indices first
@@ -3519,10 +3586,14 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
 
   // ---- source cluster state per survivor; one rnn row per distinct source (index S = fresh cluster)
   const bool nodedup = (st.flags & 1u) != 0;
+  // (survivor r = hypothesis b, cluster c of the input level: found once by bisection and kept in the
+  // live list's LDS -- free since the MSE pass -- for the table and record loops below)
+  int* wbc = livelist;
   for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
     const int b = node_of(i);
     const int c = i - cbase[b];
+    wbc[r] = b | (c << 16);
     const int src = c < in.K[b] ? in.slot[(size_t)b * Kmax + c] : S;
     srcv[r] = src;
     if (!nodedup) atomicMin(&first[src], r);
@@ -3532,6 +3603,9 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   __syncthreads();
   const int nlead = block_scan<NT>(keep, [&](int r) { return leadv[r] == r ? 1 : 0; },
                                [&](int r, int pre) { ordv[r] = pre; }, lds4);
+  // this utterance's rows of the step's row list: ONE reservation (an atomic per row before; the order
+  // of the utterances' blocks in the list is whatever the reservations make it: nothing depends on it)
+  if (tid == 0) { lds_misc[5] = nlead > 0 ? atomicAdd(&st.nrows[par], nlead) : 0; lds_misc[6] = 0; }
   block_scan<NT>(S, [&](int sl) { return live[sl] ? 0 : 1; },
              [&](int sl, int pre) { if (!live[sl] && pre < nlead) freelist[pre] = sl; }, lds4);
   for (int r = tid; r < keep; r += NT) if (leadv[r] == r) dstv[r] = freelist[ordv[r]];
@@ -3543,9 +3617,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   // ---- write the next level / the next beam
   for (long e = tid; e < (long)keep * Kmax; e += NT) {
     const int r = (int)(e / Kmax), c2 = (int)(e - (long)r * Kmax);
-    const int i = winv[r];
-    const int b = node_of(i);
-    const int c = i - cbase[b];
+    const int b = wbc[r] & 0xffff, c = wbc[r] >> 16;
     const int Kb = in.K[b];
     const bool is_new = c == Kb;
     const int Knew = Kb + (is_new ? 1 : 0);
@@ -3559,10 +3631,10 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   }
   WSTAMP(5);
   uint16_t* bp = st.bp16 + ((size_t)st.bp_base[u] + (size_t)win * B) * (L + 1);
+  const int row_base = lds_misc[5];
   for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
-    const int b = node_of(i);
-    const int c = i - cbase[b];
+    const int b = wbc[r] & 0xffff, c = wbc[r] >> 16;
     const int Kb = in.K[b];
     const bool is_new = c == Kb;
     int Knew = Kb + (is_new ? 1 : 0);
@@ -3582,19 +3654,21 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
       for (int k = 0; k < j; ++k) rec[1 + k] = (uint16_t)in.path[(size_t)b * L + k];
       rec[1 + j] = (uint16_t)c;
       for (int k = j + 1; k < L; ++k) rec[1 + k] = 0xffffu;
-      atomicMax(&st.counters[3], (unsigned long long)Knew);  // surviving hypotheses only
+      atomicMax(&lds_misc[6], Knew);  // surviving hypotheses only (one global atomic per utterance below)
     }
     if (leadv[r] == r) {
       const int src = srcv[r];
       const int nprev = src < S ? cntv[src] : 0;
       st.pool_cnt[(size_t)u * S + dstv[r]] = nprev + 1;
-      const int pos = atomicAdd(&st.nrows[par], 1);
+      const int pos = row_base + ordv[r];
       RnnRow rr; rr.utt = u; rr.src = src < S ? src : -1; rr.dst = dstv[r]; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
       st.rows[pos] = rr;
     }
   }
   WSTAMP(6);
+  __syncthreads();
   if (tid == 0) {
+    if (last && lds_misc[6] > 0) atomicMax(&st.counters[3], (unsigned long long)lds_misc[6]);
 #if defined(UIS_SELECT_TIMING)
     atomicAdd(&st.counters[(last ? 32 : 16) + 7], 1ull);                              // launches
     atomicAdd(&st.counters[(last ? 32 : 16) + 8], (unsigned long long)C);             // candidates

@@ -60,7 +60,7 @@ __host__ __device__ constexpr int rs_max_grid(int npos) { return 64 * npos; }
 
 // beam_size, max_clusters, slots per utterance: run-time values, or compile-time constants in the
 // instantiations built for one shape (every RsLds offset then folds into the instruction stream)
-struct RsDims { int B, Kmax, S; };
+struct RsDims { int B, Kmax, S, D; };  // D = observation_dim (unpadded)
 
 struct RsLds {
   // per utterance, persistent: two table sets (by step parity) + frames per slot + masks
@@ -153,6 +153,14 @@ __device__ __forceinline__ unsigned rs_magic20(unsigned d) {
   return q;
 }
 
+// one float through a buffer descriptor with a 32-bit byte offset (no 64-bit address arithmetic per lane)
+__device__ __forceinline__ float rs_buf_load_f32_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ void rs_buf_store_f32(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, byte_off, 0, 0);
+}
+
 // set bits of a wave mask below this lane (v_mbcnt: two instructions)
 __device__ __forceinline__ int rs_below(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -184,7 +192,7 @@ __device__ __forceinline__ int rs_wave_max_i32(int v) {  // small non-negative v
 // d = 256 c + 4 * (p + 16 k), k = 0..3, of 256-float block c (index 4 c + k).  Lane p == 0 returns the
 // value.  DP <= 512: one or two blocks.
 template <int DP>
-__device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&mv)[4 * ((DP + 255) / 256)],
+__device__ __forceinline__ float rs_mse16_regs(int D, const f32x4 (&mv)[4 * ((DP + 255) / 256)],
                                                const f32x4 (&xv)[4 * ((DP + 255) / 256)], const float* swgt, int p) {
   constexpr int NB = (DP + 255) / 256;
   float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -201,7 +209,7 @@ __device__ __forceinline__ float rs_mse16_regs(const DevModel& m, const f32x4 (&
     mse16_block(mc, xc, wv, A);  // (chunks past DP are zero-filled)
   }
   const float d0 = mv[0][0] - xv[0][0];  // meaningful on lane p == 0 (d = 0): the only lane whose value is stored
-  return uis_mse_finish(mse16_total(A), d0 * d0, m.D);
+  return uis_mse_finish(mse16_total(A), d0 * d0, D);
 }
 template <int DP>
 __device__ __forceinline__ void rs_load_mean16(__amdgpu_buffer_rsrc_t rs_mean, size_t slot_index, int p,
@@ -329,7 +337,7 @@ __device__ __forceinline__ RsPrep<NPOS> rs_prep(const DevModel& m, const DecodeS
           }
         } else {
           cslot = -1;
-          prior = (m.lp_sw + m.l_alpha) - ld;
+          prior = m.lp_new - ld;
         }
       }
     }
@@ -347,15 +355,16 @@ __device__ __forceinline__ RsPrep<NPOS> rs_prep(const DevModel& m, const DecodeS
 // FRONT: the MSEs, scores, prune, winners, rows -- what the step's dense stages wait for.  One wave
 // (all 64 lanes), utterance u, decode step `step` whose frame is row `frame` of the stream.  pers =
 // the utterance's persistent block, scr = its scratch (rs_prep left the free slots there).
-// `part0` = where the partial sums of the rows this utterance emitted in the previous step start
-// (the i-th slot of its new-slot list was written by its i-th row).
+// rs_part + part_off = where the partial sums of the rows this utterance emitted in the previous step
+// start (the i-th slot of its new-slot list was written by its i-th row).
 // FULL: the wave computes the MSE of the frame against EVERY live cluster mean itself (no published
 // values, no partial sums: k_decode_big, where a wave owns its utterance alone); P.old* then lists all
 // live slots and `swgt_full` is 1 / (2 sigma^2) in LDS.
 template <int DP, bool FULL = false, int NPOS = 3>
 __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& st, const RsLds& L, const RsDims dm, int u, int step,
-                                          long frame, unsigned char* pers, unsigned char* scr, const float* part0,
-                                          const RsPrep<NPOS>& P, unsigned long long* ph, const float* swgt_full = nullptr) {
+                                          long frame, unsigned char* pers, unsigned char* scr, __amdgpu_buffer_rsrc_t rs_part,
+                                          uint32_t part_off, const RsPrep<NPOS>& P, unsigned long long* ph,
+                                          const float* swgt_full = nullptr) {
   // (opaque to the optimiser: nothing lane-derived is hoisted out of the kernel's step loop, where
   // it would have to stay live -- spilled -- across the dense stages)
   int lane_ = threadIdx.x & 63;
@@ -412,7 +421,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
         }
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-          const float v = rs_mse16_regs<DP>(m, mv[h2], xv, swgt_full, p);
+          const float v = rs_mse16_regs<DP>(dm.D, mv[h2], xv, swgt_full, p);
           if (p == 0 && i0 + 4 * h2 + grp < n) smse[sl[h2]] = v;
         }
       }
@@ -435,12 +444,10 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   float pfirst = 0.0f;
   int nsl = 0;
   if (lane < nn) {
-    const __amdgpu_buffer_rsrc_t rs_part =
-        __builtin_amdgcn_make_buffer_rsrc((void*)part0, (short)0, 0x7fffffff, 0x00020000);
     nsl = snewlist[1 + lane];
 #pragma unroll
-    for (int k = 0; k < PV; ++k) pv[k] = load_sc1(rs_part, (uint32_t)(lane * PSTR * 4 + 16 * k));
-    pfirst = load_f32_sc1(part0 + lane * PSTR + rs_part_first(DP));
+    for (int k = 0; k < PV; ++k) pv[k] = load_sc1(rs_part, part_off + (uint32_t)(lane * PSTR * 4 + 16 * k));
+    pfirst = rs_buf_load_f32_sc1(rs_part, part_off + (uint32_t)((lane * PSTR + rs_part_first(DP)) * 4));
   }
   PSTAMP(0);
   // ---- the MSEs: the published values first (they arrive first), then the rewritten clusters
@@ -457,7 +464,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
         A[4 * k + e] = PV == 4 ? pv[k][e] : pv[k][e] + pv[(k + 4) & (PV - 1)][e];
       }
     }
-    smse[nsl] = uis_mse_finish(uis_mse_acc_sum(A), pfirst, m.D);
+    smse[nsl] = uis_mse_finish(uis_mse_acc_sum(A), pfirst, dm.D);
   }
   }
   rs_lds_fence();
@@ -780,7 +787,7 @@ __device__ __forceinline__ void rs_early_mse(const DevModel& m, const DecodeStat
     const int sl = (int)s_list[i < n ? i : 0];
     f32x4 mv[NV];
     rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl, p, mv);
-    const float v = rs_mse16_regs<DP>(m, mv, xv, swgt, p);
+    const float v = rs_mse16_regs<DP>(dm.D, mv, xv, swgt, p);
     if (p == 0 && i < n) tab[sl] = v;
   }
 }
@@ -982,7 +989,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   const int ncl = st.ncl;
   const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
   const int U = st.U;
-  const RsDims dm{CB ? CB : st.B, CB ? CK : st.Kmax, CB ? CB * CK + CB : st.S};
+  // (the fixed-shape classes are dispatched for unpadded models only: observation_dim = DP, rnn_hidden_size = HP)
+  const RsDims dm{CB ? CB : st.B, CB ? CK : st.Kmax, CB ? CB * CK + CB : st.S, CB ? DP : m.D};
+  const int Hreal = CB ? HP : m.H;
   const int S = dm.S, B = dm.B;
   const RsLds L = rs_lds_layout(dm.B, dm.Kmax, dm.S);
   float* swgt = reinterpret_cast<float*>(smem_raw);
@@ -1068,16 +1077,19 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hst =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
-  float* const hst = st.gi_up;
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   // per-producer phase words of this cluster: the row-counter line of the owner-select kernel, unused here
   uint32_t* const flags_c = reinterpret_cast<uint32_t*>(st.rx_nrows) + cluster * 32;
   const __amdgpu_buffer_rsrc_t rs_flags =
       __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
   // UIS_FLAG_TEST_STALL: one workgroup publishes phases below 8 only (it goes silent after two steps)
   const uint32_t live_mask = ((st.flags & 0x4000u) != 0u && cluster == 0 && rank == 5) ? 7u : 0xffffffffu;
-  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
+  const int tile0 = (cluster * st.rx_stride) >> 4;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);
-  float* const part_c = st.mse_part + (size_t)cluster * st.rx_stride * PSTR;  // this cluster's rows of partial sums
+  // this cluster's rows of partial sums
+  const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(st.mse_part + (size_t)cluster * st.rx_stride * PSTR), (short)0, 0x7fffffff, 0x00020000);
   __syncthreads();
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1100,10 +1112,10 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       const long frame_w = off0_w[q] + fpos_w[q];
       if (act_w[q]) {
 #if defined(UIS_RESIDENT_TIMING)
-        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], part_c + (size_t)prev_base[q] * PSTR,
+        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], rs_part, (uint32_t)(prev_base[q] * PSTR * 4),
                                            prep[q], (blockIdx.x == 0 && w == 0 && q == 0) ? ph_acc : nullptr);
 #else
-        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], part_c + (size_t)prev_base[q] * PSTR,
+        win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], rs_part, (uint32_t)(prev_base[q] * PSTR * 4),
                                            prep[q], nullptr);
 #endif
       }
@@ -1171,9 +1183,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);
             const long frame = s_wframe[((unsigned)re[k].nprev >> 16) & (unsigned)(SLOTS - 1)];
             re[k].nprev &= 0xffff;
-            const float* gi = st.gi0 + (size_t)frame * m.G;
+            const float* gi = st.gi0 + (size_t)frame * (3 * HP);  // (m.G)
             gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
-            hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
+            hprev[k] = rs_buf_load_f32_sc1(rs_hid, (uint32_t)(((re[k].src >= 0 ? re[k].utt * S + re[k].src : U * S) * HP + j) * 4));
           }
         };
         auto combine_rz = [&]() {  // SPLIT2: gates r and z while gate n's partial tiles wait in registers
@@ -1202,9 +1214,9 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             ghz[k] = splitk_combine<RC, 3>(spart, r, 1, e);
             ghn = splitk_combine<RC, 3>(spart, r, 2, e);
           }
-          const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr[k], ghz[k], ghn, hprev[k]) : 0.0f;
-          st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
-          hst[((tile0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;
+          const float out = j < Hreal ? uis_gru_unit(gir[k], giz[k], gin[k], ghr[k], ghz[k], ghn, hprev[k]) : 0.0f;
+          rs_buf_store_f32(rs_hid, (uint32_t)(((re[k].utt * S + re[k].dst) * HP + j) * 4), out);
+          rs_buf_store_f32(rs_hst, (uint32_t)(((tile0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e) * 4u, out);
         }
         FSTAMP(2);
         __syncthreads();
@@ -1261,7 +1273,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           const int r = e >> 8, tile = tpar1 + SH1 * (i0 + r), lrow = 16 * tile + ((e & 255) >> 4);
           if (i0 + r < my1h && lrow < nrows) {
             const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
-            st.a1[((tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
+            rs_buf_store_f32(rs_a1, (uint32_t)(((tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)) * 4u, v > 0.0f ? v : 0.0f);
           }
         }
         __syncthreads();
@@ -1316,7 +1328,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
             re[k] = lds_row_head(s_head, ework[k] ? lrow : 0);  // (no branch around the load: see the GRU stage)
             xn[k] = st.x[(size_t)s_wnext[((unsigned)re[k].nprev >> 16) & (unsigned)(SLOTS - 1)] * DP + f];  // the NEXT frame of the row's utterance
             re[k].nprev &= 0xffff;
-            old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + (re[k].src >= 0 ? re[k].src : 0)) * m.Dp + f);
+            old[k] = rs_buf_load_f32_sc1(rs_mean, (uint32_t)(((re[k].utt * S + (re[k].src >= 0 ? re[k].src : 0)) * DP + f) * 4));
           }
         };
         f32x4 w2r[1][PER];
@@ -1330,8 +1342,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           const int r = (t >> 8) + 2 * k;
           float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
           if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
-          if (f >= m.D) v = 0.0f;
-          st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+          if (f >= dm.D) v = 0.0f;
+          rs_buf_store_f32(rs_mean, (uint32_t)(((re[k].utt * S + re[k].dst) * DP + f) * 4), v);
           // this tile's share of the next step's weighted MSE against the mean just written
           // (uis_numerics.h: the row's 16 features of the tile sit in 16 adjacent lanes -- quad sums
           // left to right, then (q0 + q1) + (q2 + q3)); the select adds the tiles' sums
@@ -1340,8 +1352,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           q = q + dpp_perm<0x141>(q);  // row_half_mirror: the neighbouring quad's sum
           q = q + dpp_perm<0x140>(q);  // row_mirror: the other half's
           const int lrow = 16 * (tpar2 + SH2 * (i0 + r)) + ((t & 255) >> 4);
-          if ((t & 15) == 0) part_c[(size_t)lrow * PSTR + ft2] = q;
-          if (f == 0) { const float d0 = v - xn[k]; part_c[(size_t)lrow * PSTR + rs_part_first(DP)] = d0 * d0; }
+          if ((t & 15) == 0) rs_buf_store_f32(rs_part, (uint32_t)((lrow * PSTR + ft2) * 4), q);
+          if (f == 0) { const float d0 = v - xn[k]; rs_buf_store_f32(rs_part, (uint32_t)((lrow * PSTR + rs_part_first(DP)) * 4), d0 * d0); }
         }
         __syncthreads();
       }
