@@ -774,7 +774,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     const int per_xcd = (U + ncl - 1) / ncl;
     const bool base_shape = m.Dp <= 256 && rs_select_ok(B, Kmax, S, (long)maxT, 3);
     if (base_shape && per_xcd <= UIS_RS_UTT && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024)
-      rs_kind = (m.Hp == 512 && m.Dp == 256 && m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1")) ? RS_C1 : RS_BASE;
+      rs_kind = (m.Hp == 512 && m.Dp == 256 && m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1") && !getenv("UIS_NO_SHAPE_CLASSES")) ? RS_C1 : RS_BASE;
     else if (base_shape && per_xcd <= 2 * UIS_RS_UTT && m.Hp == 512 && m.Dp == 256 &&
              ((UIS_RS_UPW2_DEFAULT && !getenv("UIS_RS_NO_UPW2")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
              resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 2, true) <= 160 * 1024)
@@ -1035,18 +1035,24 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
       decode_kernel = rs ? (UIS_DK_RS | (rs_kind << 16)) : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
-#define UIS_BIGWS_CASE(HPV, DPV)                                                                                      \
-  if (m.Hp == HPV && m.Dp == DPV && big_ws) {                                                                        \
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_big<HPV, DPV, true>),                        \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                             \
-    if ((rc = gl.run_cooperative(UIS_K_GRU, &k_decode_big<HPV, DPV, true>, h->n_cu, dim3(32 * ncl), dim3(512),     \
-                                 shmem, m, gp.st)))                                                                  \
+      // the shapes of BASELINE's configs as compile-time constants (unpadded models only; UIS_NO_SHAPE_CLASSES=1
+      // keeps the run-time instantiations: A/B switch, bit-identical)
+      const bool exact = m.D == m.Dp && m.H == m.Hp && !getenv("UIS_NO_SHAPE_CLASSES");
+      const bool cls_c1 = exact && m.Hp == 512 && m.Dp == 256 && B == 10 && Kmax == 16;   // configs[1] / [3]: beam 10, cap 16
+      const bool cls_c4 = exact && m.Hp == 512 && m.Dp == 512 && B == 20 && Kmax == 11;   // configs[4]: beam 20, cap 11
+#define UIS_BIGWS_CASE(HPV, DPV, COND, ...)                                                                           \
+  if (m.Hp == HPV && m.Dp == DPV && big_ws && (COND)) {                                                              \
+    void (*kern)(DevModel, DecodeState) = &k_decode_big<HPV, DPV, true, ##__VA_ARGS__>;                              \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
       return rc;                                                                                                     \
   }
-      UIS_BIGWS_CASE(512, 256)
-      UIS_BIGWS_CASE(512, 128)
-      UIS_BIGWS_CASE(256, 256)
-      UIS_BIGWS_CASE(256, 128)
+      UIS_BIGWS_CASE(512, 256, cls_c1, 10, 16)
+      UIS_BIGWS_CASE(512, 256, !cls_c1)
+      UIS_BIGWS_CASE(512, 128, true)
+      UIS_BIGWS_CASE(256, 256, true)
+      UIS_BIGWS_CASE(256, 128, true)
 #undef UIS_BIGWS_CASE
 #define UIS_RS_CASE(KIND, HPV, DPV, ...)                                                                              \
   if (m.Hp == HPV && m.Dp == DPV && rs_kind == KIND) {                                                               \
@@ -1068,8 +1074,20 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RS_CASE(RS_WIDE, 512, 512, 4, 1, 0, 0, true)
       UIS_RS_CASE(RS_WIDE_C4, 512, 512, 4, 1, 20, 11, true)
 #undef UIS_RS_CASE
+#define UIS_RESIDENT_CLASS(HPV, DPV, COND, CBV, CKV)                                                                  \
+  if (m.Hp == HPV && m.Dp == DPV && !rs && !big_ws && !big && (COND)) {                                              \
+    void (*kern)(DevModel, DecodeState) = &k_decode_resident<HPV, DPV, false, CBV, CKV>;                            \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
+      return rc;                                                                                                     \
+  }
+      UIS_RESIDENT_CLASS(512, 256, cls_c1, 10, 16)
+      UIS_RESIDENT_CLASS(512, 512, cls_c4, 20, 11)
+#undef UIS_RESIDENT_CLASS
+      const bool in_class = !big && (cls_c1 || cls_c4);
 #define UIS_RESIDENT_CASE(HPV, DPV)                                                                                   \
-  if (m.Hp == HPV && m.Dp == DPV && !rs && !big_ws) {                                                                \
+  if (m.Hp == HPV && m.Dp == DPV && !rs && !big_ws && !in_class) {                                                   \
     void (*kern)(DevModel, DecodeState) = big ? &k_decode_big<HPV, DPV> : &k_decode_resident<HPV, DPV>;             \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \

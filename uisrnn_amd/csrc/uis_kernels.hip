@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_select(DevModel m, DecodeState st, int 
       prior = (c == slast[b]) ? m.lp_stay : (m.lp_sw + lb) - ld;
     } else {          // new cluster, uisrnn.py:440-446
       mse = mse_new;
-      prior = (m.lp_sw + m.l_alpha) - ld;
+      prior = m.lp_new - ld;
     }
     const float sc = sscore[b] + uis_step_loss(mse, prior);  // float32 accumulate, uisrnn.py:452
     scscore[i] = sc;
@@ -1494,7 +1494,7 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
       prior = (my_c == slast[my_b]) ? m.lp_stay : (m.lp_sw + my_lb) - my_ld;
     } else {
       mse = mse_new;
-      prior = (m.lp_sw + m.l_alpha) - my_ld;
+      prior = m.lp_new - my_ld;
     }
     my_sc = sscore[my_b] + uis_step_loss(mse, prior);
     if (uis_isfinite(my_sc)) my_key = ((unsigned long long)uis_score_key(my_sc) << 32) | (unsigned)tid;
@@ -1919,8 +1919,14 @@ __device__ __forceinline__ f32x4 sys_load_f32x4(const float* p) {
 // mailbox in host-coherent memory, polled by rank 0 of every cluster and passed on through the
 // cluster's line of pm.go; it leaves by itself after pm.idle_ticks without a command.
 // Beam tables stay in LDS from push to push; needs at most one utterance per workgroup.
-template <int HP, int DP, bool PERSIST = false>
+// CB, CK: beam_size and max_clusters as compile-time constants (0: run-time values) -- the
+// instantiations for the shapes of BASELINE's configs, dispatched for unpadded models only: every
+// table offset, division and loop bound that depends on them folds (round 4: k_decode_rs gained 4 %
+// from the same substitution).
+template <int HP, int DP, bool PERSIST = false, int CB = 0, int CK = 0>
 __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState st) {
+  m.Hp = HP; m.Dp = DP; m.G = 3 * HP;  // (what the template arguments say)
+  if (CB) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }
   constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
   constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
@@ -2871,8 +2877,10 @@ __host__ __device__ inline size_t big_ws_lds_bytes(int Hp, int Dp, int B, int Km
   return ((big_ws_select_bytes(Dp, B, Kmax, S, nws) + 255) & ~(size_t)255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
 }
 
-template <int HP, int DP, bool WS = false>
+template <int HP, int DP, bool WS = false, int CB = 0, int CK = 0>
 __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
+  m.Hp = HP; m.Dp = DP; m.G = 3 * HP;  // (what the template arguments say)
+  if (CB) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }  // (see k_decode_resident)
   constexpr int NKB = HP / 16;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
   constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
@@ -3460,7 +3468,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
         if (c < Kb) emit(c, mse[sl[e]], (c == lastb) ? m.lp_stay : (m.lp_sw + lb[e]) - ld);
       }
     }
-    emit(Kb, mse_new, (m.lp_sw + m.l_alpha) - ld);
+    emit(Kb, mse_new, m.lp_new - ld);
   }
   __syncthreads();
   WSTAMP(2);
