@@ -193,6 +193,8 @@ struct uis_handle {
   float* h_cast = nullptr;
   size_t h_cast_cap = 0;
   void* cast_pool = nullptr;  // CastPool: the threads that cast (created by the first uis_decode_f64)
+  void* h_out = nullptr;      // pinned landing block of uis_decode_f64's labels and scores
+  size_t h_out_cap = 0;
   ProfileEvents prof;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_pre = nullptr;
   // utterance groups: one stream + one cached step graph each
@@ -560,7 +562,10 @@ struct CastPool {
   bool quit = false;
   void ensure_started() {
     if (!threads.empty() || quit) return;
-    unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    // (measured on the 256-core GPU box, configs[1], frames/s of the float64 leg: 4 / 8 threads 1.600 M, 16 1.56-1.59 M,
+    // 24 1.59 M, 32 1.58 M, 48 1.59 M -- the cast is a few hundred microseconds of memory traffic; more threads only
+    // add wake-up jitter: profiles/r04_f64_leg.txt)
+    unsigned nt = std::min(std::max(1u, std::thread::hardware_concurrency()), 8u);
     if (const char* e = getenv("UIS_CAST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
     try {
       for (unsigned k = 1; k < nt; ++k) threads.emplace_back([this, k]() { worker(k); });
@@ -1028,8 +1033,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       const bool big_ws = big && !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
                           rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
                           big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
-      const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_kind == RS_UPW2 ? 2 : 1,
-                                                                             rs_kind == RS_UPW2 || rs_kind == RS_WIDE)
+      const bool rs_two = rs_kind == RS_UPW2 || rs_kind == RS_UPW2_C1, rs_wide = rs_kind == RS_WIDE || rs_kind == RS_WIDE_C4;
+      const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_two ? 2 : 1, rs_two || rs_wide)
                                             : big_ws ? big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
                                             : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
@@ -1323,6 +1328,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   for (hipEvent_t e : h->h2d_done) (void)hipEventDestroy(e);
   if (h->cast_pool) { delete static_cast<CastPool*>(h->cast_pool); h->cast_pool = nullptr; }
   if (h->h_cast) (void)hipHostFree(h->h_cast);
+  if (h->h_out) (void)hipHostFree(h->h_out);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1422,10 +1428,32 @@ UIS_EXPORT int32_t uis_decode(uis_handle* h, const float* frames, const int64_t*
                    h->io_scores.as<float>(), stats, frames);
   if (rc != UIS_OK && rc != UIS_ERR_CLUSTER_CAP) return rc;
   if (rc == UIS_OK) h->io_offsets.assign(offsets, offsets + n_utt + 1);
-  if (F > 0) HIPCHK(hipMemcpyAsync(labels_out, h->io_labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
+  // uis_decode_f64 (the caller's label array is ordinary pageable memory, a numpy array): the labels
+  // come down into a pinned block and are copied out by the CPU -- a device-to-pageable copy is staged
+  // by the runtime in small pieces
+  int32_t* lab_dst = labels_out;
+  float* sc_dst = scores_out;
+  if (h->src64) {
+    const size_t need = (size_t)std::max<int64_t>(F, 1) * 4 + (size_t)std::max(n_utt, 1) * 4;
+    if (need > h->h_out_cap) {
+      if (h->h_out) { (void)hipHostFree(h->h_out); h->h_out = nullptr; h->h_out_cap = 0; }
+      void* p = nullptr;
+      if (hipHostMalloc(&p, need, hipHostMallocDefault) == hipSuccess) { h->h_out = p; h->h_out_cap = need; }
+      else (void)hipGetLastError();  // (no pinned memory to be had: straight into the caller's arrays)
+    }
+    if (h->h_out) {
+      lab_dst = static_cast<int32_t*>(h->h_out);
+      sc_dst = reinterpret_cast<float*>(static_cast<char*>(h->h_out) + (size_t)std::max<int64_t>(F, 1) * 4);
+    }
+  }
+  if (F > 0) HIPCHK(hipMemcpyAsync(lab_dst, h->io_labels.p, (size_t)F * 4, hipMemcpyDeviceToHost, h->stream));
   if (scores_out && n_utt > 0)
-    HIPCHK(hipMemcpyAsync(scores_out, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sc_dst, h->io_scores.p, (size_t)n_utt * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (lab_dst != labels_out) {
+    if (F > 0) memcpy(labels_out, lab_dst, (size_t)F * 4);
+    if (scores_out && n_utt > 0) memcpy(scores_out, sc_dst, (size_t)n_utt * 4);
+  }
   return rc;
 }
 

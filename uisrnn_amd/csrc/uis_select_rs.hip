@@ -346,7 +346,9 @@ __device__ __forceinline__ RsPrep<NPOS> rs_prep(const DevModel& m, const DecodeS
   P.C = 0;
 #pragma unroll
   for (int k = 0; k < NPOS; ++k) {
-    if (k == 0 || P.nch > k) prep_at(lane + 64 * k, k, P.cslot[k], P.pr[k], P.bs[k]);
+    // (three positions: chunks past the grid are skipped by a wave-uniform branch -- a beam of 10 rarely has
+    // more than 64 candidates; four positions: no branch, so that the chunks' LDS round trips overlap)
+    if (NPOS > 3 || k == 0 || P.nch > k) prep_at(lane + 64 * k, k, P.cslot[k], P.pr[k], P.bs[k]);
     P.C += __popcll(__ballot(P.cslot[k] != -2));
   }
   return P;
@@ -477,7 +479,7 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   for (int k = 0; k < NPOS; ++k) {
     key[k] = UIS_RS_NOKEY;
     sc[k] = 0.0f;
-    if ((k == 0 || nch > k) && P.cslot[k] != -2) {
+    if ((NPOS > 3 || k == 0 || nch > k) && P.cslot[k] != -2) {
       const float mse = P.cslot[k] >= 0 ? smse[P.cslot[k]] : mse_new;
       sc[k] = P.bs[k] + uis_step_loss(mse, P.pr[k]);
       if (uis_isfinite(sc[k])) key[k] = uis_score_key(sc[k]);
