@@ -1780,6 +1780,16 @@ __device__ __forceinline__ long load_row_frame(__amdgpu_buffer_rsrc_t rs_rows, i
 __device__ __forceinline__ float load_f32_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one float through a buffer descriptor with a 32-bit byte offset (no 64-bit address arithmetic per lane)
+__device__ __forceinline__ float rs_buf_load_f32_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 16 /* sc1 */));
+}
+__device__ __forceinline__ void rs_buf_store_f32(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, byte_off, 0, 0);
+}
+__device__ __forceinline__ void rs_buf_store_f32x4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, 0);
+}
 
 // NV (<= RC) row tiles x NG gates of one feature tile, weights from registers: wave w walks its
 // K segment (PER k-blocks), partial tiles to LDS [UIS_KSPLIT][RC][NG][256], ends with the
@@ -1983,6 +1993,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hst =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   // hand-off buffers between the stages (h' -> linear_mean1, a1 -> linear_mean2), k-block major:
   // [row tile][k block = the producer's feature tile][16 rows][16] -- a producer tile is one
   // contiguous KiB and so is a consumer wave's 16-byte-per-lane load
@@ -2368,12 +2380,12 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
             ework[k] = r < RC && i0 + r < my1 && lrow < nrows;
             gir[k] = giz[k] = gin[k] = hprev[k] = 0.0f;
             re[k] = RowHead{0, 0, 0, 0};
-            if (ework[k]) {
+            if (ework[k]) {  // (the branch-free form that pays in k_decode_rs measured 1-2 % slower here: round 4)
               re[k] = lds_row_head(s_head, lrow - 16 * c0);
               const long frame = s_frame[lrow - 16 * c0];
-              const float* gi = st.gi0 + (size_t)frame * m.G;
+              const float* gi = st.gi0 + (size_t)frame * (3 * HP);
               gir[k] = gi[j]; giz[k] = gi[HP + j]; gin[k] = gi[2 * HP + j];
-              hprev[k] = load_f32_sc1(st.pool_hid + (re[k].src >= 0 ? (size_t)re[k].utt * S + re[k].src : (size_t)U * S) * HP + j);
+              hprev[k] = rs_buf_load_f32_sc1(rs_hid, (uint32_t)(((re[k].src >= 0 ? re[k].utt * S + re[k].src : U * S) * HP + j) * 4));
             }
           }
         };
@@ -2389,8 +2401,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           const float ghz = splitk_combine<RC, 3>(spart, r, 1, e);
           const float ghn = splitk_combine<RC, 3>(spart, r, 2, e);
           const float out = j < m.H ? uis_gru_unit(gir[k], giz[k], gin[k], ghr, ghz, ghn, hprev[k]) : 0.0f;
-          st.pool_hid[((size_t)re[k].utt * S + re[k].dst) * HP + j] = out;
-          hst[((tile0 + c0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e] = out;  // the copy linear_mean1 streams
+          rs_buf_store_f32(rs_hid, (uint32_t)(((re[k].utt * S + re[k].dst) * HP + j) * 4), out);
+          rs_buf_store_f32(rs_hst, (uint32_t)((((int)tile0 + c0 + tpar1 + SH1 * (i0 + r)) * NFT1 + ft1) * 256 + e) * 4u, out);  // the copy linear_mean1 streams
         }
         FSTAMP(2);
         __syncthreads();  // spart (and, chunked, the descriptors) are reused
@@ -2426,7 +2438,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
         const int r = e >> 8, tile = tpar1 + SH1 * (i0 + r), lrow = 16 * tile + ((e & 255) >> 4);
         if (i0 + r < my1h && lrow < nrows) {
           const float v = splitk_combine<RC, 1>(spart, r, 0, e & 255);
-          st.a1[((tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)] = v > 0.0f ? v : 0.0f;
+          rs_buf_store_f32(rs_a1, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (e & 255)) * 4u, v > 0.0f ? v : 0.0f);
         }
       }
       __syncthreads();
@@ -2467,7 +2479,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
             re[k] = RowHead{0, 0, 0, 0};
             if (ework[k]) {
               re[k] = lds_row_head(s_head, lrow - 16 * c0);
-              if (re[k].src >= 0) old[k] = load_f32_sc1(st.pool_mean + ((size_t)re[k].utt * S + re[k].src) * m.Dp + f);
+              if (re[k].src >= 0) old[k] = rs_buf_load_f32_sc1(rs_mean, (uint32_t)(((re[k].utt * S + re[k].src) * DP + f) * 4));
             }
           }
         };
@@ -2483,7 +2495,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
           float v = splitk_combine<RC, 1>(spart, r, 0, t & 255);
           if (re[k].src >= 0) v = uis_mean_update(old[k], v, re[k].nprev);
           if (f >= m.D) v = 0.0f;
-          st.pool_mean[((size_t)re[k].utt * S + re[k].dst) * m.Dp + f] = v;
+          rs_buf_store_f32(rs_mean, (uint32_t)(((re[k].utt * S + re[k].dst) * DP + f) * 4), v);
         }
         __syncthreads();
       }
@@ -3067,7 +3079,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
         if (has_next) fetch_head(next, rh_n, frame_n, hoff_n);
         const bool valid = 16 * tile + (lane & 15) < nrows;
         const int j4 = ft1 * 16 + 4 * q;
-        const float* gi = st.gi0 + (size_t)frame * m.G;
+        const float* gi = st.gi0 + (size_t)frame * (3 * HP);
         const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
         const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
         const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
@@ -3079,11 +3091,11 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
-          *reinterpret_cast<f32x4*>(st.pool_hid + ((size_t)rh.utt * S + rh.dst) * HP + j4) = out;
+          rs_buf_store_f32x4(rs_hid, (uint32_t)(((rh.utt * S + rh.dst) * HP + j4) * 4), out);
           // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
           // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
           // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
-          *reinterpret_cast<f32x4*>(hst + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = out;
+          rs_buf_store_f32x4(rs_hst, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, out);
         }
         tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
       }
@@ -3107,7 +3119,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
-        *reinterpret_cast<f32x4*>(st.a1 + ((tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) = v[0];
+        rs_buf_store_f32x4(rs_a1, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, v[0]);
       }
     }
     RSTAMP(4);
@@ -3123,7 +3135,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
       const int f4 = ft2 * 16 + 4 * q;
       f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)((((size_t)rh.utt * S + rh.src) * m.Dp + f4) * 4));
+      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)(((rh.utt * S + rh.src) * DP + f4) * 4));
       f32x4 v[1], bfirst2[GBH];
       rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
       fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
@@ -3133,7 +3145,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
           if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
           if (f4 + i >= m.D) v[0][i] = 0.0f;
         }
-        *reinterpret_cast<f32x4*>(st.pool_mean + ((size_t)rh.utt * S + rh.dst) * m.Dp + f4) = v[0];
+        rs_buf_store_f32x4(rs_mean, (uint32_t)(((rh.utt * S + rh.dst) * DP + f4) * 4), v[0]);
       }
     }
     RSTAMP(6);

@@ -153,14 +153,6 @@ __device__ __forceinline__ unsigned rs_magic20(unsigned d) {
   return q;
 }
 
-// one float through a buffer descriptor with a 32-bit byte offset (no 64-bit address arithmetic per lane)
-__device__ __forceinline__ float rs_buf_load_f32_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 16 /* sc1 */));
-}
-__device__ __forceinline__ void rs_buf_store_f32(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, byte_off, 0, 0);
-}
-
 // set bits of a wave mask below this lane (v_mbcnt: two instructions)
 __device__ __forceinline__ int rs_below(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
