@@ -1998,7 +1998,6 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
   // hand-off buffers between the stages (h' -> linear_mean1, a1 -> linear_mean2), k-block major:
   // [row tile][k block = the producer's feature tile][16 rows][16] -- a producer tile is one
   // contiguous KiB and so is a consumer wave's 16-byte-per-lane load
-  float* const hst = st.gi_up;
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
   const int rbase = cluster * st.rx_stride;
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
@@ -2981,7 +2980,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hst =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
-  float* const hst = st.gi_up;                // hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major
+  // (hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major: rs_hst, rs_a1)
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
   const int rbase = cluster * st.rx_stride;   // this cluster's rows of `rows`
   const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
