@@ -123,8 +123,11 @@ typedef struct uis_decode_opts {
                                     workgroup of the XCD decides all of them, one wave each -- one
                                     in-launch hand-off less per step and a select short enough for a
                                     single wave); A/B switch, results are bit-identical either way */
-#define UIS_FLAG_REPLICATED_SELECT 0x1000u /* one-launch decode: REQUIRE-if-applicable the replicated select
-                                    (k_decode_rs) where it is not the default (A/B switch)         */
+#define UIS_FLAG_REPLICATED_SELECT 0x1000u /* one-launch decode: use the replicated select (k_decode_rs) also in
+                                    the shape classes where it is NOT the default because the owner-select
+                                    kernel measured faster there: beam_size 17 .. 32 or observation_dim 512
+                                    (its "wide" class) and 9 .. 16 utterances per XCD (two utterances per
+                                    wave); A/B switch, results are bit-identical either way         */
 #define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */
