@@ -128,6 +128,10 @@ typedef struct uis_decode_opts {
                                     kernel measured faster there: beam_size 17 .. 32 or observation_dim 512
                                     (its "wide" class) and 9 .. 16 utterances per XCD (two utterances per
                                     wave); A/B switch, results are bit-identical either way         */
+#define UIS_FLAG_CLUSTER_BARRIERS 0x8000u /* one-launch decode with the owner select (k_decode_resident): keep the
+                                    cluster-wide barriers between GRU, linear_mean1 and linear_mean2 instead of
+                                    the per-producer phase words (a consumer wave waits for the four workgroups
+                                    that produce its K-slice); A/B switch, results are bit-identical either way */
 #define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */

@@ -752,6 +752,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
                            select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && ncl >= 1 &&
                            ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
+                           (double)U * S * m.Dp * 4.0 < 2.0e9 &&  // (the cluster means too are addressed through a 2 GB buffer descriptor)
                            resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
   // the default wherever it applies; UIS_FLAG_STEPWISE (or any of the per-step experiments) keeps
   // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
@@ -762,8 +763,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                                      "observation_dim 128, 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
                                      "stream, a device whose CU count is a multiple of 32 and no per-step path flag");
   // control words: [0, 16) XCC id per cluster, [16] abort, [32, 32 + 32 ncl) row counters,
-  // then 32 ncl barrier counters (one 128-byte line per cluster each)
-  const size_t ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
+  // then 32 ncl barrier counters, then 32 ncl phase words (one 128-byte line per cluster each)
+  const size_t ctl_words = (size_t)32 + 3 * UIS_MAX_CLUSTERS * 32;
   static const size_t ctl_place[4] = {0, 8192, (size_t)1 << 20, ((size_t)1 << 20) + 8192};
   ENSURE(cluster_ctl, ctl_place[3] + ((ctl_words * 4 + 4095) & ~(size_t)4095));
   // the one-launch decode with the REPLICATED select (k_decode_rs, uis_select_rs.hip): every workgroup of
@@ -986,6 +987,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       st.rx_stride = rx_stride;
       st.rx_nrows = reinterpret_cast<int32_t*>(ctl) + 32;
       st.rx_bar = ctl + 32 + UIS_MAX_CLUSTERS * 32;
+      st.rx_flags = ctl + 32 + 2 * UIS_MAX_CLUSTERS * 32;
       if (rs) {  // (one group: resident_ok)
         st.mse_tab = h->mse_tab.as<float>();
         st.mse_part = reinterpret_cast<float*>(h->mse_tab.as<char>() + mse_tab_bytes);
@@ -1787,7 +1789,7 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   ss.resident = m.depth == 1 && (m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) &&
                 select_fast_ok(B, Kmax, S) && ncl >= 1 && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
                 ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
-                resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+                (double)U * S * m.Dp * 4.0 < 2.0e9 && resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
   if ((opts->flags & UIS_FLAG_RESIDENT) && !ss.resident)
     { ss = uis_handle::Stream{}; return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT: the one-launch decode does not apply to this session's shape"); }
   int rc = UIS_OK;
@@ -1818,7 +1820,7 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   SALLOC(st.gi_up, m.depth > 1 ? (size_t)rows_cap * m.G : (size_t)rows_cap * m.Hp, false);  // depth 1: the resident kernel's h' staging
   SALLOC(st.a1, (size_t)rows_cap * m.Hp, true);
   SALLOC(st.counters, 96, true);
-  ss.ctl_words = (size_t)32 + 2 * UIS_MAX_CLUSTERS * 32;
+  ss.ctl_words = (size_t)32 + 3 * UIS_MAX_CLUSTERS * 32;
   SALLOC(ss.d_ctl, ss.ctl_words, true);
   st.cl_abort = ss.d_ctl + 16;
   if (ss.resident) {
@@ -1827,6 +1829,7 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
     st.rx_stride = rx_stride;
     st.rx_nrows = reinterpret_cast<int32_t*>(ss.d_ctl) + 32;
     st.rx_bar = ss.d_ctl + 32 + UIS_MAX_CLUSTERS * 32;
+    st.rx_flags = ss.d_ctl + 32 + 2 * UIS_MAX_CLUSTERS * 32;
   }
   SALLOC(ss.d_beam_scores, (size_t)U * B, false);
   if (opts->flags & UIS_FLAG_PERSISTENT) {

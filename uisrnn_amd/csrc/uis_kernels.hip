@@ -1764,6 +1764,84 @@ __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, 
   return *s_abort != 0;
 }
 
+// Hand-offs between dense stages without a cluster-wide barrier.  What a consumer wave reads in
+// linear_mean1 / linear_mean2 is ITS K-slice of every row -- 1/8 of the features, produced by four
+// of the cluster's 32 workgroups (ranks 4w .. 4w + 3 for wave w, whatever the hidden size: a rank's
+// feature tile is rank / SH1 and a wave's slice PER = NFT1 / 8 tiles).  So a producer, once its
+// stores have reached L2, publishes a phase word (3 step + 1 behind the GRU stage, + 2 behind
+// linear_mean1, + 3 behind linear_mean2) and a consumer wave polls the four words of its producers
+// -- one 16-byte load -- instead of everybody waiting for the slowest of 32 and for thread 0 to
+// tell the rest.  No atomic, no counter: a word has one writer.
+__device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint32_t phase) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
+  __syncthreads();
+  // Scope of the store.  The pollers are other workgroups of the SAME XCD (checked at run time,
+  // HW_REG_XCC_ID), reading with sc1 (L1 bypass) from the L2 all 32 share.  An agent-scope store is
+  // `global_store_dword sc1`: a scalar fabric write that also DROPS the line from that L2
+  // (MI355X_MICROARCH.md, "stores of each flavour") -- every poll of 32 workgroups would then go
+  // beyond L2.  A plain store stays in the shared L2, which is the point of coherence that matters
+  // here; that is outside what the HIP memory model promises for workgroup scope, hence the placement
+  // check, the give-up timer and the fallback path.  -DUIS_RS_FLAG_AGENT builds the
+  // by-the-book variant for A/B runs.
+#if defined(UIS_RS_FLAG_AGENT)
+  if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// The first look at the phase words, split in two so that the load can be requested early (from
+// inside the work a wave does between publishing and waiting) and examined late.
+__device__ __forceinline__ u32x4 rs_flag_peek4(__amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off) {
+  return __builtin_bit_cast(u32x4, load_sc1(rs_flags, byte_off));
+}
+__device__ __forceinline__ bool rs_flag_ready4(const u32x4& f, uint32_t phase) {
+  uint32_t mn = f[0] < f[1] ? f[0] : f[1];
+  mn = mn < f[2] ? mn : f[2];
+  mn = mn < f[3] ? mn : f[3];
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase;
+}
+__device__ __forceinline__ uint32_t rs_flag_peek_all(const uint32_t* flags) {
+  const int lane = threadIdx.x & 63;
+  return __hip_atomic_load(flags + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool rs_flag_ready_all(uint32_t f, uint32_t phase) { return __ballot(f < phase) == 0ull; }
+// true: gave up (a producer never published, or somebody else gave up)
+__device__ __forceinline__ bool rs_flag_wait(const DecodeState& st, __amdgpu_buffer_rsrc_t rs_flags, uint32_t byte_off, uint32_t phase) {
+  unsigned spins = 0;
+  for (;;) {
+    const u32x4 f = __builtin_bit_cast(u32x4, load_sc1(rs_flags, byte_off));
+    asm volatile("" ::: "memory");  // (a fresh load every round)
+    uint32_t mn = f[0] < f[1] ? f[0] : f[1];
+    mn = mn < f[2] ? mn : f[2];
+    mn = mn < f[3] ? mn : f[3];
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)mn) >= phase) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 21)) {  // ~1 s: give up instead of hanging the device
+      __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+  }
+}
+// ... and the step's last hand-off: the select needs every workgroup's partial sums and early MSEs,
+// so a wave waits for all 32 words (lane l < 32 looks at producer l's).  Passing it also means every
+// workgroup is through with the step's reads, which is what lets the next step overwrite the row
+// tiles and reuse freed slots.
+__device__ __forceinline__ bool rs_flag_wait_all(const DecodeState& st, const uint32_t* flags, uint32_t phase) {
+  const int lane = threadIdx.x & 63;
+  unsigned spins = 0;
+  for (;;) {
+    const uint32_t f = lane < 32 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : phase;
+    if (__ballot(f < phase) == 0ull) return false;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 21)) {
+      __hip_atomic_store(st.cl_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if ((spins & 255u) == 0 && __hip_atomic_load(st.cl_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+  }
+}
+
 struct RowHead { int utt, src, dst, nprev; };
 __device__ __forceinline__ RowHead load_row_head(__amdgpu_buffer_rsrc_t rs_rows, int row) {
   const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs_rows, (uint32_t)row * 32u, 0, 16);
@@ -1965,6 +2043,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     s_ctl[0] = 0;
     s_ctl[1] = 0;
     s_ctl[2] = 0;  // "this workgroup has already arrived at the barrier it is about to wait at"
+    s_ctl[9] = 0;  // a wave gave up waiting for its producers' phase words
     s_ctl[6] = 0;  // PERSIST, rank 0: the host's sequence number of the last command taken
 #if defined(UIS_RESIDENT_TIMING) || defined(UIS_RESIDENT_PROBE)
     for (int k = 0; k < 8; ++k) reinterpret_cast<unsigned long long*>(smem_raw + L.off_misc + 64)[k] = 0;
@@ -1995,6 +2074,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mean =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  // Round 4: GRU -> linear_mean1 -> linear_mean2 hand over through per-producer phase words, as in
+  // k_decode_rs (rs_flag_publish / rs_flag_wait): a consumer wave reads ITS K-slice of every row -- what
+  // ranks 4 w .. 4 w + 3 produced -- so it waits for those four workgroups, not for the slowest of 32.
+  // The barriers behind linear_mean2 and behind the select stay cluster-wide (every workgroup needs
+  // every mean / every row), which is also what makes the reuse of the staging buffers safe.
+  // UIS_FLAG_CLUSTER_BARRIERS keeps the two barriers (A/B switch, bit-identical).
+  uint32_t* const flags_c = st.rx_flags + cluster * 32;
+  const __amdgpu_buffer_rsrc_t rs_flags = __builtin_amdgcn_make_buffer_rsrc((void*)flags_c, (short)0, 128, 0x00020000);
+  const bool flag_handoff = (st.flags & 0x8000u) == 0u;
+  uint32_t fphase = 0;  // hand-offs of this launch so far (every workgroup of the cluster counts the same)
   // hand-off buffers between the stages (h' -> linear_mean1, a1 -> linear_mean2), k-block major:
   // [row tile][k block = the producer's feature tile][16 rows][16] -- a producer tile is one
   // contiguous KiB and so is a consumer wave's 16-byte-per-lane load
@@ -2410,14 +2499,26 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     }
     RSTAMP(2);
     const bool prep_next = keep_beam && did_select && s + 1 < nsteps;
-    if (prep_next) {
-      // arrive, do the first half of the next step's select preparation (this workgroup's own LDS
-      // tables: nobody else's data), then wait
-      xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
-                                               SelectNoHook(), first_step);
+    ++fphase;
+    if (flag_handoff) {
+      // publish; the first half of the next step's select preparation (this workgroup's own LDS tables:
+      // nobody else's data); then every wave waits for the four producers of its K-slice
+      rs_flag_publish(flags_c, rank, fphase);
+      if (prep_next)
+        select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                                 SelectNoHook(), first_step);
+      if (nrt > tpar1 && !rs_flag_ready4(rs_flag_peek4(rs_flags, (uint32_t)(16 * w)), fphase) &&
+          rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), fphase))
+        s_ctl[9] = 1;  // gave up (cl_abort is set): every wave leaves at the next cluster barrier
+    } else {
+      if (prep_next) {
+        // arrive, do the first half of the next step's select preparation, then wait
+        xcd_arrive(st, cluster, s_ctl);
+        select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                                 SelectNoHook(), first_step);
+      }
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     }
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(3);
 
     // ---- linear_mean1 + relu -> a1 (needs no descriptors: row tile in, row tile out)
@@ -2443,12 +2544,23 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       __syncthreads();
     }
     RSTAMP(4);
-    if (prep_next) {  // ... and the second half inside the next barrier
-      xcd_arrive(st, cluster, s_ctl);
-      select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
-                                               SelectNoHook(), first_step);
+    ++fphase;
+    if (flag_handoff) {  // ... and the second half inside the next hand-off
+      rs_flag_publish(flags_c, rank, fphase);
+      if (prep_next)
+        select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                                 SelectNoHook(), first_step);
+      if (nrt > tpar2 && !rs_flag_ready4(rs_flag_peek4(rs_flags, (uint32_t)(16 * w)), fphase) &&
+          rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), fphase))
+        s_ctl[9] = 1;
+    } else {
+      if (prep_next) {
+        xcd_arrive(st, cluster, s_ctl);
+        select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
+                                                 SelectNoHook(), first_step);
+      }
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     }
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
     RSTAMP(5);
 
     // ---- linear_mean2 + running mean -> dst slot; of every chunk this rank takes the row tiles
@@ -2500,7 +2612,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       }
     }
     RSTAMP(6);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) { left_aborted(); return; }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl) || s_ctl[9]) { left_aborted(); return; }
     RSTAMP(7);
   }
   if (!PERSIST) {
