@@ -208,10 +208,18 @@ def test_resident_decode_is_bit_identical(oracle_lib):
   many256, _ = synth.make_utterances(8960, 300, 11, 256)
   _compare(small, many256, 10, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)
   _compare(small, seqs, 10, 1, 2, oracle_lib, flags=_capi.UIS_FLAG_RESIDENT)
-  with pytest.raises(_capi.HipLibraryError):  # hidden size 24: not supported, must be refused
-    case = golden_util.load_case('d20_h24_depth3')
-    d2 = _capi.Decoder(case['params'])
-    d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
+  # hidden size 24, depth 3: a small model -- its one-launch decode is k_decode_small (round 4)
+  case = golden_util.load_case('d20_h24_depth3')
+  d2 = _capi.Decoder(case['params'])
+  out = d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
+  assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_small'
+  with pytest.raises(_capi.HipLibraryError):  # hidden size 200 (padded 208): no one-launch kernel, must be refused
+    from uisrnn_amd import weights
+    p3 = weights.init_params(40, 200, 1, sigma2=0.1, transition_bias=0.2, seed=3)
+    s3 = [np.random.default_rng(3).standard_normal((9, 40))]
+    _capi.Decoder(p3).decode(*oracle_lib.pack(s3), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
+  with pytest.raises(_capi.HipLibraryError):  # look_ahead 2: never one launch
+    d2.decode(*oracle_lib.pack(case['seqs']), 6, 2, 2, flags=_capi.UIS_FLAG_RESIDENT)
 
 
 @pytest.mark.parametrize('dim,hidden', [(256, 512), (256, 256), (512, 512), (128, 256)])
@@ -874,3 +882,46 @@ def test_candidate_arrays_on_the_wide_select(oracle_lib):
   assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_rs<wide>'
   got = dec.debug_scores(tau * seq.shape[0], 1, beam, kmax)[:, 0]
   assert np.array_equal(_bits(got), _bits(ora))
+
+
+def test_small_models_decode_in_one_launch(oracle_lib):
+  """k_decode_small (round 4): models the size of the reference's own tests -- hidden size 8 / 24,
+  rnn_depth 1, 2 and 3, observation dims that are not multiples of 16 -- run their whole beam
+  search in ONE launch, one workgroup per utterance, on the launch-per-step kernels' own tile
+  function.  Named by the library, REQUIRED with UIS_FLAG_RESIDENT (no silent fallback), bit for
+  bit the oracle's labels / scores / whole final beams, also against the launch-per-step path
+  (UIS_FLAG_STEPWISE), with and without row de-duplication, wide beams, one-frame utterances
+  (the fixtures hold empty ones), and the reference's recorded outputs of those fixtures."""
+  res = _capi.UIS_FLAG_RESIDENT
+  for name in ('tiny_d16', 'toy_d2_depth2', 'd20_h24_depth3'):
+    case = golden_util.load_case(name)
+    dec = _capi.Decoder(case['params'])
+    frames, offsets = oracle_lib.pack(case['seqs'])
+    for run in case['runs']:
+      if run['look_ahead'] != 1:
+        continue
+      ref = oracle_lib.decode(case['params'], case['seqs'], run['beam_size'], 1, run['test_iteration'], n_threads=8)
+      cap = max(int(ref['max_clusters'].max()), 4)
+      outs = {}
+      for fl in (res, res | _capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_STEPWISE, 0):
+        out = dec.decode(frames, offsets, run['beam_size'], 1, run['test_iteration'], max_clusters=cap, flags=fl,
+                         want_beam_scores=True)
+        assert out['status'] == 0
+        assert out['stats']['decode_kernel'] == ('k_decode_small' if not fl & _capi.UIS_FLAG_STEPWISE else 'stepwise:k_dense'), (name, fl)
+        for u in range(len(case['seqs'])):
+          assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), (name, fl, u)
+          assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], run['labels'][u]), (name, fl, u)  # the reference's own
+        assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores'])), (name, fl)
+        outs[fl] = out
+      assert outs[res]['stats']['rnn_rows'] == outs[_capi.UIS_FLAG_STEPWISE]['stats']['rnn_rows']
+  # a wide beam (40 of at most 64: 40 x 6 = 240 candidates), many short utterances, a single frame, depth 2
+  from uisrnn_amd import weights
+  rng = np.random.default_rng(17)
+  params = weights.init_params(33, 17, 2, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=5)
+  params['rnn_init_hidden'] = (0.2 * rng.standard_normal((2, 17))).astype(np.float32)
+  cents = rng.standard_normal((3, 33))
+  lens = [1, 7, 19, 30, 4] + [int(n) for n in rng.integers(1, 25, size=70)]
+  seqs = [(cents[np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]] * 0.4 + 0.1 * rng.standard_normal((n, 33))) for n in lens]
+  for beam, tau in ((4, 2), (40, 1)):
+    out, _ = _compare(params, seqs, beam, 1, tau, oracle_lib, flags=res)
+    assert out['stats']['decode_kernel'] == 'k_decode_small'

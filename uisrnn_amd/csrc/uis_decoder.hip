@@ -183,7 +183,7 @@ struct uis_handle {
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
-  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores;
+  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores, utt_nrows;
   size_t dbg_floats = 0;  // what the last decode left in dbg_scores (UIS_FLAG_DEBUG_SCORES)
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
@@ -747,6 +747,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 96 * 8);
   ENSURE(beam_scores_out, (size_t)U * B * 4);
+  ENSURE(utt_nrows, (size_t)U * 2 * 4);
   // the whole decode in one launch with register-resident weights (k_decode_resident)
   const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 256 || m.Hp == 512) &&
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
@@ -758,10 +759,17 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // the launch-per-step path, UIS_FLAG_RESIDENT turns "does not apply" into an error
   const bool resident = resident_ok && !use_graph && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                         !(opts->flags & UIS_FLAG_STEPWISE);
-  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident)
-    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, rnn_depth 1, rnn_hidden_size 256 or 512 (padded), "
-                                     "observation_dim 128, 256 or 512 (padded), beam_size * (max_clusters + 1) <= 256, one "
-                                     "stream, a device whose CU count is a multiple of 32 and no per-step path flag");
+  // ... and for SMALL models (small_model_ok: hidden size up to about 64, any rnn_depth -- the shapes of
+  // the reference's own tests) the whole beam search of an utterance on ONE workgroup, one launch per decode
+  // (k_decode_small); the default where the kernels above do not apply
+  const bool small = !resident_ok && L == 1 && G == 1 && !use_graph && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
+                     select_fast_ok(B, Kmax, S) && small_model_ok(m.Hp, m.Dp, m.depth) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024 &&
+                     !getenv("UIS_NO_SMALL_KERNEL");
+  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small)
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, one stream, beam_size * (max_clusters + 1) <= 256, no "
+                                     "per-step path flag and either a small model (rnn_hidden_size up to about 64, any rnn_depth) "
+                                     "or rnn_depth 1 with rnn_hidden_size 256 or 512 (padded), observation_dim 128, "
+                                     "256 or 512 (padded) and a device whose CU count is a multiple of 32");
   // control words: [0, 16) XCC id per cluster, [16] abort, [32, 32 + 32 ncl) row counters,
   // then 32 ncl barrier counters, then 32 ncl phase words (one 128-byte line per cluster each)
   const size_t ctl_words = (size_t)32 + 3 * UIS_MAX_CLUSTERS * 32;
@@ -980,6 +988,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.a1 = h->a1.as<float>() + (u0 * rows_per_utt + 48 * (size_t)g) * m.Hp;
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
     st.cl_abort = ctl + 16;
+    st.utt_nrows = h->utt_nrows.as<int32_t>() + 2 * u0;
     st.dbg_scores = dbg ? h->dbg_scores.as<float>() + 0 : nullptr;  // (one group: groups would need their own utterance offset)
     if (resident) {
       st.ncl = ncl;
@@ -1108,6 +1117,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RESIDENT_CASE(256, 128)
       UIS_RESIDENT_CASE(256, 512)
 #undef UIS_RESIDENT_CASE
+    } else if (small) {
+      const size_t shmem = small_lds_bytes(m.Dp, B, Kmax, S);
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      decode_kernel = UIS_DK_SMALL;
+      LAUNCH(UIS_K_GRU, k_decode_small, dim3(gp.U), dim3(512), shmem, m, gp.st);
     } else if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
       GraphCache& gc = h->gcache[g];
       const bool same = gc.exec && gc.lds == (size_t)lds.total && memcmp(&gc.st, &gp.st, sizeof(DecodeState)) == 0;
@@ -1315,7 +1329,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};
