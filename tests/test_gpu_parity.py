@@ -42,6 +42,9 @@ def _compare(params, seqs, beam_size, look_ahead, test_iteration, oracle_lib,
     # utterance on one workgroup (k_decode_resident) as well
     variants.append(flags | _capi.UIS_FLAG_OWNER_SELECT)
     variants.append(flags | _capi.UIS_FLAG_REPLICATED_SELECT)
+  elif not flags & _PATH_FLAGS and n_streams in (0, 1):
+    # look_ahead >= 2: one launch (k_decode_big<WIN>) where it applies, and a launch per sub-step
+    variants.append(flags | _capi.UIS_FLAG_STEPWISE)
   for fl in variants:
     # intermediate look-ahead levels hold hypotheses with up to look_ahead - 1 more clusters
     # than any survivor
@@ -126,6 +129,34 @@ def test_look_ahead_wide_beam(oracle_lib):
   out, _ = _compare(params, seqs, 50, 2, 2, oracle_lib, max_clusters=12)
   assert out['stats']['rnn_rows'] < out['stats']['rnn_rows_nodedup']
   _compare(params, seqs[:2], 20, 3, 1, oracle_lib, max_clusters=8)
+
+
+@pytest.mark.parametrize('dim,hidden', [(256, 512), (128, 256), (512, 512)])
+def test_look_ahead_in_one_launch(dim, hidden, oracle_lib):
+  """look_ahead >= 2 with every sub-step of every window in ONE launch (k_decode_big<WIN>: the
+  window kernel's sub-step as the select stage), ragged utterances, against the oracle and the
+  launch-per-sub-step path, bit for bit; more utterances than workgroups take the per-step path."""
+  params = synth.tracker_params(dim, hidden, 1, seed=5)
+  lengths = [23, 9, 30, 1, 14, 2, 27, 18, 5, 21, 16]
+  seqs, _ = synth.make_utterances(5000 + dim, len(lengths), lengths, dim)
+  dec = _capi.Decoder(params)
+  # (max_clusters from the oracle's run: the 512-dim tracker spreads over tens of clusters)
+  out, ref = _compare(params, seqs, 10, 2, 1, oracle_lib, decoder=dec)
+  assert out['stats']['decode_kernel'].startswith('stepwise')  # (_compare's last variant)
+  frames, offsets = oracle_lib.pack(seqs)
+  one = dec.decode(frames, offsets, 10, 2, 1, max_clusters=int(ref['max_clusters'].max()) + 1,
+                   want_beam_scores=True)
+  assert one['stats']['decode_kernel'] == 'k_decode_big<WIN>'
+  _compare(params, seqs[:5], 6, 3, 2, oracle_lib, decoder=dec)
+  _compare(params, seqs[:3], 25, 2, 1, oracle_lib, decoder=dec)
+  if dim == 256:
+    many = [seqs[i % len(seqs)][:8] for i in range(300)]
+    f2, o2 = oracle_lib.pack(many)
+    big = dec.decode(f2, o2, 4, 2, 1, max_clusters=6, want_beam_scores=True)
+    assert big['stats']['decode_kernel'] != 'k_decode_big<WIN>'
+    ref = oracle_lib.decode(params, many[:len(seqs)], 4, 2, 1, n_threads=8)
+    for u in range(len(seqs)):
+      assert np.array_equal(big['labels'][o2[u]:o2[u + 1]], ref['labels'][u])
 
 
 def test_tracker_d256_bit_exact(oracle_lib):
@@ -648,7 +679,7 @@ def test_calculate_score_arrays_on_the_device(oracle_lib):
       paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_OWNER_SELECT,
                _capi.UIS_FLAG_STEPWISE | _capi.UIS_FLAG_GENERIC_SELECT]
     else:
-      paths = [0, _capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_SMALL_TILES]
+      paths = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_SMALL_TILES]
     n_win = (tau * keep + look - 1) // look
     for fl in paths:
       out = dec.decode(frames, offsets, beam, look, tau, max_clusters=kmax,

@@ -738,7 +738,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // CPX mode); one row region per cluster, a multiple of 16 rows
   const int ncl = (h->n_cu >= 32 && h->n_cu % 32 == 0 && h->n_cu / 32 <= UIS_MAX_CLUSTERS) ? h->n_cu / 32 : 0;
   const int nclq = std::max(ncl, 1);
-  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * B + 15) / 16 * 16);
+  // (rows an utterance can emit per step: beam_size, or a level's capacity inside a look-ahead window)
+  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * (L == 1 ? (long)B : (long)NC) + 15) / 16 * 16);
   const long rows_cap = std::max(max_rows + 48L * G, (long)nclq * rx_stride);  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
@@ -765,8 +766,16 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const bool small = !resident_ok && L == 1 && G == 1 && !use_graph && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
                      select_fast_ok(B, Kmax, S) && small_model_ok(m.Hp, m.Dp, m.depth) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024 &&
                      !getenv("UIS_NO_SMALL_KERNEL");
-  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small)
-    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs look_ahead 1, one stream, beam_size * (max_clusters + 1) <= 256, no "
+  // ... and look_ahead >= 2 in one launch (k_decode_big<WIN>: the window kernel's sub-step as the select stage
+  // of the wave-per-row-tile decode; at most one utterance per workgroup)
+  const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 && U <= 32 * ncl &&
+                   ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256))) &&
+                   !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
+                   ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
+                   (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
+                   !getenv("UIS_NO_WINDOW_LAUNCH");
+  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small && !win)
+    return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs (look_ahead 1:) one stream, beam_size * (max_clusters + 1) <= 256, no "
                                      "per-step path flag and either a small model (rnn_hidden_size up to about 64, any rnn_depth) "
                                      "or rnn_depth 1 with rnn_hidden_size 256 or 512 (padded), observation_dim 128, "
                                      "256 or 512 (padded) and a device whose CU count is a multiple of 32");
@@ -990,7 +999,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.cl_abort = ctl + 16;
     st.utt_nrows = h->utt_nrows.as<int32_t>() + 2 * u0;
     st.dbg_scores = dbg ? h->dbg_scores.as<float>() + 0 : nullptr;  // (one group: groups would need their own utterance offset)
-    if (resident) {
+    if (resident || win) {
       st.ncl = ncl;
       st.cl_xcc = ctl;
       st.rx_stride = rx_stride;
@@ -1117,6 +1126,25 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RESIDENT_CASE(256, 128)
       UIS_RESIDENT_CASE(256, 512)
 #undef UIS_RESIDENT_CASE
+    } else if (win) {
+      // h1 into the extra slot, then ONE launch for every sub-step of every window
+      HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
+      const size_t shmem = big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B);
+      decode_kernel = UIS_DK_WINDOW;
+#define UIS_WIN_CASE(HPV, DPV)                                                                                        \
+  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+    void (*kern)(DevModel, DecodeState) = &k_decode_big<HPV, DPV, false, 0, 0, true>;                               \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
+      return rc;                                                                                                     \
+  }
+      UIS_WIN_CASE(512, 256)
+      UIS_WIN_CASE(512, 128)
+      UIS_WIN_CASE(512, 512)
+      UIS_WIN_CASE(256, 256)
+      UIS_WIN_CASE(256, 128)
+#undef UIS_WIN_CASE
     } else if (small) {
       const size_t shmem = small_lds_bytes(m.Dp, B, Kmax, S);
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1210,6 +1238,22 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   }
 #endif
 #if defined(UIS_RESIDENT_TIMING)
+  if (win) {  // even sub-steps (expanding, at look_ahead 2) and odd ones (pruning) apart
+    unsigned long long tc[88];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    static const char* names[8] = {"window", "barA", "gru", "barB", "head1", "barC", "head2", "barD"};
+    for (int wg = 0; wg < 2; ++wg)
+      for (int odd = 0; odd < 2; ++odd) {
+        fprintf(stderr, "[window launch timing] workgroup %3d, %s sub-steps, us per sub-step:", wg ? 248 : 0, odd ? "odd" : "even");
+        double sum = 0.0;
+        for (int k = 0; k < 8; ++k) {
+          const double us = (double)tc[(wg ? 64 : 48) + 8 * odd + k] * 0.01 / ((double)maxT * 0.5);
+          fprintf(stderr, " %s=%.2f", names[k], us);
+          sum += us;
+        }
+        fprintf(stderr, " | total=%.2f\n", sum);
+      }
+  }
   if (resident) {
     unsigned long long tc[88];
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));

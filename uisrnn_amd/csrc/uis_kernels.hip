@@ -2994,404 +2994,6 @@ __global__ __launch_bounds__(512) void k_decode_small(DevModel m, DecodeState st
   (void)U;
 }
 
-// ------------------------------------------------------------ resident decode, many utterances
-//
-// k_decode_resident's stages walk the row tiles in passes of three, every pass split in K over
-// the eight waves and closed by two workgroup barriers (LDS combine, epilogue): right for the
-// three row tiles of 64 utterances, wasteful for the dozens of row tiles of a thousand (the passes
-// of a stage run at ~55 % of their MFMA time: operand fetch, combine and epilogue are exposed in
-// every pass).  k_decode_big is the same launch -- same clusters, same in-launch barriers, same
-// selects from the global beam tables -- with the dense stages turned around: the workgroup's
-// W_hh slice (3 gates x all k-blocks, 96 KB at hidden size 512) and linear_mean1 slice live in
-// LDS, and a WAVE owns a row tile: it walks the full K of its tile (the segment chains of
-// uis_numerics.h combined on the fly, as in the big-tile per-step kernels) with A operands from
-// LDS and B operands (its 16 rows) streamed from L2 one segment ahead, then runs the epilogue on
-// its own accumulators.  No split-K partials, no workgroup barrier inside a stage, eight row
-// tiles in flight per CU.  The two mean-head weight slices share one LDS slot, refilled from L2
-// at the start of their stage.  Used for
-// ordinary decodes with more utterances than workgroups (U > 32 x clusters).
-
-// NA weight streams from `wbase` (LDS or global; stream a at wbase + a * wstride, [k block][lane])
-// against one row tile whose row for this lane starts at byte `boff` of `rsrc` (16 bytes per k
-// block at + kb * 64 + q * 16): total[a] = this lane's 4 features x its row.
-// GS = segments per operand group: the rows of group g + 1 are requested while group g is
-// multiplied (two register sets in turn; everything unrolled, scheduling fenced per segment so
-// that the weight reads of later segments are not hoisted into spills).
-// KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
-// k-block-major staging layout, where a wave's load is one contiguous KiB).
-// The first group arrives preloaded in `bfirst` (rows_first_group); while the LAST group is
-// multiplied the first group of the wave's NEXT row tile (at next_boff, if has_next) is requested
-// into `bfirst` again, so that a tile's dependent start-up (row descriptor -> address -> rows)
-// hides behind its predecessor's chain.
-template <int GB, int KBS>
-__device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&bfirst)[GB]) {
-  const int q = (threadIdx.x & 63) >> 4;
-#pragma unroll
-  for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
-}
-template <int NA, int NKB, int GS, int KBS>
-__device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
-                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA],
-                                               f32x4 (&bfirst)[GS * (NKB / UIS_KSPLIT)], uint32_t next_boff, bool has_next) {
-  constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
-  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT && NGRP % 2 == 0,
-                "k-blocks divide into segments, segments into an even number of groups (the last one uses the second register set)");
-  const int lane = threadIdx.x & 63, q = lane >> 4;
-  f32x4 bsec[GB];  // the second register set; groups alternate bfirst / bsec
-#pragma unroll
-  for (int grp = 0; grp < NGRP; ++grp) {
-    if (grp + 1 < NGRP) {
-      if ((grp + 1) & 1) {
-#pragma unroll
-        for (int k = 0; k < GB; ++k) bsec[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
-      } else {
-#pragma unroll
-        for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
-      }
-    }
-    const f32x4 (&b)[GB] = (grp & 1) ? bsec : bfirst;  // this group's operands
-    if (grp + 1 == NGRP && has_next) {  // (the last group reads bsec) bfirst is free: the next tile's first group
-#pragma unroll
-      for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, next_boff + (uint32_t)(k * KBS + q * 16));
-    }
-#pragma unroll
-    for (int sg = 0; sg < GS; ++sg) {
-      const int sgm = grp * GS + sg;
-      f32x4 acc[NA];
-#pragma unroll
-      for (int a = 0; a < NA; ++a)
-        acc[a] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias[a] + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int kb = 0; kb < PER; ++kb) {
-        f32x4 wa[NA];
-#pragma unroll
-        for (int a = 0; a < NA; ++a) wa[a] = wbase[(size_t)a * wstride + (size_t)(sgm * PER + kb) * 64 + lane];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int a = 0; a < NA; ++a)
-            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[sg * PER + kb][e], acc[a], 0, 0, 0);
-      }
-#pragma unroll
-      for (int a = 0; a < NA; ++a) {
-        if (sgm == 0) total[a] = acc[a];
-        else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) total[a][i] = total[a][i] + acc[a][i];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
-// LDS of k_decode_big: select scratch | W_hh slice | mean-head slot | control words | beam store
-// (table sets + per-slot counts of as many of the rank's utterances as fit in what is left of 160 KB)
-__host__ __device__ inline size_t big_lds_fixed(int Hp, int Dp, int B, int Kmax, int S) {
-  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
-}
-__host__ __device__ inline size_t big_store_stride(int Dp, int B, int Kmax, int S) {
-  return (size_t)((2 * fast_lds_layout(Dp, B, Kmax, S).set_stride + S * 4 + 15) & ~15);
-}
-__host__ __device__ inline int big_store_slots(int Hp, int Dp, int B, int Kmax, int S) {
-  const size_t fixed = big_lds_fixed(Hp, Dp, B, Kmax, S);
-  return fixed >= 160 * 1024 ? 0 : (int)((160 * 1024 - fixed) / big_store_stride(Dp, B, Kmax, S));
-}
-__host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
-  return big_lds_fixed(Hp, Dp, B, Kmax, S) + (size_t)big_store_slots(Hp, Dp, B, Kmax, S) * big_store_stride(Dp, B, Kmax, S);
-}
-
-#include "uis_select_rs.hip"
-
-// WS (wave select): the selects of a rank's utterances run CONCURRENTLY, one wave each, on the
-// single-wave select of uis_select_rs.hip (rs_prep / rs_front<FULL> / rs_back; the wave computes
-// every live cluster's MSE itself) instead of one after the other on the whole workgroup: at 1024
-// utterances a rank owns four, and their 4 x 8 us were a fifth of the step.  LDS of the select part:
-// 1 / (2 sigma^2) | log tables | nws persistent blocks | eight per-wave scratches.
-__host__ __device__ inline size_t big_ws_select_bytes(int Dp, int B, int Kmax, int S, int nws) {
-  const RsLds L = rs_lds_layout(B, Kmax, S);
-  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)nws * L.persist_stride + (size_t)8 * L.scratch_stride;
-}
-__host__ __device__ inline size_t big_ws_lds_bytes(int Hp, int Dp, int B, int Kmax, int S, int nws) {
-  return ((big_ws_select_bytes(Dp, B, Kmax, S, nws) + 255) & ~(size_t)255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
-}
-
-template <int HP, int DP, bool WS = false, int CB = 0, int CK = 0>
-__global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
-  m.Hp = HP; m.Dp = DP; m.G = 3 * HP;  // (what the template arguments say)
-  if (CB) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }  // (see k_decode_resident)
-  constexpr int NKB = HP / 16;
-  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
-  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
-  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32, "hidden size 256 / 512, observation_dim 128 / 256 / 512 (padded)");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
-  const int ncl = st.ncl;
-  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
-  const int U = st.U, S = st.S;
-  const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
-  // WS: utterances per rank (wave k owns the rank's k-th utterance)
-  const int nws = WS ? (((U + ncl - 1) / ncl) + 31) / 32 : 0;
-  const RsLds RL = rs_lds_layout(st.B, st.Kmax, S);
-  const size_t select_bytes = WS ? big_ws_select_bytes(DP, st.B, st.Kmax, S, nws) : (size_t)L.total;
-  f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((select_bytes + 255) & ~(size_t)255));  // [3][NKB][64]
-  f32x4* s_wm = s_whh + 3 * NKB * 64;                                          // [NKB][64] linear_mean1's slice, then linear_mean2's
-  int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                         // [0] abort [1] steps [2] arrived
-  // the beams of this rank's first `nstore` utterances stay in LDS from step to step (the rest, if
-  // the rank has more, goes through the global tables every step)
-  unsigned char* s_store = reinterpret_cast<unsigned char*>(s_ctl + 16);
-  const int store_stride = (int)big_store_stride(m.Dp, st.B, st.Kmax, S);
-  const int nstore = WS ? 0 : big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
-  // WS: the select part of the LDS
-  float* ws_swgt = reinterpret_cast<float*>(smem_raw);
-  double* ws_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
-  double* ws_lden = ws_lblk + UIS_RS_LOGTAB;
-  unsigned char* ws_pers = reinterpret_cast<unsigned char*>(ws_lden + UIS_RS_LOGTAB);
-  unsigned char* ws_scr = ws_pers + (size_t)nws * RL.persist_stride;
-  const int wu = __builtin_amdgcn_readfirstlane(w);
-  const int u_w = cluster + ncl * (rank + 32 * wu);
-  const bool has_u = WS && wu < nws && u_w < U;
-  unsigned char* const pers_w = ws_pers + (size_t)(has_u ? wu : 0) * RL.persist_stride;
-  unsigned char* const scr_w = ws_scr + (size_t)wu * RL.scratch_stride;
-  long off0_w = 0, N_w = 0, fpos_w = 0;
-  if (has_u) { off0_w = (long)st.off[u_w]; N_w = (long)st.off[u_w + 1] - off0_w; }
-  const long T_w = (long)st.tau * N_w;
-
-  uint32_t xcc = 0;
-  if (t == 0) {
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 0xfu;
-    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
-  }
-  if (WS) {
-    for (int i = t; i < DP; i += 512) ws_swgt[i] = m.wgt[i];
-    for (int i = t; i < UIS_RS_LOGTAB; i += 512) { ws_lblk[i] = st.logblk[i]; ws_lden[i] = st.logden[i]; }
-    // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
-    if (has_u)
-      for (int i = lane; i < RL.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = 0;
-  }
-  __syncthreads();
-  if (WS && has_u && lane == 0) {
-    int* hdr = reinterpret_cast<int*>(pers_w + RL.off_hdr);
-    hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
-    reinterpret_cast<int*>(pers_w + RL.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
-  }
-  {  // decode steps of this cluster = the longest of its utterances
-    int myT = 0;
-    for (int i = t; cluster + ncl * i < U; i += 512) {
-      const int u = cluster + ncl * i;
-      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
-      myT = T > myT ? (int)T : myT;
-    }
-    if (myT > 0) atomicMax(&s_ctl[1], myT);
-  }
-  const int ft1 = rank / SH1, tpar1 = rank % SH1;  // ranks sharing a feature tile take alternate row tiles
-  const int ft2 = rank / SH2, tpar2 = rank % SH2;
-  for (int e = t; e < NKB * 64; e += 512) {
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-      s_whh[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[0])[(size_t)(g * NFT1 + ft1) * NKB * 64 + e];
-  }
-  __syncthreads();
-  const int nsteps = s_ctl[1];
-  const f32x4* w1g = reinterpret_cast<const f32x4*>(m.w1) + (size_t)ft1 * NKB * 64;
-  const f32x4* w2g = reinterpret_cast<const f32x4*>(m.w2) + (size_t)ft2 * NKB * 64;
-
-  const __amdgpu_buffer_rsrc_t rs_rows =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_hid =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a1 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_mean =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_hst =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
-  // (hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major: rs_hst, rs_a1)
-  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
-  const int rbase = cluster * st.rx_stride;   // this cluster's rows of `rows`
-  const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
-  RowSink sink{st.rows + rbase, nullptr};
-  uint32_t bar = 0;
-  const float* bias_hh[3] = {m.bhh[0] + ft1 * 16, m.bhh[0] + HP + ft1 * 16, m.bhh[0] + 2 * HP + ft1 * 16};
-  const float* bias_1[1] = {m.b1 + ft1 * 16};
-  const float* bias_2[1] = {m.b2 + ft2 * 16};
-
-#if defined(UIS_RESIDENT_TIMING)
-  unsigned long long rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long rt_prev = wall_clock64();
-#endif
-  for (int s = 0; s < nsteps; ++s) {
-    const int par = s & 1;
-    sink.count = st.rx_nrows + cluster * 32 + par;
-    if constexpr (WS) {
-      // every utterance of this rank at once, one wave each: candidate grid, MSEs, scores, prune,
-      // winners; the rows go to the cluster's list (their order is whatever the reservations make
-      // it: nothing depends on it); the table update runs inside the barrier
-      const bool act_w = has_u && (long)s < T_w;
-      const long frame_w = off0_w + fpos_w;
-      RsWin win;
-      win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
-      if (act_w) {
-        const RsDims dm{st.B, st.Kmax, S, m.D};
-        const RsPrep<3> prep = rs_prep<true, 3>(m, st, RL, dm, s, pers_w, scr_w, ws_lblk, ws_lden, []() {});
-        win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s, frame_w, pers_w, scr_w, rs_mean /* unused: FULL */, 0u, prep, nullptr, ws_swgt);
-        int row_base = 0;
-        if (lane == 0 && win.nlead > 0) row_base = atomicAdd(sink.count, win.nlead);
-        row_base = __shfl(row_base, 0, 64);
-        if (win.is_lead()) {
-          RnnRow rr; rr.utt = u_w; rr.src = win.src(); rr.dst = win.dst(); rr.nprev = win.nprev(); rr.frame = frame_w; rr.pad = 0;
-          sink.rows[row_base + win.ord()] = rr;
-        }
-      }
-      RSTAMP(0);
-      xcd_arrive(st, cluster, s_ctl);
-      if (act_w) {
-        rs_back<3>(m, st, RL, RsDims{st.B, st.Kmax, S, m.D}, u_w, s, off0_w, pers_w, true, win, []() {});
-        fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
-      }
-      if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
-    } else {
-      for (int i = rank, k = 0; cluster + ncl * i < U; i += 32, ++k) {
-        const int u = cluster + ncl * i;
-        if (k < nstore) {
-          unsigned char* blk = s_store + (size_t)k * store_stride;
-          select_fast_body<512, true, true, DP, 7>(m, st, par, u, smem_raw, sink, s, (long)st.off[u], (long)st.off[u + 1], SelectNoHook(), 0,
-                                                   blk - L.off_slot, reinterpret_cast<int*>(blk + 2 * L.set_stride));
-        } else {
-          select_fast_body<512, true, false, DP>(m, st, par, u, smem_raw, sink);
-        }
-        __syncthreads();
-      }
-      RSTAMP(0);
-      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    }
-    RSTAMP(1);
-    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
-    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
-      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
-    const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (rank == 0 && t == 0)
-      __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int nrt = (nrows + 15) >> 4;
-
-    // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot; wave w of this rank takes the
-    // row tiles tpar1 + SH1 * (w, w + 8, ...); the next tile's descriptor and first rows are
-    // requested while the current tile's chain runs
-    {
-      constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
-      int tile = tpar1 + SH1 * w;
-      RowHead rh{0, 0, 0, 0};
-      long frame = 0;
-      uint32_t hoff = h1_off;
-      f32x4 bfirst[GBG];
-      auto fetch_head = [&](int tl, RowHead& h_, long& f_, uint32_t& o_) {
-        const int row = 16 * tl + (lane & 15);
-        const int use = rbase + (row < nrows ? row : 16 * tl);  // (a tile's first row always exists)
-        h_ = load_row_head(rs_rows, use);
-        f_ = load_row_frame(rs_rows, use);
-        o_ = h_.src >= 0 ? (uint32_t)((((size_t)h_.utt * S + h_.src) * HP) * 4) : h1_off;
-      };
-      if (tile < nrt) {
-        fetch_head(tile, rh, frame, hoff);
-        rows_first_group<GBG, 64>(rs_hid, hoff, bfirst);
-      }
-      while (tile < nrt) {
-        const int next = tile + SH1 * 8;
-        const bool has_next = next < nrt;
-        RowHead rh_n{0, 0, 0, 0};
-        long frame_n = 0;
-        uint32_t hoff_n = h1_off;
-        if (has_next) fetch_head(next, rh_n, frame_n, hoff_n);
-        const bool valid = 16 * tile + (lane & 15) < nrows;
-        const int j4 = ft1 * 16 + 4 * q;
-        const float* gi = st.gi0 + (size_t)frame * (3 * HP);
-        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
-        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
-        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
-        const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
-        f32x4 gh[3];
-        fullk_rows_sc1<3, NKB, GSG, 64>(s_whh, NKB * 64, bias_hh, rs_hid, hoff, gh, bfirst, hoff_n, has_next);
-        if (valid) {
-          f32x4 out;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
-          rs_buf_store_f32x4(rs_hid, (uint32_t)(((rh.utt * S + rh.dst) * HP + j4) * 4), out);
-          // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
-          // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
-          // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
-          rs_buf_store_f32x4(rs_hst, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, out);
-        }
-        tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
-      }
-    }
-    RSTAMP(2);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    RSTAMP(3);
-
-    // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice
-    // takes the LDS slot first (32 KB from L2: one round trip per stage)
-    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];
-    __syncthreads();
-    constexpr int GBH = 4 * (NKB / UIS_KSPLIT);
-    auto stage_off = [&](int tl) { return (uint32_t)((((tile0 + tl) * NFT1) * 256 + (lane & 15) * 16) * 4); };
-    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
-      const int row = 16 * tile + (lane & 15);
-      const bool valid = row < nrows;
-      f32x4 v[1], bfirst1[GBH];
-      rows_first_group<GBH, 1024>(rs_hst, stage_off(tile), bfirst1);
-      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_hst, stage_off(tile), v, bfirst1, 0u, false);
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
-        rs_buf_store_f32x4(rs_a1, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, v[0]);
-      }
-    }
-    RSTAMP(4);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    RSTAMP(5);
-
-    // ---- linear_mean2 + running mean -> dst slot (every wave is past the barrier: the slot is free)
-    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w2g[e];
-    __syncthreads();
-    for (int tile = tpar2 + SH2 * w; tile < nrt; tile += SH2 * 8) {
-      const int row = 16 * tile + (lane & 15);
-      const bool valid = row < nrows;
-      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
-      const int f4 = ft2 * 16 + 4 * q;
-      f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)(((rh.utt * S + rh.src) * DP + f4) * 4));
-      f32x4 v[1], bfirst2[GBH];
-      rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
-      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
-          if (f4 + i >= m.D) v[0][i] = 0.0f;
-        }
-        rs_buf_store_f32x4(rs_mean, (uint32_t)(((rh.utt * S + rh.dst) * DP + f4) * 4), v[0]);
-      }
-    }
-    RSTAMP(6);
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    RSTAMP(7);
-  }
-#if defined(UIS_RESIDENT_TIMING)
-  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
-    for (int k = 0; k < 8; ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
-#endif
-  if (WS && has_u && lane == 0) {  // this utterance's statistics
-    const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_stats);
-    atomicAdd(&st.counters[0], acc[0]);
-    atomicAdd(&st.counters[1], acc[1]);
-    atomicAdd(&st.counters[2], acc[2]);
-    atomicMax(&st.counters[3], acc[3]);
-  }
-}
-
 // ------------------------------------------------------------------ window
 //
 // look_ahead >= 2 (uisrnn.py:469-477,529-559): a window of Lw <= L frames is scored jointly.
@@ -3508,20 +3110,24 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
 #define WSTAMP(k) do {} while (0)
 #endif
 
-// NT threads per utterance: 256 for narrow beams, more when a level holds hundreds of hypotheses
-// (every phase is a scan or a count over the level's candidates)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int par) {
+// The body: one sub-step of utterance u's current window by the NT threads of the calling workgroup
+// (every thread calls it; returns are workgroup-uniform; every phase is a scan or a count over the
+// level's candidates).  `wlds` = the dynamic LDS the work arrays may use (window_lds_bytes: the
+// launch's choice), `sink` = where the sub-step's rnn rows go (the step's list and its counter).
+// INL: called from inside a one-launch decode (k_decode_big<WIN>) -- the cluster means were written
+// by other workgroups of this XCD inside the same launch, so they are read with sc1 loads (past this
+// CU's L1); everything else the body reads is immutable or was written by this very workgroup.
+template <int NT, bool INL = false>
+__device__ __forceinline__ void window_body(const DevModel& m, const DecodeState& st, int u, unsigned char* wlds, RowSink sink) {
   constexpr int NW = NT / 64;
   __shared__ int lds4[2 * NW];  // (NW for the scans, 2 NW for the two-word reductions of the prune)
   __shared__ int lds_misc[8];  // [0] nlive [1] nfinite [2..4] the prune's digit search
   __shared__ int radix_hist[256];
   __shared__ double s_logblk[UIS_WINDOW_LOGTAB];  // log(block count) for the small counts (larger ones: the global table)
-  const int u = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int B = st.B, Kmax = st.Kmax, S = st.S, L = st.L, NC = st.NC;
   const int step = st.utt_step[u];
   const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
-  if (u == 0 && tid == 0) st.nrows[par ^ 1] = 0;
   const long N = off1 - off0;
   const long T = (long)st.tau * N;
   if (step >= T) return;
@@ -3544,7 +3150,6 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
 
   unsigned char* scr = st.scratch + (size_t)u * st.scratch_stride;
   const WindowScratch W = window_scratch_layout(S, NC, Kmax, B);
-  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
   unsigned char* hot = window_lds_bytes(W) ? wlds : scr;  // same choice as the host's launch
   unsigned char* warm = window_lds_bytes(W) == W.total ? wlds : scr;
   int* live = reinterpret_cast<int*>(hot + W.live);
@@ -3589,6 +3194,11 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   // ---- weighted MSE of the frame against every live cluster state (as k_select, phase A)
   const float* pmean = st.pool_mean + (size_t)u * S * m.Dp;
   const float* xrow = st.x + (size_t)frame * m.Dp;
+  const __amdgpu_buffer_rsrc_t rs_pmean = __builtin_amdgcn_make_buffer_rsrc((void*)pmean, (short)0, 0x7fffffff, 0x00020000);
+  auto load_mean4 = [&](int slot, int d) -> f32x4 {  // four consecutive floats of the mean in `slot`
+    if (INL) return load_sc1(rs_pmean, (uint32_t)(((size_t)slot * m.Dp + d) * 4));
+    return *reinterpret_cast<const f32x4*>(pmean + (size_t)slot * m.Dp + d);
+  };
   {
     const int grp = tid >> 4, p = tid & 15;
     if (m.Dp <= 256) {
@@ -3613,11 +3223,10 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
         }
 #pragma unroll
         for (int h2 = 0; h2 < 4; ++h2) {
-          const float* mean = pmean + (size_t)sl[h2] * m.Dp;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
-            mv[h2][k] = d < m.Dp ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            mv[h2][k] = d < m.Dp ? load_mean4(sl[h2], d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
         }
 #pragma unroll
@@ -3634,7 +3243,6 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
         const int i = i0 + grp;
         const bool act = i < nlive;
         const int sl = livelist[act ? i : 0];
-        const float* mean = pmean + (size_t)sl * m.Dp;
         float A[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         float first_sq = 0.0f;
         for (int q = 0; q < m.Dp; q += 256) {
@@ -3643,7 +3251,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
             const bool in_ = d < m.Dp;
-            mv[k] = in_ ? *reinterpret_cast<const f32x4*>(mean + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            mv[k] = in_ ? load_mean4(sl, d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             xv[k] = in_ ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             wv[k] = in_ ? *reinterpret_cast<const f32x4*>(m.wgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
@@ -3852,7 +3460,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
                                [&](int r, int pre) { ordv[r] = pre; }, lds4);
   // this utterance's rows of the step's row list: ONE reservation (an atomic per row before; the order
   // of the utterances' blocks in the list is whatever the reservations make it: nothing depends on it)
-  if (tid == 0) { lds_misc[5] = nlead > 0 ? atomicAdd(&st.nrows[par], nlead) : 0; lds_misc[6] = 0; }
+  if (tid == 0) { lds_misc[5] = nlead > 0 ? atomicAdd(sink.count, nlead) : 0; lds_misc[6] = 0; }
   block_scan<NT>(S, [&](int sl) { return live[sl] ? 0 : 1; },
              [&](int sl, int pre) { if (!live[sl] && pre < nlead) freelist[pre] = sl; }, lds4);
   for (int r = tid; r < keep; r += NT) if (leadv[r] == r) dstv[r] = freelist[ordv[r]];
@@ -3909,7 +3517,7 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
       st.pool_cnt[(size_t)u * S + dstv[r]] = nprev + 1;
       const int pos = row_base + ordv[r];
       RnnRow rr; rr.utt = u; rr.src = src < S ? src : -1; rr.dst = dstv[r]; rr.nprev = nprev; rr.frame = frame; rr.pad = 0;
-      st.rows[pos] = rr;
+      sink.rows[pos] = rr;
     }
   }
   WSTAMP(6);
@@ -3929,6 +3537,14 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
     atomicAdd(&st.counters[1], (unsigned long long)keep);
     atomicAdd(&st.counters[2], (unsigned long long)C);
   }
+}
+
+// NT threads per utterance: 256 for narrow beams, more when a level holds hundreds of hypotheses
+template <int NT>
+__global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.nrows[par ^ 1] = 0;
+  window_body<NT, false>(m, st, (int)blockIdx.x, wlds, RowSink{st.rows, st.nrows + par});
 }
 
 // look_ahead >= 2: trace[-N:] from the per-window back-pointers
@@ -3961,6 +3577,435 @@ __global__ void k_backtrace_window(DecodeState st, int32_t* __restrict__ labels,
     }
     r = (int)rec[0];
     if (r >= st.B) r = st.B - 1;  // records of windows that never ran (overflowed utterance) are stale
+  }
+}
+
+// ------------------------------------------------------------ resident decode, many utterances
+//
+// k_decode_resident's stages walk the row tiles in passes of three, every pass split in K over
+// the eight waves and closed by two workgroup barriers (LDS combine, epilogue): right for the
+// three row tiles of 64 utterances, wasteful for the dozens of row tiles of a thousand (the passes
+// of a stage run at ~55 % of their MFMA time: operand fetch, combine and epilogue are exposed in
+// every pass).  k_decode_big is the same launch -- same clusters, same in-launch barriers, same
+// selects from the global beam tables -- with the dense stages turned around: the workgroup's
+// W_hh slice (3 gates x all k-blocks, 96 KB at hidden size 512) and linear_mean1 slice live in
+// LDS, and a WAVE owns a row tile: it walks the full K of its tile (the segment chains of
+// uis_numerics.h combined on the fly, as in the big-tile per-step kernels) with A operands from
+// LDS and B operands (its 16 rows) streamed from L2 one segment ahead, then runs the epilogue on
+// its own accumulators.  No split-K partials, no workgroup barrier inside a stage, eight row
+// tiles in flight per CU.  The two mean-head weight slices share one LDS slot, refilled from L2
+// at the start of their stage.  Used for
+// ordinary decodes with more utterances than workgroups (U > 32 x clusters).
+
+// NA weight streams from `wbase` (LDS or global; stream a at wbase + a * wstride, [k block][lane])
+// against one row tile whose row for this lane starts at byte `boff` of `rsrc` (16 bytes per k
+// block at + kb * 64 + q * 16): total[a] = this lane's 4 features x its row.
+// GS = segments per operand group: the rows of group g + 1 are requested while group g is
+// multiplied (two register sets in turn; everything unrolled, scheduling fenced per segment so
+// that the weight reads of later segments are not hoisted into spills).
+// KBS = bytes between consecutive k-blocks of this lane's row (64: a plain row; 1024: the
+// k-block-major staging layout, where a wave's load is one contiguous KiB).
+// The first group arrives preloaded in `bfirst` (rows_first_group); while the LAST group is
+// multiplied the first group of the wave's NEXT row tile (at next_boff, if has_next) is requested
+// into `bfirst` again, so that a tile's dependent start-up (row descriptor -> address -> rows)
+// hides behind its predecessor's chain.
+template <int GB, int KBS>
+__device__ __forceinline__ void rows_first_group(__amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&bfirst)[GB]) {
+  const int q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(k * KBS + q * 16));
+}
+template <int NA, int NKB, int GS, int KBS>
+__device__ __forceinline__ void fullk_rows_sc1(const f32x4* wbase, int wstride, const float* const (&bias)[NA],
+                                               __amdgpu_buffer_rsrc_t rsrc, uint32_t boff, f32x4 (&total)[NA],
+                                               f32x4 (&bfirst)[GS * (NKB / UIS_KSPLIT)], uint32_t next_boff, bool has_next) {
+  constexpr int PER = NKB / UIS_KSPLIT, NGRP = UIS_KSPLIT / GS, GB = GS * PER;
+  static_assert(PER * UIS_KSPLIT == NKB && NGRP * GS == UIS_KSPLIT && NGRP % 2 == 0,
+                "k-blocks divide into segments, segments into an even number of groups (the last one uses the second register set)");
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  f32x4 bsec[GB];  // the second register set; groups alternate bfirst / bsec
+#pragma unroll
+  for (int grp = 0; grp < NGRP; ++grp) {
+    if (grp + 1 < NGRP) {
+      if ((grp + 1) & 1) {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) bsec[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+      } else {
+#pragma unroll
+        for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, boff + (uint32_t)(((grp + 1) * GB + k) * KBS + q * 16));
+      }
+    }
+    const f32x4 (&b)[GB] = (grp & 1) ? bsec : bfirst;  // this group's operands
+    if (grp + 1 == NGRP && has_next) {  // (the last group reads bsec) bfirst is free: the next tile's first group
+#pragma unroll
+      for (int k = 0; k < GB; ++k) bfirst[k] = load_sc1(rsrc, next_boff + (uint32_t)(k * KBS + q * 16));
+    }
+#pragma unroll
+    for (int sg = 0; sg < GS; ++sg) {
+      const int sgm = grp * GS + sg;
+      f32x4 acc[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        acc[a] = sgm == 0 ? *reinterpret_cast<const f32x4*>(bias[a] + 4 * q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kb = 0; kb < PER; ++kb) {
+        f32x4 wa[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) wa[a] = wbase[(size_t)a * wstride + (size_t)(sgm * PER + kb) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[a][e], b[sg * PER + kb][e], acc[a], 0, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        if (sgm == 0) total[a] = acc[a];
+        else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) total[a][i] = total[a][i] + acc[a][i];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// LDS of k_decode_big: select scratch | W_hh slice | mean-head slot | control words | beam store
+// (table sets + per-slot counts of as many of the rank's utterances as fit in what is left of 160 KB)
+__host__ __device__ inline size_t big_lds_fixed(int Hp, int Dp, int B, int Kmax, int S) {
+  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+__host__ __device__ inline size_t big_store_stride(int Dp, int B, int Kmax, int S) {
+  return (size_t)((2 * fast_lds_layout(Dp, B, Kmax, S).set_stride + S * 4 + 15) & ~15);
+}
+__host__ __device__ inline int big_store_slots(int Hp, int Dp, int B, int Kmax, int S) {
+  const size_t fixed = big_lds_fixed(Hp, Dp, B, Kmax, S);
+  return fixed >= 160 * 1024 ? 0 : (int)((160 * 1024 - fixed) / big_store_stride(Dp, B, Kmax, S));
+}
+__host__ __device__ inline size_t big_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+  return big_lds_fixed(Hp, Dp, B, Kmax, S) + (size_t)big_store_slots(Hp, Dp, B, Kmax, S) * big_store_stride(Dp, B, Kmax, S);
+}
+
+#include "uis_select_rs.hip"
+
+// WS (wave select): the selects of a rank's utterances run CONCURRENTLY, one wave each, on the
+// single-wave select of uis_select_rs.hip (rs_prep / rs_front<FULL> / rs_back; the wave computes
+// every live cluster's MSE itself) instead of one after the other on the whole workgroup: at 1024
+// utterances a rank owns four, and their 4 x 8 us were a fifth of the step.  LDS of the select part:
+// 1 / (2 sigma^2) | log tables | nws persistent blocks | eight per-wave scratches.
+__host__ __device__ inline size_t big_ws_select_bytes(int Dp, int B, int Kmax, int S, int nws) {
+  const RsLds L = rs_lds_layout(B, Kmax, S);
+  return (size_t)Dp * 4 + (size_t)2 * UIS_RS_LOGTAB * 8 + (size_t)nws * L.persist_stride + (size_t)8 * L.scratch_stride;
+}
+__host__ __device__ inline size_t big_ws_lds_bytes(int Hp, int Dp, int B, int Kmax, int S, int nws) {
+  return ((big_ws_select_bytes(Dp, B, Kmax, S, nws) + 255) & ~(size_t)255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+
+// WIN (round 4): look_ahead >= 2 in ONE launch.  The select stage is a sub-step of the window kernel
+// (window_body: expand / prune, uisrnn.py:469-477,529-559) run by the workgroup that owns the
+// utterance (rank i owns utterance cluster + ncl i: at most one per workgroup), the dense stages are
+// the ones below -- a sub-step was four launches before.  The window's work arrays and the weight
+// slices take turns in the LDS: the owners refill their W_hh slice behind the window stage (96 KB from
+// L2, ~2 us; the mean-head slices are refilled per stage anyway).
+__host__ __device__ inline size_t big_win_lds_bytes(int Hp, int S, int NC, int Kmax, int B) {
+  const size_t win = (window_lds_bytes(window_scratch_layout(S, NC, Kmax, B)) + 255) & ~(size_t)255;
+  const size_t weights = (size_t)4 * (Hp / 16) * 64 * 16;
+  return (win > weights ? win : weights) + 64;
+}
+
+template <int HP, int DP, bool WS = false, int CB = 0, int CK = 0, bool WIN = false>
+__global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
+  static_assert(!(WIN && WS), "one kind of select stage");
+  m.Hp = HP; m.Dp = DP; m.G = 3 * HP;  // (what the template arguments say)
+  if (CB) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }  // (see k_decode_resident)
+  constexpr int NKB = HP / 16;
+  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
+  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32, "hidden size 256 / 512, observation_dim 128 / 256 / 512 (padded)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int ncl = st.ncl;
+  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
+  const int U = st.U, S = st.S;
+  const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
+  // WS: utterances per rank (wave k owns the rank's k-th utterance)
+  const int nws = WS ? (((U + ncl - 1) / ncl) + 31) / 32 : 0;
+  const RsLds RL = rs_lds_layout(st.B, st.Kmax, S);
+  const size_t select_bytes = WIN ? 0 : WS ? big_ws_select_bytes(DP, st.B, st.Kmax, S, nws) : (size_t)L.total;
+  f32x4* s_whh = reinterpret_cast<f32x4*>(smem_raw + ((select_bytes + 255) & ~(size_t)255));  // [3][NKB][64]
+  f32x4* s_wm = s_whh + 3 * NKB * 64;                                          // [NKB][64] linear_mean1's slice, then linear_mean2's
+  // [0] abort [1] steps [2] arrived (WIN: behind whichever is larger, the window's arrays or the weights)
+  int* s_ctl = WIN ? reinterpret_cast<int*>(smem_raw + big_win_lds_bytes(HP, S, st.NC, st.Kmax, st.B) - 64)
+                   : reinterpret_cast<int*>(s_wm + NKB * 64);
+  // the beams of this rank's first `nstore` utterances stay in LDS from step to step (the rest, if
+  // the rank has more, goes through the global tables every step)
+  unsigned char* s_store = reinterpret_cast<unsigned char*>(s_ctl + 16);
+  const int store_stride = (int)big_store_stride(m.Dp, st.B, st.Kmax, S);
+  const int nstore = (WS || WIN) ? 0 : big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
+  // WIN: this workgroup's utterance, if it owns one
+  const int u_own = cluster + ncl * rank;
+  const bool win_owner = WIN && u_own < U;
+  // WS: the select part of the LDS
+  float* ws_swgt = reinterpret_cast<float*>(smem_raw);
+  double* ws_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
+  double* ws_lden = ws_lblk + UIS_RS_LOGTAB;
+  unsigned char* ws_pers = reinterpret_cast<unsigned char*>(ws_lden + UIS_RS_LOGTAB);
+  unsigned char* ws_scr = ws_pers + (size_t)nws * RL.persist_stride;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int u_w = cluster + ncl * (rank + 32 * wu);
+  const bool has_u = WS && wu < nws && u_w < U;
+  unsigned char* const pers_w = ws_pers + (size_t)(has_u ? wu : 0) * RL.persist_stride;
+  unsigned char* const scr_w = ws_scr + (size_t)wu * RL.scratch_stride;
+  long off0_w = 0, N_w = 0, fpos_w = 0;
+  if (has_u) { off0_w = (long)st.off[u_w]; N_w = (long)st.off[u_w + 1] - off0_w; }
+  const long T_w = (long)st.tau * N_w;
+
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
+  }
+  if (WS) {
+    for (int i = t; i < DP; i += 512) ws_swgt[i] = m.wgt[i];
+    for (int i = t; i < UIS_RS_LOGTAB; i += 512) { ws_lblk[i] = st.logblk[i]; ws_lden[i] = st.logden[i]; }
+    // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
+    if (has_u)
+      for (int i = lane; i < RL.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = 0;
+  }
+  __syncthreads();
+  if (WS && has_u && lane == 0) {
+    int* hdr = reinterpret_cast<int*>(pers_w + RL.off_hdr);
+    hdr[0] = 1; hdr[1] = 1; hdr[2] = 1 << 20;  // one hypothesis, grid stride 1
+    reinterpret_cast<int*>(pers_w + RL.off_hyp)[1] = -1;  // {K 0, last -1, sum 0, score 0}
+  }
+  {  // decode steps of this cluster = the longest of its utterances
+    int myT = 0;
+    for (int i = t; cluster + ncl * i < U; i += 512) {
+      const int u = cluster + ncl * i;
+      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      myT = T > myT ? (int)T : myT;
+    }
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  const int ft1 = rank / SH1, tpar1 = rank % SH1;  // ranks sharing a feature tile take alternate row tiles
+  const int ft2 = rank / SH2, tpar2 = rank % SH2;
+  for (int e = t; e < NKB * 64; e += 512) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      s_whh[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[0])[(size_t)(g * NFT1 + ft1) * NKB * 64 + e];
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+  const f32x4* w1g = reinterpret_cast<const f32x4*>(m.w1) + (size_t)ft1 * NKB * 64;
+  const f32x4* w2g = reinterpret_cast<const f32x4*>(m.w2) + (size_t)ft2 * NKB * 64;
+
+  const __amdgpu_buffer_rsrc_t rs_rows =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hid =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mean =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  // (hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major: rs_hst, rs_a1)
+  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
+  const int rbase = cluster * st.rx_stride;   // this cluster's rows of `rows`
+  const uint32_t h1_off = (uint32_t)((size_t)U * S * HP * 4);  // the extra slot holding h1
+  RowSink sink{st.rows + rbase, nullptr};
+  uint32_t bar = 0;
+  const float* bias_hh[3] = {m.bhh[0] + ft1 * 16, m.bhh[0] + HP + ft1 * 16, m.bhh[0] + 2 * HP + ft1 * 16};
+  const float* bias_1[1] = {m.b1 + ft1 * 16};
+  const float* bias_2[1] = {m.b2 + ft2 * 16};
+
+#if defined(UIS_RESIDENT_TIMING)
+  unsigned long long rt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (WIN: [8 ..) the odd sub-steps)
+  unsigned long long rt_prev = wall_clock64();
+#endif
+  for (int s = 0; s < nsteps; ++s) {
+    const int par = s & 1;
+    sink.count = st.rx_nrows + cluster * 32 + par;
+    if constexpr (WS) {
+      // every utterance of this rank at once, one wave each: candidate grid, MSEs, scores, prune,
+      // winners; the rows go to the cluster's list (their order is whatever the reservations make
+      // it: nothing depends on it); the table update runs inside the barrier
+      const bool act_w = has_u && (long)s < T_w;
+      const long frame_w = off0_w + fpos_w;
+      RsWin win;
+      win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
+      if (act_w) {
+        const RsDims dm{st.B, st.Kmax, S, m.D};
+        const RsPrep<3> prep = rs_prep<true, 3>(m, st, RL, dm, s, pers_w, scr_w, ws_lblk, ws_lden, []() {});
+        win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s, frame_w, pers_w, scr_w, rs_mean /* unused: FULL */, 0u, prep, nullptr, ws_swgt);
+        int row_base = 0;
+        if (lane == 0 && win.nlead > 0) row_base = atomicAdd(sink.count, win.nlead);
+        row_base = __shfl(row_base, 0, 64);
+        if (win.is_lead()) {
+          RnnRow rr; rr.utt = u_w; rr.src = win.src(); rr.dst = win.dst(); rr.nprev = win.nprev(); rr.frame = frame_w; rr.pad = 0;
+          sink.rows[row_base + win.ord()] = rr;
+        }
+      }
+      RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
+      xcd_arrive(st, cluster, s_ctl);
+      if (act_w) {
+        rs_back<3>(m, st, RL, RsDims{st.B, st.Kmax, S, m.D}, u_w, s, off0_w, pers_w, true, win, []() {});
+        fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
+      }
+      if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    } else if constexpr (WIN) {
+      // this sub-step of the owned utterance's window: scores, expand / prune, next level or beam, rows
+      if (win_owner) window_body<512, true>(m, st, u_own, smem_raw, sink);
+      RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+      if (win_owner) {  // the window's arrays sat where the W_hh slice lives
+        for (int e = t; e < NKB * 64; e += 512) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            s_whh[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[0])[(size_t)(g * NFT1 + ft1) * NKB * 64 + e];
+        }
+      }
+      __syncthreads();
+    } else {
+      for (int i = rank, k = 0; cluster + ncl * i < U; i += 32, ++k) {
+        const int u = cluster + ncl * i;
+        if (k < nstore) {
+          unsigned char* blk = s_store + (size_t)k * store_stride;
+          select_fast_body<512, true, true, DP, 7>(m, st, par, u, smem_raw, sink, s, (long)st.off[u], (long)st.off[u + 1], SelectNoHook(), 0,
+                                                   blk - L.off_slot, reinterpret_cast<int*>(blk + 2 * L.set_stride));
+        } else {
+          select_fast_body<512, true, false, DP>(m, st, par, u, smem_raw, sink);
+        }
+        __syncthreads();
+      }
+      RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    }
+    RSTAMP(1 + (WIN ? 8 * (s & 1) : 0));
+    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
+    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+    const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rank == 0 && t == 0)
+      __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nrt = (nrows + 15) >> 4;
+
+    // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot; wave w of this rank takes the
+    // row tiles tpar1 + SH1 * (w, w + 8, ...); the next tile's descriptor and first rows are
+    // requested while the current tile's chain runs
+    {
+      constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
+      int tile = tpar1 + SH1 * w;
+      RowHead rh{0, 0, 0, 0};
+      long frame = 0;
+      uint32_t hoff = h1_off;
+      f32x4 bfirst[GBG];
+      auto fetch_head = [&](int tl, RowHead& h_, long& f_, uint32_t& o_) {
+        const int row = 16 * tl + (lane & 15);
+        const int use = rbase + (row < nrows ? row : 16 * tl);  // (a tile's first row always exists)
+        h_ = load_row_head(rs_rows, use);
+        f_ = load_row_frame(rs_rows, use);
+        o_ = h_.src >= 0 ? (uint32_t)((((size_t)h_.utt * S + h_.src) * HP) * 4) : h1_off;
+      };
+      if (tile < nrt) {
+        fetch_head(tile, rh, frame, hoff);
+        rows_first_group<GBG, 64>(rs_hid, hoff, bfirst);
+      }
+      while (tile < nrt) {
+        const int next = tile + SH1 * 8;
+        const bool has_next = next < nrt;
+        RowHead rh_n{0, 0, 0, 0};
+        long frame_n = 0;
+        uint32_t hoff_n = h1_off;
+        if (has_next) fetch_head(next, rh_n, frame_n, hoff_n);
+        const bool valid = 16 * tile + (lane & 15) < nrows;
+        const int j4 = ft1 * 16 + 4 * q;
+        const float* gi = st.gi0 + (size_t)frame * (3 * HP);
+        const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
+        const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
+        const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
+        const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
+        f32x4 gh[3];
+        fullk_rows_sc1<3, NKB, GSG, 64>(s_whh, NKB * 64, bias_hh, rs_hid, hoff, gh, bfirst, hoff_n, has_next);
+        if (valid) {
+          f32x4 out;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+          rs_buf_store_f32x4(rs_hid, (uint32_t)(((rh.utt * S + rh.dst) * HP + j4) * 4), out);
+          // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
+          // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
+          // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
+          rs_buf_store_f32x4(rs_hst, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, out);
+        }
+        tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
+      }
+    }
+    RSTAMP(2 + (WIN ? 8 * (s & 1) : 0));
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(3 + (WIN ? 8 * (s & 1) : 0));
+
+    // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice
+    // takes the LDS slot first (32 KB from L2: one round trip per stage)
+    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];
+    __syncthreads();
+    constexpr int GBH = 4 * (NKB / UIS_KSPLIT);
+    auto stage_off = [&](int tl) { return (uint32_t)((((tile0 + tl) * NFT1) * 256 + (lane & 15) * 16) * 4); };
+    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      f32x4 v[1], bfirst1[GBH];
+      rows_first_group<GBH, 1024>(rs_hst, stage_off(tile), bfirst1);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_hst, stage_off(tile), v, bfirst1, 0u, false);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
+        rs_buf_store_f32x4(rs_a1, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, v[0]);
+      }
+    }
+    RSTAMP(4 + (WIN ? 8 * (s & 1) : 0));
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(5 + (WIN ? 8 * (s & 1) : 0));
+
+    // ---- linear_mean2 + running mean -> dst slot (every wave is past the barrier: the slot is free)
+    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w2g[e];
+    __syncthreads();
+    for (int tile = tpar2 + SH2 * w; tile < nrt; tile += SH2 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
+      const int f4 = ft2 * 16 + 4 * q;
+      f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)(((rh.utt * S + rh.src) * DP + f4) * 4));
+      f32x4 v[1], bfirst2[GBH];
+      rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
+          if (f4 + i >= m.D) v[0][i] = 0.0f;
+        }
+        rs_buf_store_f32x4(rs_mean, (uint32_t)(((rh.utt * S + rh.dst) * DP + f4) * 4), v[0]);
+      }
+    }
+    RSTAMP(6 + (WIN ? 8 * (s & 1) : 0));
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(7 + (WIN ? 8 * (s & 1) : 0));
+  }
+#if defined(UIS_RESIDENT_TIMING)
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
+    for (int k = 0; k < (WIN ? 16 : 8); ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
+#endif
+  if (WS && has_u && lane == 0) {  // this utterance's statistics
+    const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_stats);
+    atomicAdd(&st.counters[0], acc[0]);
+    atomicAdd(&st.counters[1], acc[1]);
+    atomicAdd(&st.counters[2], acc[2]);
+    atomicMax(&st.counters[3], acc[3]);
   }
 }
 
