@@ -3117,8 +3117,12 @@ __device__ __forceinline__ int block_scan(int n, V val, E emit, int* lds4) {
 // INL: called from inside a one-launch decode (k_decode_big<WIN>) -- the cluster means were written
 // by other workgroups of this XCD inside the same launch, so they are read with sc1 loads (past this
 // CU's L1); everything else the body reads is immutable or was written by this very workgroup.
+// phase: 0 the whole sub-step; 1 only the part that does not read the cluster means (live list,
+// candidate offsets: k_decode_big<WIN> runs it while it waits for the previous sub-step's last
+// barrier), 2 the rest (the LDS between the two calls untouched).
 template <int NT, bool INL = false>
-__device__ __forceinline__ void window_body(const DevModel& m, const DecodeState& st, int u, unsigned char* wlds, RowSink sink) {
+__device__ __forceinline__ void window_body(const DevModel& m, const DecodeState& st, int u, unsigned char* wlds, RowSink sink,
+                                            int phase = 0) {
   constexpr int NW = NT / 64;
   __shared__ int lds4[2 * NW];  // (NW for the scans, 2 NW for the two-word reductions of the prune)
   __shared__ int lds_misc[8];  // [0] nlive [1] nfinite [2..4] the prune's digit search
@@ -3168,26 +3172,32 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
   int* freelist = reinterpret_cast<int*>(warm + W.freelist);
 
   // ---- live cluster states of the input level, candidate offsets
-  for (int sl = tid; sl <= S; sl += NT) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
-  if (tid < UIS_WINDOW_LOGTAB) s_logblk[tid] = st.logblk[tid];  // (the host fills at least UIS_RS_LOGTAB entries)
-  if (tid < 8) lds_misc[tid] = 0;
-  __syncthreads();
-  for (int e = tid; e < n_in * Kmax; e += NT) {
-    const int i = e / Kmax, c = e - i * Kmax;
-    if (c < in.K[i]) live[in.slot[(size_t)i * Kmax + c]] = 1;
+  int C = 0;
+  if (phase != 2) {
+    for (int sl = tid; sl <= S; sl += NT) { if (sl < S) live[sl] = 0; first[sl] = 0x7fffffff; }
+    if (tid < UIS_WINDOW_LOGTAB) s_logblk[tid] = st.logblk[tid];  // (the host fills at least UIS_RS_LOGTAB entries)
+    if (tid < 8) lds_misc[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < n_in * Kmax; e += NT) {
+      const int i = e / Kmax, c = e - i * Kmax;
+      if (c < in.K[i]) live[in.slot[(size_t)i * Kmax + c]] = 1;
+    }
+    C = block_scan<NT>(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
+    if (tid == 0) cbase[n_in] = C;
+    for (int s0 = 0; s0 < S; s0 += NT) {  // (one reservation per wave, not per live slot: the list's order is free)
+      const int sl = s0 + tid;
+      const bool on = sl < S && live[sl] != 0;
+      const unsigned long long m = __ballot(on);
+      int base = 0;
+      if ((tid & 63) == 0 && m) base = atomicAdd(&lds_misc[0], __popcll(m));
+      base = __shfl(base, 0, 64);
+      if (on) livelist[base + wave_below(m)] = sl;
+    }
+    __syncthreads();
+    if (phase == 1) return;
+  } else {
+    C = cbase[n_in];
   }
-  const int C = block_scan<NT>(n_in, [&](int i) { return in.K[i] + 1; }, [&](int i, int pre) { cbase[i] = pre; }, lds4);
-  if (tid == 0) cbase[n_in] = C;
-  for (int s0 = 0; s0 < S; s0 += NT) {  // (one reservation per wave, not per live slot: the list's order is free)
-    const int sl = s0 + tid;
-    const bool on = sl < S && live[sl] != 0;
-    const unsigned long long m = __ballot(on);
-    int base = 0;
-    if ((tid & 63) == 0 && m) base = atomicAdd(&lds_misc[0], __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (on) livelist[base + wave_below(m)] = sl;
-  }
-  __syncthreads();
   const int nlive = lds_misc[0];
   WSTAMP(0);
 
@@ -3858,7 +3868,8 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
     } else if constexpr (WIN) {
       // this sub-step of the owned utterance's window: scores, expand / prune, next level or beam, rows
-      if (win_owner) window_body<512, true>(m, st, u_own, smem_raw, sink);
+      // (its first part ran while this workgroup waited at the previous sub-step's last barrier)
+      if (win_owner) window_body<512, true>(m, st, u_own, smem_raw, sink, s == 0 ? 0 : 2);
       RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
       if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
       if (win_owner) {  // the window's arrays sat where the W_hh slice lives
@@ -3945,13 +3956,12 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       }
     }
     RSTAMP(2 + (WIN ? 8 * (s & 1) : 0));
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    RSTAMP(3 + (WIN ? 8 * (s & 1) : 0));
-
-    // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice
-    // takes the LDS slot first (32 KB from L2: one round trip per stage)
+    // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice takes the LDS slot
+    // (32 KB from L2) between this workgroup's arrival at the barrier and the barrier's completion
+    xcd_arrive(st, cluster, s_ctl);
     for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];
-    __syncthreads();
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(3 + (WIN ? 8 * (s & 1) : 0));
     constexpr int GBH = 4 * (NKB / UIS_KSPLIT);
     auto stage_off = [&](int tl) { return (uint32_t)((((tile0 + tl) * NFT1) * 256 + (lane & 15) * 16) * 4); };
     for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
@@ -3967,12 +3977,12 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       }
     }
     RSTAMP(4 + (WIN ? 8 * (s & 1) : 0));
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
-    RSTAMP(5 + (WIN ? 8 * (s & 1) : 0));
-
-    // ---- linear_mean2 + running mean -> dst slot (every wave is past the barrier: the slot is free)
+    // ---- linear_mean2 + running mean -> dst slot; its slice likewise (every wave of this workgroup
+    // is past linear_mean1 once the arrival's workgroup barrier is: the slot is free)
+    xcd_arrive(st, cluster, s_ctl);
     for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w2g[e];
-    __syncthreads();
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    RSTAMP(5 + (WIN ? 8 * (s & 1) : 0));
     for (int tile = tpar2 + SH2 * w; tile < nrt; tile += SH2 * 8) {
       const int row = 16 * tile + (lane & 15);
       const bool valid = row < nrows;
@@ -3993,7 +4003,16 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       }
     }
     RSTAMP(6 + (WIN ? 8 * (s & 1) : 0));
-    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    if constexpr (WIN) {
+      // the next sub-step's live list and candidate offsets need nothing the other workgroups are still
+      // writing: between the arrival and the barrier's completion (this workgroup's own linear_mean2
+      // is done: the LDS is free; the W_hh slice is reloaded behind the window stage anyway)
+      xcd_arrive(st, cluster, s_ctl);
+      if (win_owner && s + 1 < nsteps) window_body<512, true>(m, st, u_own, smem_raw, sink, 1);
+      if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    } else {
+      if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+    }
     RSTAMP(7 + (WIN ? 8 * (s & 1) : 0));
   }
 #if defined(UIS_RESIDENT_TIMING)
