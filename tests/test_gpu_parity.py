@@ -135,7 +135,7 @@ def test_look_ahead_wide_beam(oracle_lib):
 def test_look_ahead_in_one_launch(dim, hidden, oracle_lib):
   """look_ahead >= 2 with every sub-step of every window in ONE launch (k_decode_big<WIN>: the
   window kernel's sub-step as the select stage), ragged utterances, against the oracle and the
-  launch-per-sub-step path, bit for bit; more utterances than workgroups take the per-step path."""
+  launch-per-sub-step path, bit for bit; also with more utterances than workgroups."""
   params = synth.tracker_params(dim, hidden, 1, seed=5)
   lengths = [23, 9, 30, 1, 14, 2, 27, 18, 5, 21, 16]
   seqs, _ = synth.make_utterances(5000 + dim, len(lengths), lengths, dim)
@@ -153,7 +153,10 @@ def test_look_ahead_in_one_launch(dim, hidden, oracle_lib):
     many = [seqs[i % len(seqs)][:8] for i in range(300)]
     f2, o2 = oracle_lib.pack(many)
     big = dec.decode(f2, o2, 4, 2, 1, max_clusters=6, want_beam_scores=True)
-    assert big['stats']['decode_kernel'] != 'k_decode_big<WIN>'
+    assert big['stats']['decode_kernel'] == 'k_decode_big<WIN>'  # (a workgroup runs its utterances' windows in turn)
+    step = dec.decode(f2, o2, 4, 2, 1, max_clusters=6, want_beam_scores=True, flags=_capi.UIS_FLAG_STEPWISE)
+    assert np.array_equal(big['labels'], step['labels'])
+    assert np.array_equal(_bits(big['beam_scores']), _bits(step['beam_scores']))
     ref = oracle_lib.decode(params, many[:len(seqs)], 4, 2, 1, n_threads=8)
     for u in range(len(seqs)):
       assert np.array_equal(big['labels'][o2[u]:o2[u + 1]], ref['labels'][u])

@@ -27,9 +27,12 @@ def draw(rng):
     dim = int(rng.choice([120, 128, 250, 256, 400, 512]))
     hid = int(rng.choice([250, 256, 500, 512]))
     depth = 1
-    look = 1
+    look = int(rng.choice([1, 1, 1, 2, 2, 3]))   # look_ahead >= 2: k_decode_big<WIN>
     beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select
     n_utt = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 64, 70, 100, 128]))
+    if look > 1:
+      beam = int(rng.integers(1, 13 if look == 2 else 7))
+      n_utt = int(rng.choice([1, 3, 8, 9, 40, 64, 70, 270]))
     max_len = 0  # set below from the oracle's budget
   else:
     dim = int(rng.integers(1, 80))
@@ -41,7 +44,7 @@ def draw(rng):
     max_len = 14 if look == 3 else 30
   tau = int(rng.choice([1, 2, 2, 3]))
   if big:  # keep the oracle (a CPU) at a second or two per case
-    max_len = int(np.clip(12000 // (n_utt * beam * tau), 3, 48))
+    max_len = int(np.clip(12000 // (n_utt * beam * tau * (1 if look == 1 else 6 ** (look - 1))), 3, 48))
   lengths = [int(v) for v in rng.integers(1, max_len + 1, size=n_utt)]
   return dim, hid, depth, beam, look, tau, lengths
 

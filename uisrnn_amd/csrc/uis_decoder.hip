@@ -767,8 +767,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                      select_fast_ok(B, Kmax, S) && small_model_ok(m.Hp, m.Dp, m.depth) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024 &&
                      !getenv("UIS_NO_SMALL_KERNEL");
   // ... and look_ahead >= 2 in one launch (k_decode_big<WIN>: the window kernel's sub-step as the select stage
-  // of the wave-per-row-tile decode; at most one utterance per workgroup)
-  const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 && U <= 32 * ncl &&
+  // of the wave-per-row-tile decode)
+  const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
+                   (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
                    ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256))) &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                    ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&

@@ -3714,7 +3714,7 @@ __host__ __device__ inline size_t big_ws_lds_bytes(int Hp, int Dp, int B, int Km
 
 // WIN (round 4): look_ahead >= 2 in ONE launch.  The select stage is a sub-step of the window kernel
 // (window_body: expand / prune, uisrnn.py:469-477,529-559) run by the workgroup that owns the
-// utterance (rank i owns utterance cluster + ncl i: at most one per workgroup), the dense stages are
+// utterance (rank i owns utterances cluster + ncl (i + 32 k)), the dense stages are
 // the ones below -- a sub-step was four launches before.  The window's work arrays and the weight
 // slices take turns in the LDS: the owners refill their W_hh slice behind the window stage (96 KB from
 // L2, ~2 us; the mean-head slices are refilled per stage anyway).
@@ -3754,8 +3754,11 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   const int store_stride = (int)big_store_stride(m.Dp, st.B, st.Kmax, S);
   const int nstore = (WS || WIN) ? 0 : big_store_slots(HP, m.Dp, st.B, st.Kmax, S);
   // WIN: this workgroup's utterance, if it owns one
+  // WIN: this workgroup's utterances (cluster + ncl (rank + 32 i)); with exactly one -- up to 32 per XCD --
+  // the first part of its next sub-step runs in the shadow of the step's last barrier
   const int u_own = cluster + ncl * rank;
   const bool win_owner = WIN && u_own < U;
+  const bool win_single = win_owner && u_own + 32 * ncl >= U;
   // WS: the select part of the LDS
   float* ws_swgt = reinterpret_cast<float*>(smem_raw);
   double* ws_lblk = reinterpret_cast<double*>(smem_raw + (size_t)DP * 4);
@@ -3869,7 +3872,14 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     } else if constexpr (WIN) {
       // this sub-step of the owned utterance's window: scores, expand / prune, next level or beam, rows
       // (its first part ran while this workgroup waited at the previous sub-step's last barrier)
-      if (win_owner) window_body<512, true>(m, st, u_own, smem_raw, sink, s == 0 ? 0 : 2);
+      if (win_single) {
+        window_body<512, true>(m, st, u_own, smem_raw, sink, s == 0 ? 0 : 2);
+      } else if (win_owner) {
+        for (int u = u_own; u < U; u += 32 * ncl) {
+          window_body<512, true>(m, st, u, smem_raw, sink, 0);
+          __syncthreads();
+        }
+      }
       RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
       if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
       if (win_owner) {  // the window's arrays sat where the W_hh slice lives
@@ -4008,7 +4018,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       // writing: between the arrival and the barrier's completion (this workgroup's own linear_mean2
       // is done: the LDS is free; the W_hh slice is reloaded behind the window stage anyway)
       xcd_arrive(st, cluster, s_ctl);
-      if (win_owner && s + 1 < nsteps) window_body<512, true>(m, st, u_own, smem_raw, sink, 1);
+      if (win_single && s + 1 < nsteps) window_body<512, true>(m, st, u_own, smem_raw, sink, 1);
       if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
     } else {
       if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
