@@ -3236,7 +3236,10 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int d = 4 * (p + 16 * k);
-            mv[h2][k] = d < m.Dp ? load_mean4(sl[h2], d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // (no branch around the load: sixteen of them are in flight per group; a chunk past Dp reads
+            // the slot's first floats instead and is zeroed)
+            const f32x4 got = load_mean4(sl[h2], d < m.Dp ? d : 0);
+            mv[h2][k] = d < m.Dp ? got : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
         }
 #pragma unroll
@@ -3261,7 +3264,8 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
           for (int k = 0; k < 4; ++k) {
             const int d = q + 4 * (p + 16 * k);
             const bool in_ = d < m.Dp;
-            mv[k] = in_ ? load_mean4(sl, d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const f32x4 got = load_mean4(sl, in_ ? d : 0);
+            mv[k] = in_ ? got : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             xv[k] = in_ ? *reinterpret_cast<const f32x4*>(xrow + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             wv[k] = in_ ? *reinterpret_cast<const f32x4*>(m.wgt + d) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
           }
@@ -3438,11 +3442,28 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
       int* wl = ordv;  // (free until the leader bookkeeping below)
       block_scan<NT>(C, [&](int i) { return key[i] <= kstar ? 1 : 0; },
                  [&](int i, int pre) { if (key[i] <= kstar) wl[pre] = i; }, lds4);
-      for (int a = tid; a < keep; a += NT) {
-        const unsigned long long ka = key[wl[a]];
-        int rank = 0;
-        for (int b2 = 0; b2 < keep; ++b2) rank += key[wl[b2]] < ka ? 1 : 0;
-        winv[rank] = wl[a];
+      if (keep <= 64) {
+        // one wave, a winner per lane, the others' keys by lane broadcast (the loop below it was fifty
+        // dependent LDS round trips per winner)
+        if (tid < 64) {
+          const int mine = tid < keep ? wl[tid] : 0;
+          const unsigned long long kl = tid < keep ? key[mine] : ~0ull;
+          const unsigned klo32 = (unsigned)kl, khi32 = (unsigned)(kl >> 32);
+          int rank = 0;
+          for (int b2 = 0; b2 < keep; ++b2) {
+            const unsigned long long kb = ((unsigned long long)__builtin_amdgcn_readlane(khi32, b2) << 32) |
+                                          __builtin_amdgcn_readlane(klo32, b2);
+            rank += kb < kl ? 1 : 0;
+          }
+          if (tid < keep) winv[rank] = mine;
+        }
+      } else {
+        for (int a = tid; a < keep; a += NT) {
+          const unsigned long long ka = key[wl[a]];
+          int rank = 0;
+          for (int b2 = 0; b2 < keep; ++b2) rank += key[wl[b2]] < ka ? 1 : 0;
+          winv[rank] = wl[a];
+        }
       }
     }
   }
