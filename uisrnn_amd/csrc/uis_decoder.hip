@@ -746,7 +746,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // depth 1: k_decode_resident's h' staging buffer
   ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : (size_t)rows_cap * m.Hp * 4);
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
+#if defined(UIS_RESIDENT_TIMING)
+  ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + (96 + 1024) * 8);
+#else
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + 96 * 8);
+#endif
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   ENSURE(utt_nrows, (size_t)U * 2 * 4);
   // the whole decode in one launch with register-resident weights (k_decode_resident)
@@ -1254,6 +1258,23 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
         }
         fprintf(stderr, " | total=%.2f\n", sum);
       }
+    std::vector<unsigned long long> per((size_t)96 + 1024);
+    HIPCHK(hipMemcpy(per.data(), h->counters.as<unsigned long long>(), per.size() * 8, hipMemcpyDeviceToHost));
+    for (int wg = 0; wg < 2; ++wg) {
+      fprintf(stderr, "[window launch timing] workgroup %3d, gru of the even sub-steps, us by wave:", wg ? 248 : 0);
+      for (int w = 0; w < 8; ++w) fprintf(stderr, " %.1f", (double)per[80 + 8 * wg + w] * 0.01 / ((double)maxT * 0.5));
+      fprintf(stderr, "\n");
+    }
+    static const char* what[4] = {"gru", "wait B", "head1", "head2"};
+    for (int k = 0; k < 4; ++k) {
+      fprintf(stderr, "[window launch timing] %s, even sub-steps, us by rank (mean over the clusters):", what[k]);
+      for (int r = 0; r < 32; ++r) {
+        double sum = 0.0;
+        for (int c = 0; c < ncl; ++c) sum += (double)per[(size_t)96 + 256 * k + c + ncl * r];
+        fprintf(stderr, " %.1f", sum / ncl * 0.01 / ((double)maxT * 0.5));
+      }
+      fprintf(stderr, "\n");
+    }
   }
   if (resident) {
     unsigned long long tc[88];

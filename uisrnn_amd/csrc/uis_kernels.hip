@@ -3858,6 +3858,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (WIN: [8 ..) the odd sub-steps)
+  unsigned long long wv_acc = 0;
   unsigned long long rt_prev = wall_clock64();
 #endif
   for (int s = 0; s < nsteps; ++s) {
@@ -3893,12 +3894,11 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     } else if constexpr (WIN) {
       // this sub-step of the owned utterance's window: scores, expand / prune, next level or beam, rows
       // (its first part ran while this workgroup waited at the previous sub-step's last barrier)
-      if (win_single) {
-        window_body<512, true>(m, st, u_own, smem_raw, sink, s == 0 ? 0 : 2);
-      } else if (win_owner) {
+      // (ONE call site for the whole body: inlined twice it doubled the kernel and spilled into the dense loops)
+      if (win_owner) {
         for (int u = u_own; u < U; u += 32 * ncl) {
-          window_body<512, true>(m, st, u, smem_raw, sink, 0);
-          __syncthreads();
+          window_body<512, true>(m, st, u, smem_raw, sink, win_single && s > 0 ? 2 : 0);
+          if (!win_single) __syncthreads();
         }
       }
       RSTAMP(0 + (WIN ? 8 * (s & 1) : 0));
@@ -3934,6 +3934,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     if (rank == 0 && t == 0)
       __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int nrt = (nrows + 15) >> 4;
+#if defined(UIS_RESIDENT_TIMING)
+    const unsigned long long wv_t0 = wall_clock64();
+#endif
 
     // ---- GRU: h' = gru(gi0[frame], W_hh h_src + b_hh) -> dst slot; wave w of this rank takes the
     // row tiles tpar1 + SH1 * (w, w + 8, ...); the next tile's descriptor and first rows are
@@ -3986,6 +3989,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
         tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
       }
     }
+#if defined(UIS_RESIDENT_TIMING)
+    if (WIN && !(s & 1)) wv_acc += wall_clock64() - wv_t0;  // this wave's own GRU time (even sub-steps)
+#endif
     RSTAMP(2 + (WIN ? 8 * (s & 1) : 0));
     // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice takes the LDS slot
     // (32 KB from L2) between this workgroup's arrival at the barrier and the barrier's completion
@@ -4049,6 +4055,13 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 #if defined(UIS_RESIDENT_TIMING)
   if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 248))
     for (int k = 0; k < (WIN ? 16 : 8); ++k) st.counters[(blockIdx.x == 0 ? 48 : 64) + k] = rt_acc[k];
+  if (WIN && t == 0) {  // every workgroup's GRU time and wait behind it (even sub-steps), and the same for the mean heads
+    st.counters[96 + blockIdx.x] = rt_acc[2];
+    st.counters[96 + 256 + blockIdx.x] = rt_acc[3];
+    st.counters[96 + 512 + blockIdx.x] = rt_acc[4];
+    st.counters[96 + 768 + blockIdx.x] = rt_acc[6];
+  }
+  if (WIN && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 248)) st.counters[80 + (blockIdx.x ? 8 : 0) + w] = wv_acc;
 #endif
   if (WS && has_u && lane == 0) {  // this utterance's statistics
     const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_stats);
