@@ -121,7 +121,8 @@ def committed_traffic(kernel, avg_launch_us=None):
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')))
   for path in reversed(files):
     try:
-      entry = json.load(open(path))['kernels'][base]
+      kernels = json.load(open(path))['kernels']
+      entry = kernels[kernel] if kernel in kernels else kernels[base]  # (an instantiation's own record first)
       out = {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
              'source': os.path.relpath(path, ROOT)}
       then = entry.get('avg_launch_us')
