@@ -99,7 +99,10 @@ typedef struct uis_decode_opts {
                                     applies: look_ahead 1, rnn_depth 1, rnn_hidden_size 256 or 512
                                     and observation_dim 128, 256 or 512 (after padding to 16),
                                     beam_size * (max_clusters + 1) <= 256, one stream, a device
-                                    whose CU count is a multiple of 32                          */
+                                    whose CU count is a multiple of 32; small models (hidden size up
+                                    to about 64, any rnn_depth) with one workgroup per utterance;
+                                    look_ahead >= 2 at rnn_depth 1 and those hidden sizes with the
+                                    window's sub-step as the select stage (UIS_DK_WINDOW)        */
 #define UIS_FLAG_STEPWISE   0x80u /* keep the launch-per-step path (four kernels per decode
                                     step) even where the one-launch decode applies (A/B switch;
                                     results are bit-identical either way)                     */
