@@ -162,6 +162,41 @@ def test_look_ahead_in_one_launch(dim, hidden, oracle_lib):
       assert np.array_equal(big['labels'][o2[u]:o2[u + 1]], ref['labels'][u])
 
 
+@pytest.mark.parametrize('dim,hidden', [(250, 200), (100, 400), (40, 500), (512, 130), (64, 256)])
+def test_in_between_sizes_take_the_one_launch_kernels(dim, hidden, oracle_lib):
+  """rnn_depth 1, hidden size 129 .. 256 / 385 .. 512, observation dim up to 256 / 385 .. 512: the
+  library pads the model up to the cluster kernels' shapes (256 / 512 x 128 / 256 / 512) -- the
+  canonical K-segment length is the same there, so the oracle (which pads to 16) is matched bit for
+  bit -- and the decode is one launch, look_ahead 1 and 2."""
+  from uisrnn_amd import weights
+  params = weights.init_params(dim, hidden, 1, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=dim + hidden)
+  params['rnn_init_hidden'] = (0.2 * np.random.default_rng(7).standard_normal((1, hidden))).astype(np.float32)
+  rng = np.random.default_rng(dim * 1000 + hidden)
+  cents = rng.standard_normal((3, dim))
+  seqs = []
+  for n in (23, 7, 31, 1, 16, 12, 20, 9, 28):
+    ids = np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]
+    seqs.append((cents[ids] * 0.4 + 0.1 * rng.standard_normal((n, dim))).astype(np.float64))
+  dec = _capi.Decoder(params)
+  _, ref = _compare(params, seqs, 8, 1, 2, oracle_lib, decoder=dec)
+  frames, offsets = oracle_lib.pack(seqs)
+  cap = int(ref['max_clusters'].max()) + 1
+  out = dec.decode(frames, offsets, 8, 1, 2, max_clusters=cap)
+  assert out['status'] == 0
+  if 8 * (cap + 1) <= 256:  # (the select's LDS budget; an untrained model can spread over many clusters)
+    assert out['stats']['decode_kernel'].startswith('k_decode_r')
+  _, ref = _compare(params, seqs[:4], 5, 2, 1, oracle_lib, decoder=dec)
+  f4, o4 = oracle_lib.pack(seqs[:4])
+  out = dec.decode(f4, o4, 5, 2, 1, max_clusters=int(ref['max_clusters'].max()) + 2)
+  assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_big<WIN>'
+  # CoreRNN.forward on the padded model
+  x = rng.standard_normal(dim).astype(np.float32)
+  h0 = rng.standard_normal((1, hidden)).astype(np.float32)
+  mean, hout = dec.rnn_step(x, h0)
+  mean_o, hout_o = oracle_lib.rnn_step(params, x, h0)
+  assert np.array_equal(_bits(mean), _bits(mean_o)) and np.array_equal(_bits(hout), _bits(hout_o))
+
+
 def test_tracker_d256_bit_exact(oracle_lib):
   params = synth.tracker_params(256, 512, 1, seed=0)
   seqs, _ = synth.make_utterances(2000, 12, [50, 80, 31, 64, 17, 100, 1, 2, 77,
@@ -247,12 +282,12 @@ def test_resident_decode_is_bit_identical(oracle_lib):
   d2 = _capi.Decoder(case['params'])
   out = d2.decode(*oracle_lib.pack(case['seqs']), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
   assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_small'
-  with pytest.raises(_capi.HipLibraryError):  # hidden size 200 (padded 208): no one-launch kernel, must be refused
+  with pytest.raises(_capi.HipLibraryError):  # hidden size 300 (19 k-blocks: neither 256 nor 512 keeps the segment length): must be refused
     from uisrnn_amd import weights
-    p3 = weights.init_params(40, 200, 1, sigma2=0.1, transition_bias=0.2, seed=3)
+    p3 = weights.init_params(40, 300, 1, sigma2=0.1, transition_bias=0.2, seed=3)
     s3 = [np.random.default_rng(3).standard_normal((9, 40))]
     _capi.Decoder(p3).decode(*oracle_lib.pack(s3), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
-  with pytest.raises(_capi.HipLibraryError):  # look_ahead 2: never one launch
+  with pytest.raises(_capi.HipLibraryError):  # look_ahead 2 at rnn_depth 3: no one-launch kernel
     d2.decode(*oracle_lib.pack(case['seqs']), 6, 2, 2, flags=_capi.UIS_FLAG_RESIDENT)
 
 

@@ -24,8 +24,8 @@ def bits(a):
 def draw(rng):
   big = rng.random() < 0.45  # shapes of the one-launch kernels
   if big:
-    dim = int(rng.choice([120, 128, 250, 256, 400, 512]))
-    hid = int(rng.choice([250, 256, 500, 512]))
+    dim = int(rng.choice([30, 120, 128, 250, 256, 400, 512]))
+    hid = int(rng.choice([130, 200, 250, 256, 390, 500, 512]))   # (129 .. 256 / 385 .. 512: padded up to the kernels' shapes)
     depth = 1
     look = int(rng.choice([1, 1, 1, 2, 2, 3]))   # look_ahead >= 2: k_decode_big<WIN>
     beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select

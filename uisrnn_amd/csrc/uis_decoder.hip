@@ -774,7 +774,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // of the wave-per-row-tile decode)
   const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
                    (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
-                   ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256))) &&
+                   ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512))) &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                    ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                    (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
@@ -1149,6 +1149,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_WIN_CASE(512, 512)
       UIS_WIN_CASE(256, 256)
       UIS_WIN_CASE(256, 128)
+      UIS_WIN_CASE(256, 512)
 #undef UIS_WIN_CASE
     } else if (small) {
       const size_t shmem = small_lds_bytes(m.Dp, B, Kmax, S);
@@ -1448,7 +1449,20 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
     return bail(fail(UIS_ERR_HIP, "event create failed"));
   DevModel& m = h->m;
   m.D = D; m.H = H; m.depth = depth;
-  m.Dp = round_up(D, 16); m.Hp = round_up(H, 16); m.G = 3 * m.Hp;
+  m.Dp = round_up(D, 16); m.Hp = round_up(H, 16);
+  // The one-launch cluster kernels exist for padded hidden sizes 256 / 512 and observation dims 128 / 256 /
+  // 512.  Padding further than to 16 is free of numerical consequences exactly where it keeps the canonical
+  // K-segment length q = ceil(blocks / 8) (uis_numerics.h: the extra blocks are zeros inside the last
+  // segments, empty segments add +0.0f either way; the MSE's sixteen tile accumulators take zero tiles):
+  // hidden sizes 129 .. 256 and 385 .. 512, observation dims up to 256 and 385 .. 512 -- so those models
+  // (rnn_depth 1) get the kernels' shapes instead of the launch-per-step path.
+  if (depth == 1 && !getenv("UIS_PAD_TO_16_ONLY")) {
+    const int qh = (m.Hp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT, qd = (m.Dp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT;
+    const int hp = qh == 2 ? 256 : qh == 4 ? 512 : 0;
+    const int dp = m.Dp <= 128 ? 128 : qd == 2 ? 256 : qd == 4 ? 512 : 0;
+    if (hp && dp) { m.Hp = hp; m.Dp = dp; }
+  }
+  m.G = 3 * m.Hp;
   m.lp_stay = std::log(1.0 - d->transition_bias);  // np.log(1 - transition_bias), uisrnn.py:416
   m.lp_sw = std::log(d->transition_bias);
   m.l_alpha = std::log(d->crp_alpha);
