@@ -96,9 +96,9 @@ typedef struct uis_decode_opts {
                                     the stages of a step; launched cooperatively so that all
                                     workgroups are co-resident) and fail with UIS_ERR_UNSUPPORTED
                                     where it does not apply.  It is the DEFAULT wherever it
-                                    applies: look_ahead 1, rnn_depth 1, rnn_hidden_size 129 .. 256 or
+                                    applies: look_ahead 1, rnn_depth 1, rnn_hidden_size 65 .. 256 or
                                     385 .. 512 and observation_dim up to 256 or 385 .. 512 (the model is
-                                    padded up to 256 / 512 x 128 / 256 / 512 at uis_create),
+                                    padded up to 128 / 256 / 512 x 128 / 256 / 512 at uis_create),
                                     beam_size * (max_clusters + 1) <= 256, one stream, a device
                                     whose CU count is a multiple of 32; small models (hidden size up
                                     to about 64, any rnn_depth) with one workgroup per utterance;

@@ -162,10 +162,11 @@ def test_look_ahead_in_one_launch(dim, hidden, oracle_lib):
       assert np.array_equal(big['labels'][o2[u]:o2[u + 1]], ref['labels'][u])
 
 
-@pytest.mark.parametrize('dim,hidden', [(250, 200), (100, 400), (40, 500), (512, 130), (64, 256)])
+@pytest.mark.parametrize('dim,hidden', [(250, 200), (100, 400), (40, 500), (512, 130), (64, 256),
+                                        (256, 100), (100, 128), (400, 70)])
 def test_in_between_sizes_take_the_one_launch_kernels(dim, hidden, oracle_lib):
-  """rnn_depth 1, hidden size 129 .. 256 / 385 .. 512, observation dim up to 256 / 385 .. 512: the
-  library pads the model up to the cluster kernels' shapes (256 / 512 x 128 / 256 / 512) -- the
+  """rnn_depth 1, hidden size 65 .. 256 / 385 .. 512, observation dim up to 256 / 385 .. 512: the
+  library pads the model up to the cluster kernels' shapes (128 / 256 / 512 x 128 / 256 / 512) -- the
   canonical K-segment length is the same there, so the oracle (which pads to 16) is matched bit for
   bit -- and the decode is one launch, look_ahead 1 and 2."""
   from uisrnn_amd import weights

@@ -25,7 +25,7 @@ def draw(rng):
   big = rng.random() < 0.45  # shapes of the one-launch kernels
   if big:
     dim = int(rng.choice([30, 120, 128, 250, 256, 400, 512]))
-    hid = int(rng.choice([130, 200, 250, 256, 390, 500, 512]))   # (129 .. 256 / 385 .. 512: padded up to the kernels' shapes)
+    hid = int(rng.choice([70, 100, 128, 130, 200, 250, 256, 390, 500, 512]))   # (65 .. 256 / 385 .. 512: padded up to the kernels' shapes)
     depth = 1
     look = int(rng.choice([1, 1, 1, 2, 2, 3]))   # look_ahead >= 2: k_decode_big<WIN>
     beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select

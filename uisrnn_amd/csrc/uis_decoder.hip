@@ -754,7 +754,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   ENSURE(utt_nrows, (size_t)U * 2 * 4);
   // the whole decode in one launch with register-resident weights (k_decode_resident)
-  const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 256 || m.Hp == 512) &&
+  const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) &&
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
                            select_fast_ok(B, Kmax, S) && !(opts->flags & UIS_FLAG_GENERIC_SELECT) && ncl >= 1 &&
                            ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
@@ -774,7 +774,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // of the wave-per-row-tile decode)
   const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
                    (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
-                   ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512))) &&
+                   (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                    ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                    (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
@@ -782,7 +782,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small && !win)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs (look_ahead 1:) one stream, beam_size * (max_clusters + 1) <= 256, no "
                                      "per-step path flag and either a small model (rnn_hidden_size up to about 64, any rnn_depth) "
-                                     "or rnn_depth 1 with rnn_hidden_size 256 or 512 (padded), observation_dim 128, "
+                                     "or rnn_depth 1 with rnn_hidden_size 128, 256 or 512 (padded), observation_dim 128, "
                                      "256 or 512 (padded) and a device whose CU count is a multiple of 32");
   // control words: [0, 16) XCC id per cluster, [16] abort, [32, 32 + 32 ncl) row counters,
   // then 32 ncl barrier counters, then 32 ncl phase words (one 128-byte line per cluster each)
@@ -1083,6 +1083,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_BIGWS_CASE(512, 128, true)
       UIS_BIGWS_CASE(256, 256, true)
       UIS_BIGWS_CASE(256, 128, true)
+      UIS_BIGWS_CASE(128, 256, true)
+      UIS_BIGWS_CASE(128, 128, true)
 #undef UIS_BIGWS_CASE
 #define UIS_RS_CASE(KIND, HPV, DPV, ...)                                                                              \
   if (m.Hp == HPV && m.Dp == DPV && rs_kind == KIND) {                                                               \
@@ -1097,6 +1099,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RS_CASE(RS_BASE, 512, 128, 3, 1, 0, 0, false)
       UIS_RS_CASE(RS_BASE, 256, 256, 3, 1, 0, 0, false)
       UIS_RS_CASE(RS_BASE, 256, 128, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_BASE, 128, 256, 3, 1, 0, 0, false)
+      UIS_RS_CASE(RS_BASE, 128, 128, 3, 1, 0, 0, false)
       UIS_RS_CASE(RS_C1, 512, 256, 3, 1, 10, 16, false)
       UIS_RS_CASE(RS_UPW2, 512, 256, 3, 2, 0, 0, true)
       UIS_RS_CASE(RS_UPW2_C1, 512, 256, 3, 2, 10, 16, true)
@@ -1130,6 +1134,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RESIDENT_CASE(256, 256)
       UIS_RESIDENT_CASE(256, 128)
       UIS_RESIDENT_CASE(256, 512)
+      UIS_RESIDENT_CASE(128, 256)
+      UIS_RESIDENT_CASE(128, 128)
+      UIS_RESIDENT_CASE(128, 512)
 #undef UIS_RESIDENT_CASE
     } else if (win) {
       // h1 into the extra slot, then ONE launch for every sub-step of every window
@@ -1150,6 +1157,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_WIN_CASE(256, 256)
       UIS_WIN_CASE(256, 128)
       UIS_WIN_CASE(256, 512)
+      UIS_WIN_CASE(128, 256)
+      UIS_WIN_CASE(128, 128)
+      UIS_WIN_CASE(128, 512)
 #undef UIS_WIN_CASE
     } else if (small) {
       const size_t shmem = small_lds_bytes(m.Dp, B, Kmax, S);
@@ -1454,11 +1464,11 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   // 512.  Padding further than to 16 is free of numerical consequences exactly where it keeps the canonical
   // K-segment length q = ceil(blocks / 8) (uis_numerics.h: the extra blocks are zeros inside the last
   // segments, empty segments add +0.0f either way; the MSE's sixteen tile accumulators take zero tiles):
-  // hidden sizes 129 .. 256 and 385 .. 512, observation dims up to 256 and 385 .. 512 -- so those models
+  // hidden sizes 65 .. 256 and 385 .. 512, observation dims up to 256 and 385 .. 512 -- so those models
   // (rnn_depth 1) get the kernels' shapes instead of the launch-per-step path.
   if (depth == 1 && !getenv("UIS_PAD_TO_16_ONLY")) {
     const int qh = (m.Hp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT, qd = (m.Dp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT;
-    const int hp = qh == 2 ? 256 : qh == 4 ? 512 : 0;
+    const int hp = (qh == 1 && H > 64) ? 128 : qh == 2 ? 256 : qh == 4 ? 512 : 0;  // (up to 64: k_decode_small's)
     const int dp = m.Dp <= 128 ? 128 : qd == 2 ? 256 : qd == 4 ? 512 : 0;
     if (hp && dp) { m.Hp = hp; m.Dp = dp; }
   }
