@@ -177,7 +177,7 @@ enum {
   UIS_DK_RESIDENT = 3,   /* one launch, owner select (k_decode_resident)                      */
   UIS_DK_BIG = 4,        /* one launch, a wave per row tile (k_decode_big)                    */
   UIS_DK_BIG_WS = 5,     /* ... with a rank's selects running concurrently (k_decode_big<WS>) */
-  UIS_DK_SMALL = 6,      /* one launch, one workgroup per utterance: small models, any rnn_depth (k_decode_small) */
+  UIS_DK_SMALL = 6,      /* one launch, one workgroup per utterance: small models, any rnn_depth, any look_ahead (k_decode_small) */
   UIS_DK_WINDOW = 7      /* one launch, look_ahead >= 2: a window sub-step as the select stage (k_decode_big<WIN>) */
 };
 /* ... in bits 16..23 for UIS_DK_RS its instantiation: 1 base, 2 base with the shape of BASELINE configs[1] as

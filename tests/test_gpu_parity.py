@@ -288,8 +288,11 @@ def test_resident_decode_is_bit_identical(oracle_lib):
     p3 = weights.init_params(40, 300, 1, sigma2=0.1, transition_bias=0.2, seed=3)
     s3 = [np.random.default_rng(3).standard_normal((9, 40))]
     _capi.Decoder(p3).decode(*oracle_lib.pack(s3), 6, 1, 2, flags=_capi.UIS_FLAG_RESIDENT)
-  with pytest.raises(_capi.HipLibraryError):  # look_ahead 2 at rnn_depth 3: no one-launch kernel
-    d2.decode(*oracle_lib.pack(case['seqs']), 6, 2, 2, flags=_capi.UIS_FLAG_RESIDENT)
+  # look_ahead 2 on the small model: one launch too (k_decode_small with a window sub-step as its select)
+  out = d2.decode(*oracle_lib.pack(case['seqs']), 6, 2, 2, flags=_capi.UIS_FLAG_RESIDENT)
+  assert out['status'] == 0 and out['stats']['decode_kernel'] == 'k_decode_small'
+  with pytest.raises(_capi.HipLibraryError):  # look_ahead 2, hidden size 300: no one-launch kernel
+    _capi.Decoder(p3).decode(*oracle_lib.pack(s3), 6, 2, 2, flags=_capi.UIS_FLAG_RESIDENT)
 
 
 @pytest.mark.parametrize('dim,hidden', [(256, 512), (256, 256), (512, 512), (128, 256)])
@@ -995,3 +998,16 @@ def test_small_models_decode_in_one_launch(oracle_lib):
   for beam, tau in ((4, 2), (40, 1)):
     out, _ = _compare(params, seqs, beam, 1, tau, oracle_lib, flags=res)
     assert out['stats']['decode_kernel'] == 'k_decode_small'
+  # look_ahead >= 2 on small models: the same kernel with a sub-step of the window kernel as its select
+  for beam, look, tau, n in ((4, 2, 2, 20), (3, 3, 1, 12), (12, 2, 1, 8)):
+    out, _ = _compare(params, seqs[:n], beam, look, tau, oracle_lib, flags=res)
+    assert out['stats']['decode_kernel'] == 'k_decode_small'
+  case = golden_util.load_case('d32_lookahead3')
+  dec = _capi.Decoder(case['params'])
+  frames, offsets = oracle_lib.pack(case['seqs'])
+  for run in case['runs']:
+    out, _ = _compare(case['params'], case['seqs'], run['beam_size'], run['look_ahead'], run['test_iteration'],
+                      oracle_lib, decoder=dec, flags=res)
+    assert out['stats']['decode_kernel'] == 'k_decode_small'
+    for u in range(len(case['seqs'])):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], run['labels'][u])  # the reference's own

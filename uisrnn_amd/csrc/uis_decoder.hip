@@ -791,12 +791,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // ... and for SMALL models (small_model_ok: hidden size up to about 64, any rnn_depth -- the shapes of
   // the reference's own tests) the whole beam search of an utterance on ONE workgroup, one launch per decode
   // (k_decode_small); the default where the kernels above do not apply
-  const bool small = !resident_ok && L == 1 && G == 1 && !use_graph && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
-                     select_fast_ok(B, Kmax, S) && small_model_ok(m.Hp, m.Dp, m.depth) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024 &&
-                     !getenv("UIS_NO_SMALL_KERNEL");
+  // (look_ahead >= 2: with a sub-step of the window kernel in the select's place, its work arrays in LDS)
+  const bool small_shape = G == 1 && !use_graph && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
+                           small_model_ok(m.Hp, m.Dp, m.depth) && !getenv("UIS_NO_SMALL_KERNEL");
+  const bool small = !resident_ok && small_shape &&
+                     (L == 1 ? select_fast_ok(B, Kmax, S) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024
+                             : wsl.total <= 128 * 1024 && (double)U * NC * std::max(m.G, m.Hp) * 4.0 < 2.0e9);
   // ... and look_ahead >= 2 in one launch (k_decode_big<WIN>: the window kernel's sub-step as the select stage
   // of the wave-per-row-tile decode)
-  const bool win = L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
+  const bool win = !small && L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
                    (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
                    (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
@@ -1186,10 +1189,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_WIN_CASE(128, 512)
 #undef UIS_WIN_CASE
     } else if (small) {
-      const size_t shmem = small_lds_bytes(m.Dp, B, Kmax, S);
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+      const size_t shmem = L == 1 ? small_lds_bytes(m.Dp, B, Kmax, S) : small_win_lds_bytes(S, (int)NC, Kmax, B);
       decode_kernel = UIS_DK_SMALL;
-      LAUNCH(UIS_K_GRU, k_decode_small, dim3(gp.U), dim3(512), shmem, m, gp.st);
+      if (L == 1) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_small<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(UIS_K_GRU, k_decode_small<false>, dim3(gp.U), dim3(512), shmem, m, gp.st);
+      } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_small<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        LAUNCH(UIS_K_GRU, k_decode_small<true>, dim3(gp.U), dim3(512), shmem, m, gp.st);
+      }
     } else if (use_graph && gp.maxT >= UIS_GRAPH_STEPS) {
       GraphCache& gc = h->gcache[g];
       const bool same = gc.exec && gc.lds == (size_t)lds.total && memcmp(&gc.st, &gp.st, sizeof(DecodeState)) == 0;

@@ -2907,93 +2907,6 @@ __host__ __device__ inline bool small_model_ok(int Hp, int Dp, int depth) {
   return nft + (depth - 1) * 4 * nft + nft + Dp / 16 <= 24;
 }
 
-__global__ __launch_bounds__(512) void k_decode_small(DevModel m, DecodeState st) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int t = threadIdx.x, u = blockIdx.x;
-  const int B = st.B, S = st.S, U = st.U;
-  const FastLds L = fast_lds_layout(m.Dp, B, st.Kmax, S);
-  float* spart = reinterpret_cast<float*>(smem_raw + ((L.total + 255) & ~255));  // [UIS_KSPLIT][3][256]
-  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
-  const long T = (long)st.tau * (off1 - off0);
-  RnnRow* const rows_u = st.rows + (size_t)u * B;          // this utterance's rows of a step (at most beam_size)
-  float* const gi_up_u = st.gi_up + (size_t)u * B * m.G;    // (rnn_depth >= 2)
-  float* const a1_u = st.a1 + (size_t)u * B * m.Hp;
-  int32_t* const cnt = st.utt_nrows + 2 * (size_t)u;        // row counters by step parity
-  const int nft = m.Hp / 16, nKb = m.Hp / 16;
-  if (t == 0) { cnt[0] = 0; cnt[1] = 0; }
-  __syncthreads();
-  for (long s = 0; s < T; ++s) {
-    const int par = (int)(s & 1);
-    if (t == 0) cnt[par ^ 1] = 0;  // (its last reader, the previous step's dense part, is behind a barrier)
-    select_fast_body<512, true, true, 0, 7>(m, st, par, u, smem_raw, RowSink{rows_u, cnt + par}, (int)s, off0, off1,
-                                            SelectNoHook(), 0);
-    __syncthreads();
-    const int n = __hip_atomic_load(cnt + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int r0 = 0; r0 < n; r0 += 16) {
-      // the row whose vectors this lane streams as the B operand (a tile's first row always exists)
-      const int lrow = r0 + (t & 15);
-      const RnnRow rb = rows_u[lrow < n ? lrow : r0];
-      // thread t < 256 owns element (row r0 + (t >> 4), feature (t & 15) of the current feature tile)
-      const int erow = r0 + ((t & 255) >> 4);
-      const bool ework = t < 256 && erow < n;
-      RnnRow re = rb;
-      if (ework) re = rows_u[erow];
-      for (int l = 0; l < m.depth; ++l) {
-        if (l > 0) {  // input-side gates of layer l: gi_up[row] = b_ih + W_ih h'_{l-1}
-          const float* in[1] = {hid_ptr(m, st, rb, rb.dst, l - 1)};
-          for (int ft = 0; ft < m.G / 16; ++ft) {
-            splitk_tile<1, 1, 1>(m.wih[l], 0, ft, nKb, in, m.bih[l] + ft * 16, 0, spart);
-            if (ework) gi_up_u[(size_t)erow * m.G + ft * 16 + (t & 15)] = splitk_combine<1, 1>(spart, 0, 0, t);
-            __syncthreads();
-          }
-        }
-        const float* hsrc[1] = {rb.src >= 0 ? hid_ptr(m, st, rb, rb.src, l) : m.h1 + (size_t)l * m.Hp};
-        for (int ft = 0; ft < nft; ++ft) {
-          splitk_tile<3, 1, 1>(m.whh[l], nft, ft, nKb, hsrc, m.bhh[l] + ft * 16, m.Hp, spart);
-          if (ework) {
-            const int j = ft * 16 + (t & 15);
-            const float* gi = l == 0 ? st.gi0 + (size_t)re.frame * m.G : gi_up_u + (size_t)erow * m.G;
-            const float* hs = re.src >= 0 ? hid_ptr(m, st, re, re.src, l) : m.h1 + (size_t)l * m.Hp;
-            const float ghr = splitk_combine<1, 3>(spart, 0, 0, t);
-            const float ghz = splitk_combine<1, 3>(spart, 0, 1, t);
-            const float ghn = splitk_combine<1, 3>(spart, 0, 2, t);
-            const float out = j < m.H ? uis_gru_unit(gi[j], gi[m.Hp + j], gi[2 * m.Hp + j], ghr, ghz, ghn, hs[j]) : 0.0f;
-            const_cast<float*>(hid_ptr(m, st, re, re.dst, l))[j] = out;
-          }
-          __syncthreads();
-        }
-      }
-      {  // a1[row] = relu(b1 + W1 h'_top)
-        const float* in[1] = {hid_ptr(m, st, rb, rb.dst, m.depth - 1)};
-        for (int ft = 0; ft < nft; ++ft) {
-          splitk_tile<1, 1, 1>(m.w1, 0, ft, nKb, in, m.b1 + ft * 16, 0, spart);
-          if (ework) {
-            const float v = splitk_combine<1, 1>(spart, 0, 0, t);
-            a1_u[(size_t)erow * m.Hp + ft * 16 + (t & 15)] = v > 0.0f ? v : 0.0f;
-          }
-          __syncthreads();
-        }
-      }
-      {  // mean = b2 + W2 a1; running-mean update (uisrnn.py:425-429) -> dst slot
-        const float* in[1] = {a1_u + (size_t)(lrow < n ? lrow : r0) * m.Hp};
-        for (int ft = 0; ft < m.Dp / 16; ++ft) {
-          splitk_tile<1, 1, 1>(m.w2, 0, ft, nKb, in, m.b2 + ft * 16, 0, spart);
-          if (ework) {
-            const int f = ft * 16 + (t & 15);
-            float v = splitk_combine<1, 1>(spart, 0, 0, t);
-            if (re.src >= 0) v = uis_mean_update(st.pool_mean[((size_t)u * S + re.src) * m.Dp + f], v, re.nprev);
-            if (f >= m.D) v = 0.0f;
-            st.pool_mean[((size_t)u * S + re.dst) * m.Dp + f] = v;
-          }
-          __syncthreads();
-        }
-      }
-    }
-    __syncthreads();
-  }
-  (void)U;
-}
-
 // ------------------------------------------------------------------ window
 //
 // look_ahead >= 2 (uisrnn.py:469-477,529-559): a window of Lw <= L frames is scored jointly.
@@ -3577,6 +3490,106 @@ __global__ __launch_bounds__(NT) void k_window(DevModel m, DecodeState st, int p
   if (blockIdx.x == 0 && threadIdx.x == 0) st.nrows[par ^ 1] = 0;
   window_body<NT, false>(m, st, (int)blockIdx.x, wlds, RowSink{st.rows, st.nrows + par});
 }
+
+// ---- k_decode_small (described above, next to small_lds_bytes; here because its WIN form runs window_body)
+// WIN (round 4): look_ahead >= 2 -- the select is a sub-step of the window kernel (window_body: expand / prune),
+// a level holds up to NC hypotheses and emits up to NC rows; its work arrays take the select's place in LDS.
+__host__ __device__ inline size_t small_win_lds_bytes(int S, int NC, int Kmax, int B) {
+  return (size_t)((window_scratch_layout(S, NC, Kmax, B).total + 255) & ~255) + (size_t)UIS_KSPLIT * 3 * 256 * 4 + 64;
+}
+template <bool WIN>
+__global__ __launch_bounds__(512) void k_decode_small(DevModel m, DecodeState st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, u = blockIdx.x;
+  const int B = st.B, S = st.S, U = st.U;
+  const int rpu = WIN ? st.NC : B;  // rows an utterance can emit per (sub-)step
+  const size_t sel_bytes = WIN ? window_scratch_layout(S, st.NC, st.Kmax, B).total : (size_t)fast_lds_layout(m.Dp, B, st.Kmax, S).total;
+  float* spart = reinterpret_cast<float*>(smem_raw + ((sel_bytes + 255) & ~(size_t)255));  // [UIS_KSPLIT][3][256]
+  const long off0 = (long)st.off[u], off1 = (long)st.off[u + 1];
+  const long T = (long)st.tau * (off1 - off0);
+  RnnRow* const rows_u = st.rows + (size_t)u * rpu;        // this utterance's rows of a step (at most beam_size / a level)
+  float* const gi_up_u = st.gi_up + (size_t)u * rpu * m.G;  // (rnn_depth >= 2)
+  float* const a1_u = st.a1 + (size_t)u * rpu * m.Hp;
+  int32_t* const cnt = st.utt_nrows + 2 * (size_t)u;        // row counters by step parity
+  const int nft = m.Hp / 16, nKb = m.Hp / 16;
+  if (t == 0) { cnt[0] = 0; cnt[1] = 0; }
+  __syncthreads();
+  for (long s = 0; s < T; ++s) {
+    const int par = (int)(s & 1);
+    if (t == 0) cnt[par ^ 1] = 0;  // (its last reader, the previous step's dense part, is behind a barrier)
+    if constexpr (WIN) {
+      window_body<512, true>(m, st, u, smem_raw, RowSink{rows_u, cnt + par});
+    } else {
+      select_fast_body<512, true, true, 0, 7>(m, st, par, u, smem_raw, RowSink{rows_u, cnt + par}, (int)s, off0, off1,
+                                              SelectNoHook(), 0);
+    }
+    __syncthreads();
+    const int n = __hip_atomic_load(cnt + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r0 = 0; r0 < n; r0 += 16) {
+      // the row whose vectors this lane streams as the B operand (a tile's first row always exists)
+      const int lrow = r0 + (t & 15);
+      const RnnRow rb = rows_u[lrow < n ? lrow : r0];
+      // thread t < 256 owns element (row r0 + (t >> 4), feature (t & 15) of the current feature tile)
+      const int erow = r0 + ((t & 255) >> 4);
+      const bool ework = t < 256 && erow < n;
+      RnnRow re = rb;
+      if (ework) re = rows_u[erow];
+      for (int l = 0; l < m.depth; ++l) {
+        if (l > 0) {  // input-side gates of layer l: gi_up[row] = b_ih + W_ih h'_{l-1}
+          const float* in[1] = {hid_ptr(m, st, rb, rb.dst, l - 1)};
+          for (int ft = 0; ft < m.G / 16; ++ft) {
+            splitk_tile<1, 1, 1>(m.wih[l], 0, ft, nKb, in, m.bih[l] + ft * 16, 0, spart);
+            if (ework) gi_up_u[(size_t)erow * m.G + ft * 16 + (t & 15)] = splitk_combine<1, 1>(spart, 0, 0, t);
+            __syncthreads();
+          }
+        }
+        const float* hsrc[1] = {rb.src >= 0 ? hid_ptr(m, st, rb, rb.src, l) : m.h1 + (size_t)l * m.Hp};
+        for (int ft = 0; ft < nft; ++ft) {
+          splitk_tile<3, 1, 1>(m.whh[l], nft, ft, nKb, hsrc, m.bhh[l] + ft * 16, m.Hp, spart);
+          if (ework) {
+            const int j = ft * 16 + (t & 15);
+            const float* gi = l == 0 ? st.gi0 + (size_t)re.frame * m.G : gi_up_u + (size_t)erow * m.G;
+            const float* hs = re.src >= 0 ? hid_ptr(m, st, re, re.src, l) : m.h1 + (size_t)l * m.Hp;
+            const float ghr = splitk_combine<1, 3>(spart, 0, 0, t);
+            const float ghz = splitk_combine<1, 3>(spart, 0, 1, t);
+            const float ghn = splitk_combine<1, 3>(spart, 0, 2, t);
+            const float out = j < m.H ? uis_gru_unit(gi[j], gi[m.Hp + j], gi[2 * m.Hp + j], ghr, ghz, ghn, hs[j]) : 0.0f;
+            const_cast<float*>(hid_ptr(m, st, re, re.dst, l))[j] = out;
+          }
+          __syncthreads();
+        }
+      }
+      {  // a1[row] = relu(b1 + W1 h'_top)
+        const float* in[1] = {hid_ptr(m, st, rb, rb.dst, m.depth - 1)};
+        for (int ft = 0; ft < nft; ++ft) {
+          splitk_tile<1, 1, 1>(m.w1, 0, ft, nKb, in, m.b1 + ft * 16, 0, spart);
+          if (ework) {
+            const float v = splitk_combine<1, 1>(spart, 0, 0, t);
+            a1_u[(size_t)erow * m.Hp + ft * 16 + (t & 15)] = v > 0.0f ? v : 0.0f;
+          }
+          __syncthreads();
+        }
+      }
+      {  // mean = b2 + W2 a1; running-mean update (uisrnn.py:425-429) -> dst slot
+        const float* in[1] = {a1_u + (size_t)(lrow < n ? lrow : r0) * m.Hp};
+        for (int ft = 0; ft < m.Dp / 16; ++ft) {
+          splitk_tile<1, 1, 1>(m.w2, 0, ft, nKb, in, m.b2 + ft * 16, 0, spart);
+          if (ework) {
+            const int f = ft * 16 + (t & 15);
+            float v = splitk_combine<1, 1>(spart, 0, 0, t);
+            if (re.src >= 0) v = uis_mean_update(st.pool_mean[((size_t)u * S + re.src) * m.Dp + f], v, re.nprev);
+            if (f >= m.D) v = 0.0f;
+            st.pool_mean[((size_t)u * S + re.dst) * m.Dp + f] = v;
+          }
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+  }
+  (void)U;
+}
+
 
 // look_ahead >= 2: trace[-N:] from the per-window back-pointers
 __global__ void k_backtrace_window(DecodeState st, int32_t* __restrict__ labels, float* __restrict__ scores,
