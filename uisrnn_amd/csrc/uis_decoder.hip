@@ -794,14 +794,17 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // (look_ahead >= 2: with a sub-step of the window kernel in the select's place, its work arrays in LDS)
   const bool small_shape = G == 1 && !use_graph && !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
                            small_model_ok(m.Hp, m.Dp, m.depth) && !getenv("UIS_NO_SMALL_KERNEL");
+  // (a model of the cluster kernels' shapes -- hidden size 128 with a small observation dim also counts as
+  // "small" -- goes to them: k_decode_big<WIN> below)
+  const bool cluster_shape = m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512);
   const bool small = !resident_ok && small_shape &&
                      (L == 1 ? select_fast_ok(B, Kmax, S) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024
-                             : wsl.total <= 128 * 1024 && (double)U * NC * std::max(m.G, m.Hp) * 4.0 < 2.0e9);
+                             : !cluster_shape && wsl.total <= 128 * 1024 && (double)U * NC * std::max(m.G, m.Hp) * 4.0 < 2.0e9);
   // ... and look_ahead >= 2 in one launch (k_decode_big<WIN>: the window kernel's sub-step as the select stage
   // of the wave-per-row-tile decode)
   const bool win = !small && L > 1 && m.depth == 1 && G == 1 && !use_graph && ncl >= 1 &&
                    (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
-                   (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) &&
+                   cluster_shape &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                    ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                    (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
