@@ -1011,3 +1011,19 @@ def test_small_models_decode_in_one_launch(oracle_lib):
     assert out['stats']['decode_kernel'] == 'k_decode_small'
     for u in range(len(case['seqs'])):
       assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], run['labels'][u])  # the reference's own
+
+
+@pytest.mark.parametrize('hidden', [256, 512])
+def test_depth2_upper_layer_on_the_lds_weight_kernels(hidden, oracle_lib):
+  """rnn_depth 2 at hidden size 256 / 512 with thousands of rnn rows per step (launch-per-step path, k_wt_*):
+  the upper layer's input-side gates run on the wave-per-row-tile kernel too (k_wt_gru<.., UP>) -- same
+  canonical sums as the split-K tiles, so the oracle is matched bit for bit."""
+  from uisrnn_amd import weights
+  params = weights.init_params(48, hidden, 2, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=hidden)
+  params['rnn_init_hidden'] = (0.2 * np.random.default_rng(1).standard_normal((2, hidden))).astype(np.float32)
+  rng = np.random.default_rng(hidden + 1)
+  cents = rng.standard_normal((3, 48))
+  lens = [int(n) for n in rng.integers(1, 9, size=260)]
+  seqs = [(cents[np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]] * 0.4 + 0.1 * rng.standard_normal((n, 48))) for n in lens]
+  out, _ = _compare(params, seqs, 8, 1, 1, oracle_lib)
+  assert out['stats']['decode_kernel'] == 'stepwise:k_wt'

@@ -383,7 +383,11 @@ int launch_rnn(uis_handle* h, Launcher& lch, const DecodeState& st, int par, lon
     const int ng1 = wt_groups(h->n_cu, nft);
     const size_t kb_bytes = (size_t)nft * 1024;  // one weight stream of a feature tile: all k-blocks
     for (int l = 0; l < m.depth; ++l) {
-      if (l > 0) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
+      // (layers >= 1: the input-side gates by the same kernel, W_ih in the LDS slot; UIS_WT_NO_UPPER=1 keeps the split-K tiles)
+      static const bool wt_upper = getenv("UIS_WT_NO_UPPER") == nullptr;
+      if (l > 0 && !wt_upper) LAUNCH(UIS_K_UPPER_IN, k_dense_upper_in, dim3(step_grid_blocks(mr, m.G / 16, 1, 1)), dim3(512), 0, m, st, par, l);
+      if (l > 0 && wt_upper && m.Hp == 512) LAUNCH(UIS_K_UPPER_IN, (k_wt_gru<32, true>), dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
+      if (l > 0 && wt_upper && m.Hp != 512) LAUNCH(UIS_K_UPPER_IN, (k_wt_gru<16, true>), dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
       if (m.Hp == 512) LAUNCH(UIS_K_GRU, k_wt_gru<32>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
       else LAUNCH(UIS_K_GRU, k_wt_gru<16>, dim3(nft * ng1), dim3(512), 3 * kb_bytes, m, st, par, l, ng1);
     }
@@ -1536,6 +1540,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   if ((rc = upload(h, std::vector<float>((size_t)depth * m.Hp, 0.0f), &m.h1))) return bail(rc);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_select_fast), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_gru<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_gru<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_head<32, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wt_head<32, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_window<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);

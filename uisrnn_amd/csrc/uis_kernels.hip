@@ -2754,7 +2754,10 @@ __host__ __device__ inline int wt_groups(int n_cu, int nft) {  // row groups: ab
   ng = ng < 8 ? 8 : ng - ng % 8;
   return ng;
 }
-template <int NKB>
+// UP: the input-side gates of GRU layer `layer` >= 1 instead -- gi_up[row][G] = b_ih + W_ih h'_{layer-1} (what
+// k_dense_upper_in computes with split-K tiles: 204 us per step at 1024 utterances against 80 for a GRU
+// layer of the same size here) -- same streams, no gate arithmetic.
+template <int NKB, bool UP = false>
 __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int par, int layer, int ng) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   f32x4* s_w = reinterpret_cast<f32x4*>(smem_raw);  // [3][NKB][64]
@@ -2766,15 +2769,17 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
   if (grp >= nrt) return;  // nothing in this group
   for (int e = t; e < NKB * 64; e += 512) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) s_w[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(m.whh[layer])[(size_t)(g * nft + ft) * NKB * 64 + e];
+    for (int g = 0; g < 3; ++g) s_w[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(UP ? m.wih[layer] : m.whh[layer])[(size_t)(g * nft + ft) * NKB * 64 + e];
   }
   __syncthreads();
-  const float* bias[3] = {m.bhh[layer] + ft * 16, m.bhh[layer] + m.Hp + ft * 16, m.bhh[layer] + 2 * m.Hp + ft * 16};
+  const float* bvec = UP ? m.bih[layer] : m.bhh[layer];
+  const float* bias[3] = {bvec + ft * 16, bvec + m.Hp + ft * 16, bvec + 2 * m.Hp + ft * 16};
   constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
   auto fetch = [&](int tl, RnnRow& r_, const float*& hs_) {
     const int row = 16 * tl + (lane & 15);
     r_ = st.rows[row < nrows ? row : 16 * tl];  // (a tile's first row always exists)
-    hs_ = r_.src >= 0 ? hid_ptr(m, st, r_, r_.src, layer) : m.h1 + (size_t)layer * m.Hp;
+    if (UP) hs_ = hid_ptr(m, st, r_, r_.dst, layer - 1);  // (this step's output of the layer below)
+    else hs_ = r_.src >= 0 ? hid_ptr(m, st, r_, r_.src, layer) : m.h1 + (size_t)layer * m.Hp;
   };
   int tile = grp + ng * w;
   RnnRow me{};
@@ -2790,14 +2795,22 @@ __global__ __launch_bounds__(512) void k_wt_gru(DevModel m, DecodeState st, int 
     const int row = 16 * tile + (lane & 15);
     const bool valid = row < nrows;
     const int j4 = ft * 16 + 4 * q;
-    const float* gi = layer == 0 ? st.gi0 + (size_t)me.frame * m.G : st.gi_up + (size_t)(valid ? row : 16 * tile) * m.G;
-    const f32x4 gir = *reinterpret_cast<const f32x4*>(gi + j4);
-    const f32x4 giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j4);
-    const f32x4 gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j4);
-    const f32x4 hprev = *reinterpret_cast<const f32x4*>(hs + j4);
+    f32x4 gir = {0.0f, 0.0f, 0.0f, 0.0f}, giz = gir, gin = gir, hprev = gir;
+    if (!UP) {
+      const float* gi = layer == 0 ? st.gi0 + (size_t)me.frame * m.G : st.gi_up + (size_t)(valid ? row : 16 * tile) * m.G;
+      gir = *reinterpret_cast<const f32x4*>(gi + j4);
+      giz = *reinterpret_cast<const f32x4*>(gi + m.Hp + j4);
+      gin = *reinterpret_cast<const f32x4*>(gi + 2 * m.Hp + j4);
+      hprev = *reinterpret_cast<const f32x4*>(hs + j4);
+    }
     f32x4 gh[3];
     fullk_rows_plain<3, NKB, GSG>(s_w, NKB * 64, bias, hs, gh, bfirst, hs_n, has_next);
-    if (valid) {
+    if (valid && UP) {
+      float* go = st.gi_up + (size_t)row * m.G + j4;
+      *reinterpret_cast<f32x4*>(go) = gh[0];
+      *reinterpret_cast<f32x4*>(go + m.Hp) = gh[1];
+      *reinterpret_cast<f32x4*>(go + 2 * m.Hp) = gh[2];
+    } else if (valid) {
       f32x4 out;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
