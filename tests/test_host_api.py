@@ -360,3 +360,40 @@ def test_sequence_match_accuracy_known_answers():
     acc([0, 1], [0])
   with pytest.raises(ValueError):
     acc([], [])
+
+
+def test_predict_splits_a_list_that_does_not_fit_the_device():
+  """The reference's predict takes a list of any size (uisrnn.py:588-589).  When the library reports that
+  the decode state of a batch does not fit (UIS_ERR_OOM), the host layer decodes the list in halves --
+  recursively -- and hands the labels back in the caller's order.  (Plumbing test with a stand-in decoder:
+  no device here.)"""
+  from uisrnn_amd import uisrnn as host
+
+  class StandIn:
+    """Decodes at most `room` utterances at a time; labels = the utterance's own tag, so order is checkable."""
+    def __init__(self, room):
+      self.room, self.batches = room, []
+
+    def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+      if len(seqs) > self.room:
+        err = _capi.HipLibraryError('uis_decode_f64 failed (-5): decode state would need 999 GB')
+        err.status = _capi.UIS_ERR_OOM
+        raise err
+      self.batches.append(len(seqs))
+      labels = np.concatenate([np.full(s.shape[0], int(s[0, 0]), dtype=np.int32) for s in seqs])
+      return {'status': 0, 'labels': labels, 'overflow': np.zeros(len(seqs), dtype=np.int32),
+              'stats': {'decode_kernel': 'stand-in'}}
+
+  model_args, _, inference_args = arguments.parse_arguments([])
+  model_args.observation_dim = 4
+  model = uisrnn_amd.UISRNN(model_args)
+  seqs = [np.full((3 + k % 4, 4), float(k)) for k in range(11)]
+  dec = StandIn(room=3)
+  out = model._decode_batch(seqs, inference_args, decoder=dec)  # pylint: disable=protected-access
+  assert [lab[0] for lab in out] == list(range(11))
+  assert [len(lab) for lab in out] == [s.shape[0] for s in seqs]
+  assert sum(dec.batches) == 11 and max(dec.batches) <= 3
+  # a single utterance that does not fit is an error, not a loop
+  with pytest.raises(_capi.HipLibraryError):
+    model._decode_batch(seqs[:1], inference_args, decoder=StandIn(room=0))  # pylint: disable=protected-access
+  assert host is not None

@@ -206,6 +206,18 @@ class UISRNN:
         out = decoder.decode_f64(sub, args.beam_size, args.look_ahead,
                                  args.test_iteration, max_clusters=cap, flags=flags)
       except _capi.HipLibraryError as err:
+        if err.status == _capi.UIS_ERR_OOM and len(pending) > 1:
+          # the decode state of this many utterances does not fit the device (or the pinned staging
+          # block the host): the reference's predict takes a list of any size (uisrnn.py:588-589), so
+          # the list goes in two halves, one after the other -- alternating members, so that a list
+          # dealt longest-first stays even -- and each half may halve again
+          for part in (pending[0::2], pending[1::2]):
+            part_labels = self._decode_batch([sequences[u] for u in part], args, flags, device, decoder)
+            for u, labels in zip(part, part_labels):
+              results[u] = labels
+          with self._state_lock:
+            self._single_pass = False  # several decodes: no single resident label buffer
+          return results
         if err.status != _capi.UIS_ERR_UNSUPPORTED or args.look_ahead < 2:
           raise
         # a look-ahead window of some utterances held more assignment prefixes than a level has
