@@ -1027,3 +1027,27 @@ def test_depth2_upper_layer_on_the_lds_weight_kernels(hidden, oracle_lib):
   seqs = [(cents[np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]] * 0.4 + 0.1 * rng.standard_normal((n, 48))) for n in lens]
   out, _ = _compare(params, seqs, 8, 1, 1, oracle_lib)
   assert out['stats']['decode_kernel'] == 'stepwise:k_wt'
+
+
+def test_predict_decodes_an_oversized_list_in_halves(monkeypatch, oracle_lib):
+  """predict(list) when the list's decode state exceeds what the library accepts (UIS_ERR_OOM; the ceiling
+  lowered through UIS_MAX_STATE_BYTES): the host layer splits the list, recursively, and the labels come
+  back in the caller's order, identical to the unsplit decode's."""
+  import uisrnn_amd
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model = uisrnn_amd.UISRNN(model_args)
+  params = synth.tracker_params(256, 512, 1, seed=0)
+  model.load_params(params)
+  lens = [40, 12, 33, 1, 25, 18, 30, 7, 22, 15, 9]
+  seqs, _ = synth.make_utterances(9100, len(lens), lens, 256)
+  whole = model.predict(seqs, inference_args)
+  assert model.last_stats['decode_kernel'].startswith('k_decode_')
+  # one utterance's state: S = 10 * 16 + 10 slots x (256 + 512) floats = 522 KB: room for three
+  monkeypatch.setenv('UIS_MAX_STATE_BYTES', str(3.5 * 170 * 768 * 4))
+  split = model.predict(seqs, inference_args)
+  assert split == whole
+  ref = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=4)
+  assert split == [l.tolist() for l in ref['labels']]
+  monkeypatch.setenv('UIS_MAX_STATE_BYTES', '1000')  # not even one utterance fits: the library's error goes up
+  with pytest.raises(_capi.HipLibraryError):
+    model.predict(seqs[:2], inference_args)
