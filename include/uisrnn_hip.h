@@ -98,7 +98,8 @@ typedef struct uis_decode_opts {
                                     where it does not apply.  It is the DEFAULT wherever it
                                     applies: look_ahead 1, rnn_depth 1, rnn_hidden_size 65 .. 256 or
                                     385 .. 512 and observation_dim up to 256 or 385 .. 512 (the model is
-                                    padded up to 128 / 256 / 512 x 128 / 256 / 512 at uis_create),
+                                    padded up to 128 / 256 / 512 x 128 / 256 / 512 at uis_create; rnn_depth >= 2
+                                    at those sizes: k_decode_deep, UIS_DK_DEEP),
                                     beam_size * (max_clusters + 1) <= 256, one stream, a device
                                     whose CU count is a multiple of 32; small models (hidden size up
                                     to about 64, any rnn_depth) with one workgroup per utterance;
@@ -178,7 +179,8 @@ enum {
   UIS_DK_BIG = 4,        /* one launch, a wave per row tile (k_decode_big)                    */
   UIS_DK_BIG_WS = 5,     /* ... with a rank's selects running concurrently (k_decode_big<WS>) */
   UIS_DK_SMALL = 6,      /* one launch, one workgroup per utterance: small models, any rnn_depth, any look_ahead (k_decode_small) */
-  UIS_DK_WINDOW = 7      /* one launch, look_ahead >= 2: a window sub-step as the select stage (k_decode_big<WIN>) */
+  UIS_DK_WINDOW = 7,     /* one launch, look_ahead >= 2: a window sub-step as the select stage (k_decode_big<WIN>) */
+  UIS_DK_DEEP = 8        /* one launch, rnn_depth >= 2 at hidden size 128 / 256 / 512: the weight slot refilled per stage (k_decode_deep) */
 };
 /* ... in bits 16..23 for UIS_DK_RS its instantiation: 1 base, 2 base with the shape of BASELINE configs[1] as
  * compile-time constants, 3 two utterances per wave (9 .. 16 per XCD), 4 wide (beam_size <= 32 / observation

@@ -1025,7 +1025,7 @@ def test_depth2_upper_layer_on_the_lds_weight_kernels(hidden, oracle_lib):
   cents = rng.standard_normal((3, 48))
   lens = [int(n) for n in rng.integers(1, 9, size=260)]
   seqs = [(cents[np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]] * 0.4 + 0.1 * rng.standard_normal((n, 48))) for n in lens]
-  out, _ = _compare(params, seqs, 8, 1, 1, oracle_lib)
+  out, _ = _compare(params, seqs, 8, 1, 1, oracle_lib, flags=_capi.UIS_FLAG_STEPWISE)
   assert out['stats']['decode_kernel'] == 'stepwise:k_wt'
 
 
@@ -1051,3 +1051,38 @@ def test_predict_decodes_an_oversized_list_in_halves(monkeypatch, oracle_lib):
   monkeypatch.setenv('UIS_MAX_STATE_BYTES', '1000')  # not even one utterance fits: the library's error goes up
   with pytest.raises(_capi.HipLibraryError):
     model.predict(seqs[:2], inference_args)
+
+
+@pytest.mark.parametrize('dim,hidden,depth', [(48, 256, 2), (256, 512, 2), (30, 100, 3), (200, 500, 2)])
+def test_deep_models_decode_in_one_launch(dim, hidden, depth, oracle_lib):
+  """rnn_depth >= 2 at the cluster kernels' shapes (hidden size 65 .. 256 / 385 .. 512 after padding):
+  k_decode_deep -- k_decode_big's stages with the workgroup's weight slot refilled per stage, one more pair
+  of stages per upper layer -- against the oracle and the launch-per-step path, bit for bit, ragged
+  utterances, few and many (more than one per workgroup)."""
+  from uisrnn_amd import weights
+  params = weights.init_params(dim, hidden, depth, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=dim + hidden)
+  params['rnn_init_hidden'] = (0.2 * np.random.default_rng(2).standard_normal((depth, hidden))).astype(np.float32)
+  rng = np.random.default_rng(dim * 7 + hidden)
+  cents = rng.standard_normal((3, dim))
+  lens = [19, 6, 25, 1, 13, 9, 22, 4, 16]
+  seqs = [(cents[np.repeat(rng.integers(0, 3, size=n // 4 + 1), 4)[:n]] * 0.4 + 0.1 * rng.standard_normal((n, dim))) for n in lens]
+  dec = _capi.Decoder(params)
+  out, ref = _compare(params, seqs, 6, 1, 2, oracle_lib, decoder=dec)
+  frames, offsets = oracle_lib.pack(seqs)
+  cap = int(ref['max_clusters'].max()) + 1
+  one = dec.decode(frames, offsets, 6, 1, 2, max_clusters=cap, flags=_capi.UIS_FLAG_RESIDENT)
+  assert one['status'] == 0 and one['stats']['decode_kernel'] == 'k_decode_deep'
+  # CoreRNN.forward through every layer of the padded model
+  x = rng.standard_normal(dim).astype(np.float32)
+  h0 = rng.standard_normal((depth, hidden)).astype(np.float32)
+  mean, hout = dec.rnn_step(x, h0)
+  mean_o, hout_o = oracle_lib.rnn_step(params, x, h0)
+  assert np.array_equal(_bits(mean), _bits(mean_o)) and np.array_equal(_bits(hout), _bits(hout_o))
+  if hidden == 256:
+    many = [seqs[i % len(seqs)][:6] for i in range(300)]
+    f2, o2 = oracle_lib.pack(many)
+    big = dec.decode(f2, o2, 4, 1, 1, max_clusters=cap, want_beam_scores=True)
+    assert big['status'] == 0 and big['stats']['decode_kernel'] == 'k_decode_deep'
+    step = dec.decode(f2, o2, 4, 1, 1, max_clusters=cap, want_beam_scores=True, flags=_capi.UIS_FLAG_STEPWISE)
+    assert np.array_equal(big['labels'], step['labels'])
+    assert np.array_equal(_bits(big['beam_scores']), _bits(step['beam_scores']))

@@ -47,7 +47,7 @@ KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
 # uis_stats.decode_kernel (UIS_DK_* | UIS_DF_* << 8): the kernel family that ran the decode steps
 DECODE_KERNELS = {0: 'none', 1: 'stepwise', 2: 'k_decode_rs', 3: 'k_decode_resident', 4: 'k_decode_big',
                   5: 'k_decode_big<WS>', 6: 'k_decode_small',
-                  7: 'k_decode_big<WIN>'}
+                  7: 'k_decode_big<WIN>', 8: 'k_decode_deep'}
 DENSE_FAMILIES = {0: '', 1: 'k_dense', 2: 'k_big', 3: 'k_wt'}
 
 

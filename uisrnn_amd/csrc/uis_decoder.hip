@@ -186,7 +186,7 @@ struct uis_handle {
   // workspace (grow only)
   DevBuf off, utt_step, overflow, xpad, gi0, mse0, logblk, logden, pool_mean, pool_hid, pool_cnt;
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
-  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores, utt_nrows;
+  DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores, utt_nrows, hst;
   size_t dbg_floats = 0;  // what the last decode left in dbg_scores (UIS_FLAG_DEBUG_SCORES)
   DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
@@ -777,6 +777,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // depth 1: k_decode_resident's h' staging buffer
   ENSURE(gi_up, m.depth > 1 ? (size_t)rows_cap * m.G * 4 : (size_t)rows_cap * m.Hp * 4);
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
+  // rnn_depth >= 2 in one launch (k_decode_deep): the cluster kernels' shapes, the select's LDS budget; the
+  // two hand-off buffers a layer's h' goes through
+  const bool deep_shape = L == 1 && m.depth >= 2 && G == 1 &&
+                          ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) ||
+                           (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256)) || (m.Hp == 128 && (m.Dp == 128 || m.Dp == 256)));
+  if (deep_shape) ENSURE(hst, (size_t)2 * rows_cap * m.Hp * 4);
 #if defined(UIS_RESIDENT_TIMING)
   ENSURE(counters, (size_t)UIS_MAX_GROUPS * 4 * 8 + (96 + 1024) * 8);
 #else
@@ -804,6 +810,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // (a model of the cluster kernels' shapes -- hidden size 128 with a small observation dim also counts as
   // "small" -- goes to them: k_decode_big<WIN> below)
   const bool cluster_shape = m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512);
+  // rnn_depth >= 2 at the cluster kernels' shapes: k_decode_big's stages with the weight slot refilled per stage
+  const bool deep = deep_shape && !small_shape && !use_graph && ncl >= 1 && select_fast_ok(B, Kmax, S) &&
+                    !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
+                    (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
+                    ((double)U * S + 1) * m.depth * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.G * 4.0 < 2.0e9 &&
+                    (double)U * S * m.Dp * 4.0 < 2.0e9 && deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 157 * 1024 &&
+                    !getenv("UIS_NO_DEEP_KERNEL");
   const bool small = !resident_ok && small_shape &&
                      (L == 1 ? select_fast_ok(B, Kmax, S) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024
                              : !cluster_shape && wsl.total <= 128 * 1024 && (double)U * NC * std::max(m.G, m.Hp) * 4.0 < 2.0e9);
@@ -816,7 +829,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                    ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
                    (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
                    !getenv("UIS_NO_WINDOW_LAUNCH");
-  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small && !win)
+  if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small && !win && !deep)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs (look_ahead 1:) one stream, beam_size * (max_clusters + 1) <= 256, no "
                                      "per-step path flag and either a small model (rnn_hidden_size up to about 64, any rnn_depth) "
                                      "or rnn_depth 1 with rnn_hidden_size 128, 256 or 512 (padded), observation_dim 128, "
@@ -1040,8 +1053,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.counters = h->counters.as<unsigned long long>() + 4 * g;
     st.cl_abort = ctl + 16;
     st.utt_nrows = h->utt_nrows.as<int32_t>() + 2 * u0;
+    st.hst = deep_shape ? h->hst.as<float>() : nullptr;
+    st.hst_elems = (size_t)rows_cap * m.Hp;
     st.dbg_scores = dbg ? h->dbg_scores.as<float>() + 0 : nullptr;  // (one group: groups would need their own utterance offset)
-    if (resident || win) {
+    if (resident || win || deep) {
       st.ncl = ncl;
       st.cl_xcc = ctl;
       st.rx_stride = rx_stride;
@@ -1198,6 +1213,27 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_WIN_CASE(128, 128)
       UIS_WIN_CASE(128, 512)
 #undef UIS_WIN_CASE
+    } else if (deep) {
+      // h1 of every layer into the extra slot, then ONE launch for every step of every utterance
+      HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.depth * m.Hp, m.h1, (size_t)m.depth * m.Hp * 4, hipMemcpyDeviceToDevice, sg));
+      const size_t shmem = deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S);
+      decode_kernel = UIS_DK_DEEP;
+#define UIS_DEEP_CASE(HPV, DPV)                                                                                       \
+  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+    void (*kern)(DevModel, DecodeState) = &k_decode_deep<HPV, DPV>;                                                 \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
+      return rc;                                                                                                     \
+  }
+      UIS_DEEP_CASE(512, 256)
+      UIS_DEEP_CASE(512, 128)
+      UIS_DEEP_CASE(512, 512)
+      UIS_DEEP_CASE(256, 256)
+      UIS_DEEP_CASE(256, 128)
+      UIS_DEEP_CASE(128, 128)
+      UIS_DEEP_CASE(128, 256)
+#undef UIS_DEEP_CASE
     } else if (small) {
       const size_t shmem = L == 1 ? small_lds_bytes(m.Dp, B, Kmax, S) : small_win_lds_bytes(S, (int)NC, Kmax, B);
       decode_kernel = UIS_DK_SMALL;
@@ -1508,7 +1544,7 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   // segments, empty segments add +0.0f either way; the MSE's sixteen tile accumulators take zero tiles):
   // hidden sizes 65 .. 256 and 385 .. 512, observation dims up to 256 and 385 .. 512 -- so those models
   // (rnn_depth 1) get the kernels' shapes instead of the launch-per-step path.
-  if (depth == 1 && !getenv("UIS_PAD_TO_16_ONLY")) {
+  if (!getenv("UIS_PAD_TO_16_ONLY")) {  // (any rnn_depth: the upper layers' K axis is the hidden size too)
     const int qh = (m.Hp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT, qd = (m.Dp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT;
     const int hp = (qh == 1 && H > 64) ? 128 : qh == 2 ? 256 : qh == 4 ? 512 : 0;  // (up to 64: k_decode_small's)
     const int dp = m.Dp <= 128 ? 128 : qd == 2 ? 256 : qd == 4 ? 512 : 0;

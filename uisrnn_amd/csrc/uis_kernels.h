@@ -131,6 +131,8 @@ struct DecodeState {
   int32_t* rx_nrows;
   uint32_t* rx_bar;
   int32_t* utt_nrows;     // [U][2] k_decode_small: an utterance's row counters, by step parity
+  float* hst;             // k_decode_deep: two hand-off buffers [2][hst_elems] (layer l writes [l & 1]), k-block-major row tiles
+  size_t hst_elems;
   uint32_t* rx_flags;     // [ncl][32] per-producer phase words (one 128-byte line per cluster): the hand-offs between the dense stages
   // k_decode_rs (replicated select): mse_tab[((step parity) * U + u) * S + slot] = weighted MSE of
   // that step's frame against the cluster mean in `slot`, published one step ahead by the

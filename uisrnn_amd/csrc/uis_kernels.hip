@@ -4098,6 +4098,233 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   }
 }
 
+// rnn_depth >= 2 in ONE launch (round 4): k_decode_big's grid, barriers and wave-per-row-tile stages with one
+// more pair of stages per upper layer.  A workgroup's 96 KB weight slot cannot hold W_hh of every layer and
+// W_ih of the upper ones, so the slot is REFILLED stage by stage from L2 / the Infinity Cache (the price of
+// depth in this design: three refills per step at depth 2, where the copy can it runs between a barrier's
+// arrival and its completion).  Per step: selects (each utterance on its owner workgroup, tables in global
+// memory) | layer 0: GRU | layers l >= 1: input-side gates gi = b_ih + W_ih h'_{l-1} into gi_up (read back by the
+// very wave that wrote them: no barrier, only the slot swap), then the GRU of layer l | linear_mean1 |
+// linear_mean2.  A layer's h' goes to its cluster-state slot and, k-block-major, to the hand-off buffer
+// hst[l & 1] that the next stage of EVERY rank streams.  Same canonical sums as everywhere (uis_numerics.h).
+__host__ __device__ inline size_t deep_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
+  return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
+}
+template <int HP, int DP>
+__global__ __launch_bounds__(512) void k_decode_deep(DevModel m, DecodeState st) {
+  // (m.Hp == HP, m.Dp == DP: the host picks the instantiation; m is NOT written here -- its per-layer pointer
+  // arrays are indexed by a run-time layer number and stay in the kernel-argument segment only if it is read-only)
+  constexpr int NKB = HP / 16;
+  constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;
+  constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;
+  static_assert(NFT1 * SH1 == 32 && NFT2 * SH2 == 32, "hidden size 128 / 256 / 512, observation_dim 128 / 256 / 512 (padded)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, q = lane >> 4;
+  const int ncl = st.ncl;
+  const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
+  const int U = st.U, S = st.S, depth = m.depth;
+  const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
+  f32x4* s_slot = reinterpret_cast<f32x4*>(smem_raw + (((size_t)L.total + 255) & ~(size_t)255));  // [3][NKB][64]: W_hh / W_ih of the layer at hand
+  f32x4* s_wm = s_slot + 3 * NKB * 64;                                                            // [NKB][64]: linear_mean1's slice, then linear_mean2's
+  int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                                           // [0] abort [1] steps [2] arrived
+  uint32_t xcc = 0;
+  if (t == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (rank == 0) __hip_atomic_store(st.cl_xcc + cluster, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
+  }
+  __syncthreads();
+  {
+    int myT = 0;
+    for (int i = t; cluster + ncl * i < U; i += 512) {
+      const int u = cluster + ncl * i;
+      const long T = (long)st.tau * (long)(st.off[u + 1] - st.off[u]);
+      myT = T > myT ? (int)T : myT;
+    }
+    if (myT > 0) atomicMax(&s_ctl[1], myT);
+  }
+  __syncthreads();
+  const int nsteps = s_ctl[1];
+  const int ft1 = rank / SH1, tpar1 = rank % SH1;
+  const int ft2 = rank / SH2, tpar2 = rank % SH2;
+  auto fill_slot = [&](const float* wmat) {  // this rank's feature tile of a [3 gates][HP] x HP matrix in tile order
+    for (int e = t; e < NKB * 64; e += 512) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) s_slot[g * NKB * 64 + e] = reinterpret_cast<const f32x4*>(wmat)[(size_t)(g * NFT1 + ft1) * NKB * 64 + e];
+    }
+  };
+  const f32x4* w1g = reinterpret_cast<const f32x4*>(m.w1) + (size_t)ft1 * NKB * 64;
+  const f32x4* w2g = reinterpret_cast<const f32x4*>(m.w2) + (size_t)ft2 * NKB * 64;
+  const __amdgpu_buffer_rsrc_t rs_rows = __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hid = __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mean = __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gup = __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+  // (one descriptor per use, built from the layer's parity: an indexed pair of descriptors lives in scratch)
+  auto hs_rsrc = [&](int l_) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(st.hst + ((l_ & 1) ? st.hst_elems : (size_t)0)), (short)0, 0x7fffffff, 0x00020000);
+  };
+  const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;
+  const int rbase = cluster * st.rx_stride;
+  const uint32_t h1_off = (uint32_t)((size_t)U * S * depth * HP * 4);  // the extra slot: h1 of every layer
+  RowSink sink{st.rows + rbase, nullptr};
+  uint32_t bar = 0;
+  const float* bias_1[1] = {m.b1 + ft1 * 16};
+  const float* bias_2[1] = {m.b2 + ft2 * 16};
+  constexpr int GSG = 2, GBG = GSG * (NKB / UIS_KSPLIT);
+  constexpr int GBH = 4 * (NKB / UIS_KSPLIT);
+  auto stage_off = [&](int tl) { return (uint32_t)((((tile0 + tl) * NFT1) * 256 + (lane & 15) * 16) * 4); };
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int par = s & 1;
+    sink.count = st.rx_nrows + cluster * 32 + par;
+    for (int i = rank; cluster + ncl * i < U; i += 32) {
+      select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
+      __syncthreads();
+    }
+    // (the slot last held W_hh of the top layer: layer 0's goes in while the barrier completes)
+    xcd_arrive(st, cluster, s_ctl);
+    fill_slot(m.whh[0]);
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+      __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
+    const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rank == 0 && t == 0)
+      __hip_atomic_store(st.rx_nrows + cluster * 32 + (par ^ 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nrt = (nrows + 15) >> 4;
+
+    for (int l = 0; l < depth; ++l) {
+      if (l > 0) {
+        // ---- input-side gates of layer l: gi_up[row] = b_ih + W_ih h'_{l-1} (this rank's 16 units of each gate;
+        // W_ih went into the slot while the barrier behind layer l - 1 completed)
+        const float* bias_ih[3] = {m.bih[l] + ft1 * 16, m.bih[l] + HP + ft1 * 16, m.bih[l] + 2 * HP + ft1 * 16};
+        const __amdgpu_buffer_rsrc_t rs_below = hs_rsrc(l - 1);
+        for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
+          const int row = 16 * tile + (lane & 15);
+          f32x4 gi[3], bfirst[GBG];
+          rows_first_group<GBG, 1024>(rs_below, stage_off(tile), bfirst);
+          fullk_rows_sc1<3, NKB, GSG, 1024>(s_slot, NKB * 64, bias_ih, rs_below, stage_off(tile), gi, bfirst, 0u, false);
+          if (row < nrows) {
+            const uint32_t go = (uint32_t)(((rbase + row) * 3 * HP + ft1 * 16 + 4 * q) * 4);
+            rs_buf_store_f32x4(rs_gup, go, gi[0]);
+            rs_buf_store_f32x4(rs_gup, go + (uint32_t)(HP * 4), gi[1]);
+            rs_buf_store_f32x4(rs_gup, go + (uint32_t)(2 * HP * 4), gi[2]);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave is done with W_ih: the slot takes W_hh of this layer
+        fill_slot(m.whh[l]);
+        __syncthreads();
+      }
+      // ---- GRU of layer l: h' = gru(gi, W_hh h_src + b_hh) -> dst slot (layer l) and hst[l & 1]
+      {
+        const float* bias_hh[3] = {m.bhh[l] + ft1 * 16, m.bhh[l] + HP + ft1 * 16, m.bhh[l] + 2 * HP + ft1 * 16};
+        const uint32_t lay = (uint32_t)(l * HP * 4);
+        const __amdgpu_buffer_rsrc_t rs_out = hs_rsrc(l);
+        int tile = tpar1 + SH1 * w;
+        RowHead rh{0, 0, 0, 0};
+        long frame = 0;
+        uint32_t hoff = h1_off + lay;
+        f32x4 bfirst[GBG];
+        auto fetch_head = [&](int tl, RowHead& h_, long& f_, uint32_t& o_) {
+          const int row = 16 * tl + (lane & 15);
+          const int use = rbase + (row < nrows ? row : 16 * tl);  // (a tile's first row always exists)
+          h_ = load_row_head(rs_rows, use);
+          f_ = load_row_frame(rs_rows, use);
+          o_ = h_.src >= 0 ? (uint32_t)((((size_t)h_.utt * S + h_.src) * depth * HP) * 4) + lay : h1_off + lay;
+        };
+        if (tile < nrt) {
+          fetch_head(tile, rh, frame, hoff);
+          rows_first_group<GBG, 64>(rs_hid, hoff, bfirst);
+        }
+        while (tile < nrt) {
+          const int next = tile + SH1 * 8;
+          const bool has_next = next < nrt;
+          RowHead rh_n{0, 0, 0, 0};
+          long frame_n = 0;
+          uint32_t hoff_n = h1_off + lay;
+          if (has_next) fetch_head(next, rh_n, frame_n, hoff_n);
+          const int row = 16 * tile + (lane & 15);
+          const bool valid = row < nrows;
+          const int j4 = ft1 * 16 + 4 * q;
+          f32x4 gir, giz, gin;
+          if (l == 0) {
+            const float* gi = st.gi0 + (size_t)frame * (3 * HP);
+            gir = *reinterpret_cast<const f32x4*>(gi + j4);
+            giz = *reinterpret_cast<const f32x4*>(gi + HP + j4);
+            gin = *reinterpret_cast<const f32x4*>(gi + 2 * HP + j4);
+          } else {  // (written a moment ago by this very wave, but last step's line may sit in this CU's L1)
+            const uint32_t go = (uint32_t)(((rbase + (valid ? row : 16 * tile)) * 3 * HP + j4) * 4);
+            gir = load_sc1(rs_gup, go);
+            giz = load_sc1(rs_gup, go + (uint32_t)(HP * 4));
+            gin = load_sc1(rs_gup, go + (uint32_t)(2 * HP * 4));
+          }
+          const f32x4 hprev = load_sc1(rs_hid, hoff + (uint32_t)(j4 * 4));
+          f32x4 gh[3];
+          fullk_rows_sc1<3, NKB, GSG, 64>(s_slot, NKB * 64, bias_hh, rs_hid, hoff, gh, bfirst, hoff_n, has_next);
+          if (valid) {
+            f32x4 out;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
+            rs_buf_store_f32x4(rs_hid, (uint32_t)((((size_t)rh.utt * S + rh.dst) * depth * HP + j4) * 4) + lay, out);
+            rs_buf_store_f32x4(rs_out, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, out);
+          }
+          tile = next; rh = rh_n; frame = frame_n; hoff = hoff_n;
+        }
+      }
+      // every rank's slice of h'_l has to be there before anybody streams it
+      xcd_arrive(st, cluster, s_ctl);
+      if (l + 1 == depth) {
+        for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w1g[e];  // linear_mean1's slice, in the barrier's shadow
+      } else {
+        fill_slot(m.wih[l + 1]);  // (this workgroup's waves are past the GRU: the slot is free)
+      }
+      if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+    }
+
+    // ---- linear_mean1 + relu -> a1 (hand-off layout)
+    const __amdgpu_buffer_rsrc_t rs_top = hs_rsrc(depth - 1);
+    for (int tile = tpar1 + SH1 * w; tile < nrt; tile += SH1 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      f32x4 v[1], bfirst1[GBH];
+      rows_first_group<GBH, 1024>(rs_top, stage_off(tile), bfirst1);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_1, rs_top, stage_off(tile), v, bfirst1, 0u, false);
+      if (row < nrows) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[0][i] = v[0][i] > 0.0f ? v[0][i] : 0.0f;
+        rs_buf_store_f32x4(rs_a1, (uint32_t)((((int)tile0 + tile) * NFT1 + ft1) * 256 + (lane & 15) * 16 + 4 * q) * 4u, v[0]);
+      }
+    }
+    xcd_arrive(st, cluster, s_ctl);
+    for (int e = t; e < NKB * 64; e += 512) s_wm[e] = w2g[e];
+    if (rs_xcd_wait(st, cluster, 32u * ++bar, s_ctl)) return;
+
+    // ---- linear_mean2 + running mean -> dst slot
+    for (int tile = tpar2 + SH2 * w; tile < nrt; tile += SH2 * 8) {
+      const int row = 16 * tile + (lane & 15);
+      const bool valid = row < nrows;
+      const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
+      const int f4 = ft2 * 16 + 4 * q;
+      f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)(((rh.utt * S + rh.src) * DP + f4) * 4));
+      f32x4 v[1], bfirst2[GBH];
+      rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
+      fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
+          if (f4 + i >= m.D) v[0][i] = 0.0f;
+        }
+        rs_buf_store_f32x4(rs_mean, (uint32_t)(((rh.utt * S + rh.dst) * DP + f4) * 4), v[0]);
+      }
+    }
+    if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
+  }
+}
+
 // trace[-N:] of the best hypothesis (uisrnn.py:561) by walking the back-pointers.
 // One wave per utterance.  The walk best hypothesis -> parent -> ... is a chain of N dependent
 // loads (0.15 us each: 157 us for 1000 steps with one thread per utterance).  Here lane l owns
