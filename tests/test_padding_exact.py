@@ -16,8 +16,8 @@ def _bits(a):
 
 def _pad_hidden(params, hp):
   """The same model with rnn_hidden_size hp: the added units have zero weights, biases and initial state."""
-  h = params['rnn_hidden_size']
-  assert params['rnn_depth'] == 1 and hp >= h
+  h, depth = params['rnn_hidden_size'], params['rnn_depth']
+  assert hp >= h
 
   def rows(w):  # [3H, K] -> [3Hp, K], gate by gate (r | z | n, torch.nn.GRU's layout)
     out = np.zeros((3 * hp,) + w.shape[1:], dtype=np.float32)
@@ -32,10 +32,12 @@ def _pad_hidden(params, hp):
 
   p = dict(params)
   p['rnn_hidden_size'] = hp
-  p['gru_weight_ih'] = [rows(params['gru_weight_ih'][0])]
-  p['gru_weight_hh'] = [cols(rows(params['gru_weight_hh'][0]))]
-  p['gru_bias_ih'] = [rows(params['gru_bias_ih'][0])]
-  p['gru_bias_hh'] = [rows(params['gru_bias_hh'][0])]
+  # (layer 0 reads the observation, the upper layers the hidden vector below: their K axis is padded too)
+  p['gru_weight_ih'] = [rows(w) if l == 0 else cols(rows(w)) for l, w in enumerate(params['gru_weight_ih'])]
+  p['gru_weight_hh'] = [cols(rows(w)) for w in params['gru_weight_hh']]
+  p['gru_bias_ih'] = [rows(b) for b in params['gru_bias_ih']]
+  p['gru_bias_hh'] = [rows(b) for b in params['gru_bias_hh']]
+  assert len(p['gru_weight_ih']) == depth
   w1 = np.zeros((hp, hp), dtype=np.float32)
   w1[:h, :h] = params['linear_mean1_weight']
   p['linear_mean1_weight'] = w1
@@ -45,9 +47,9 @@ def _pad_hidden(params, hp):
   return p
 
 
-def _model(dim, hidden, seed):
-  p = weights.init_params(dim, hidden, 1, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=seed)
-  p['rnn_init_hidden'] = (0.2 * np.random.default_rng(seed).standard_normal((1, hidden))).astype(np.float32)
+def _model(dim, hidden, seed, depth=1):
+  p = weights.init_params(dim, hidden, depth, sigma2=0.1, transition_bias=0.2, crp_alpha=1.0, seed=seed)
+  p['rnn_init_hidden'] = (0.2 * np.random.default_rng(seed).standard_normal((depth, hidden))).astype(np.float32)
   return p
 
 
@@ -61,16 +63,16 @@ def _utterances(dim, seed):
   return seqs
 
 
-@pytest.mark.parametrize('dim,hidden,padded', [(20, 200, 256), (33, 130, 256), (20, 100, 128), (16, 70, 128),
-                                              (12, 400, 512), (24, 500, 512)])
-def test_zero_padding_the_hidden_size_inside_a_segment_class_moves_no_bit(dim, hidden, padded, oracle_lib):
-  params = _model(dim, hidden, seed=dim + hidden)
+@pytest.mark.parametrize('dim,hidden,padded,depth', [(20, 200, 256, 1), (33, 130, 256, 1), (20, 100, 128, 1), (16, 70, 128, 1),
+                                                    (12, 400, 512, 1), (24, 500, 512, 1), (20, 100, 128, 2), (12, 200, 256, 3)])
+def test_zero_padding_the_hidden_size_inside_a_segment_class_moves_no_bit(dim, hidden, padded, depth, oracle_lib):
+  params = _model(dim, hidden, seed=dim + hidden, depth=depth)
   twin = _pad_hidden(params, padded)
   rng = np.random.default_rng(hidden)
   for _ in range(4):
     x = rng.standard_normal(dim).astype(np.float32)
-    h0 = rng.standard_normal((1, hidden)).astype(np.float32)
-    h0p = np.zeros((1, padded), dtype=np.float32)
+    h0 = rng.standard_normal((depth, hidden)).astype(np.float32)
+    h0p = np.zeros((depth, padded), dtype=np.float32)
     h0p[:, :hidden] = h0
     mean, hout = oracle_lib.rnn_step(params, x, h0)
     mean_p, hout_p = oracle_lib.rnn_step(twin, x, h0p)
