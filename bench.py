@@ -87,7 +87,8 @@ def flops_per_frame(cfg, clusters=4):
   """algorithmic FLOPs per input frame (test_iteration decode steps each)."""
   dim, hid = cfg['observation_dim'], cfg['rnn_hidden_size']
   beam, look, tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
-  p = 3 * hid * dim + 3 * hid * hid + hid * hid + dim * hid
+  # (every GRU layer: input-side and hidden-side gates; layer 0 reads the observation, the others the layer below)
+  p = 3 * hid * dim + 3 * hid * hid + (cfg['rnn_depth'] - 1) * 6 * hid * hid + hid * hid + dim * hid
   if look == 1:
     per_step = 2.0 * p * beam + 3.0 * dim * beam * (clusters + 1)
   else:
@@ -158,6 +159,8 @@ def parse(argv=None):
   ap.add_argument('--utterances', type=int, default=None, help='utterances per GPU')
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--beam_size', type=int, default=None)
+  ap.add_argument('--rnn_depth', type=int, default=None,
+                  help='GRU layers of the model (not a BASELINE config: the closed-form tracker weights at that depth)')
   ap.add_argument('--ragged', action='store_true',
                   help='utterance lengths uniform in [frames / 2, frames]; the whole job\'s utterances are '
                        'dealt to the ranks by uisrnn_amd.distributed.shard_utterances (longest first)')
@@ -357,7 +360,7 @@ class Workload:
       # (H x H) and linear_mean2 (D x H); the input-side projection is k_dense_input_proj's.
       kernel = prof['decode_kernel']  # named by the library (uis_stats.decode_kernel): its dispatch rule, not a copy of it
       kclass = 'gru'
-      per_row = 2.0 * (3 * hid * hid + hid * hid + dim * hid)
+      per_row = 2.0 * (3 * hid * hid + (cfg['rnn_depth'] - 1) * 6 * hid * hid + hid * hid + dim * hid)
       flop_algo = per_row * prof['rnn_rows_nodedup']
       flop_exec = per_row * prof['rnn_rows']
       algo_bytes = int(4 * (3 * hid * hid + hid * hid + dim * hid) + self.n_utt * n_steps * bps)
@@ -473,9 +476,11 @@ def main(argv=None):
     cfg['frames'] = args.frames
   if args.beam_size is not None:
     cfg['beam_size'] = args.beam_size
-  if args.utterances is not None or args.frames is not None or args.beam_size is not None:
-    cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}]'.format(
-        cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'])
+  if args.rnn_depth is not None:
+    cfg['rnn_depth'] = args.rnn_depth
+  if args.utterances is not None or args.frames is not None or args.beam_size is not None or args.rnn_depth is not None:
+    cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}, rnn_depth {}]'.format(
+        cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'], cfg['rnn_depth'])
   if args.ragged:
     cfg['workload'] += ' [ragged: lengths uniform in [frames / 2, frames], longest-first sharding]'
   big = cfg['utterances_per_gpu'] * cfg['frames'] > 200_000 or cfg['look_ahead'] > 1
@@ -617,7 +622,7 @@ def main(argv=None):
                        'identical: {}'.format(sample, w.n_utt, sample_frames, threads, cpu_s, parity)}
     extras = None
     if (not args.no_extra_configs and world == 1 and on_gpu and args.config == 1 and not args.ragged and
-        args.utterances is None and args.frames is None and args.beam_size is None):
+        args.utterances is None and args.frames is None and args.beam_size is None and args.rnn_depth is None):
       first = w.last
       w_cap = w.cap
       extras = []
