@@ -1072,6 +1072,12 @@ def test_deep_models_decode_in_one_launch(dim, hidden, depth, oracle_lib):
   cap = int(ref['max_clusters'].max()) + 1
   one = dec.decode(frames, offsets, 6, 1, 2, max_clusters=cap, flags=_capi.UIS_FLAG_RESIDENT)
   assert one['status'] == 0 and one['stats']['decode_kernel'] == 'k_decode_deep'
+  # look_ahead 2 / 3 on the deep model: the same kernel with a window sub-step as its select stage
+  _, ref2 = _compare(params, seqs[:5], 4, 2, 1, oracle_lib, decoder=dec)
+  f5, o5 = oracle_lib.pack(seqs[:5])
+  two = dec.decode(f5, o5, 4, 2, 1, max_clusters=int(ref2['max_clusters'].max()) + 2)
+  assert two['status'] == 0 and two['stats']['decode_kernel'] == 'k_decode_deep'
+  _compare(params, seqs[:3], 3, 3, 1, oracle_lib, decoder=dec)
   # CoreRNN.forward through every layer of the padded model
   x = rng.standard_normal(dim).astype(np.float32)
   h0 = rng.standard_normal((depth, hidden)).astype(np.float32)

@@ -779,7 +779,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(a1, (size_t)rows_cap * m.Hp * 4);
   // rnn_depth >= 2 in one launch (k_decode_deep): the cluster kernels' shapes, the select's LDS budget; the
   // two hand-off buffers a layer's h' goes through
-  const bool deep_shape = L == 1 && m.depth >= 2 && G == 1 &&
+  const bool deep_shape = m.depth >= 2 && G == 1 &&
                           ((m.Hp == 512 && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512)) ||
                            (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256)) || (m.Hp == 128 && (m.Dp == 128 || m.Dp == 256)));
   if (deep_shape) ENSURE(hst, (size_t)2 * rows_cap * m.Hp * 4);
@@ -811,7 +811,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // "small" -- goes to them: k_decode_big<WIN> below)
   const bool cluster_shape = m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512);
   // rnn_depth >= 2 at the cluster kernels' shapes: k_decode_big's stages with the weight slot refilled per stage
-  const bool deep = deep_shape && !small_shape && !use_graph && ncl >= 1 && select_fast_ok(B, Kmax, S) &&
+  // (look_ahead >= 2: with the window's sub-step as the select stage, for the shapes instantiated below)
+  const bool deep_win_shape = (m.Hp == 512 && m.Dp == 256) || (m.Hp == 256 && (m.Dp == 128 || m.Dp == 256)) || (m.Hp == 128 && m.Dp == 128);
+  const bool deep = deep_shape && !small_shape && !use_graph && ncl >= 1 &&
+                    (L == 1 ? select_fast_ok(B, Kmax, S)
+                            : deep_win_shape && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 && !getenv("UIS_NO_WINDOW_LAUNCH")) &&
                     !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
                     (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                     ((double)U * S + 1) * m.depth * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.G * 4.0 < 2.0e9 &&
@@ -1216,10 +1220,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     } else if (deep) {
       // h1 of every layer into the extra slot, then ONE launch for every step of every utterance
       HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.depth * m.Hp, m.h1, (size_t)m.depth * m.Hp * 4, hipMemcpyDeviceToDevice, sg));
-      const size_t shmem = deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S);
+      const size_t shmem = L == 1 ? deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S) : big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B);
       decode_kernel = UIS_DK_DEEP;
 #define UIS_DEEP_CASE(HPV, DPV)                                                                                       \
-  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+  if (m.Hp == HPV && m.Dp == DPV && L == 1) {                                                                        \
     void (*kern)(DevModel, DecodeState) = &k_decode_deep<HPV, DPV>;                                                 \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \
@@ -1234,6 +1238,19 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_DEEP_CASE(128, 128)
       UIS_DEEP_CASE(128, 256)
 #undef UIS_DEEP_CASE
+#define UIS_DEEPW_CASE(HPV, DPV)                                                                                      \
+  if (m.Hp == HPV && m.Dp == DPV && L > 1) {                                                                         \
+    void (*kern)(DevModel, DecodeState) = &k_decode_deep<HPV, DPV, true>;                                           \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
+      return rc;                                                                                                     \
+  }
+      UIS_DEEPW_CASE(512, 256)
+      UIS_DEEPW_CASE(256, 256)
+      UIS_DEEPW_CASE(256, 128)
+      UIS_DEEPW_CASE(128, 128)
+#undef UIS_DEEPW_CASE
     } else if (small) {
       const size_t shmem = L == 1 ? small_lds_bytes(m.Dp, B, Kmax, S) : small_win_lds_bytes(S, (int)NC, Kmax, B);
       decode_kernel = UIS_DK_SMALL;

@@ -4110,7 +4110,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 __host__ __device__ inline size_t deep_lds_bytes(int Hp, int Dp, int B, int Kmax, int S) {
   return (size_t)((fast_lds_layout(Dp, B, Kmax, S).total + 255) & ~255) + (size_t)4 * (Hp / 16) * 64 * 16 + 64;
 }
-template <int HP, int DP>
+// WIN: look_ahead >= 2 -- the select stage is a sub-step of the window kernel run by the utterance's owner
+// workgroup, as in k_decode_big<WIN>; its work arrays lie over the weight slot, which is refilled behind it anyway.
+template <int HP, int DP, bool WIN = false>
 __global__ __launch_bounds__(512) void k_decode_deep(DevModel m, DecodeState st) {
   // (m.Hp == HP, m.Dp == DP: the host picks the instantiation; m is NOT written here -- its per-layer pointer
   // arrays are indexed by a run-time layer number and stay in the kernel-argument segment only if it is read-only)
@@ -4124,9 +4126,11 @@ __global__ __launch_bounds__(512) void k_decode_deep(DevModel m, DecodeState st)
   const int cluster = blockIdx.x % ncl, rank = blockIdx.x / ncl;
   const int U = st.U, S = st.S, depth = m.depth;
   const FastLds L = fast_lds_layout(m.Dp, st.B, st.Kmax, S);
-  f32x4* s_slot = reinterpret_cast<f32x4*>(smem_raw + (((size_t)L.total + 255) & ~(size_t)255));  // [3][NKB][64]: W_hh / W_ih of the layer at hand
+  f32x4* s_slot = reinterpret_cast<f32x4*>(smem_raw + (WIN ? (size_t)0 : (((size_t)L.total + 255) & ~(size_t)255)));  // [3][NKB][64]: W_hh / W_ih of the layer at hand
   f32x4* s_wm = s_slot + 3 * NKB * 64;                                                            // [NKB][64]: linear_mean1's slice, then linear_mean2's
-  int* s_ctl = reinterpret_cast<int*>(s_wm + NKB * 64);                                           // [0] abort [1] steps [2] arrived
+  // [0] abort [1] steps [2] arrived (WIN: behind whichever is larger, the window's arrays or the weights)
+  int* s_ctl = WIN ? reinterpret_cast<int*>(smem_raw + big_win_lds_bytes(HP, S, st.NC, st.Kmax, st.B) - 64)
+                   : reinterpret_cast<int*>(s_wm + NKB * 64);
   uint32_t xcc = 0;
   if (t == 0) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -4180,7 +4184,8 @@ __global__ __launch_bounds__(512) void k_decode_deep(DevModel m, DecodeState st)
     const int par = s & 1;
     sink.count = st.rx_nrows + cluster * 32 + par;
     for (int i = rank; cluster + ncl * i < U; i += 32) {
-      select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
+      if constexpr (WIN) window_body<512, true>(m, st, cluster + ncl * i, smem_raw, sink, 0);
+      else select_fast_body<512, true, false, DP>(m, st, par, cluster + ncl * i, smem_raw, sink);
       __syncthreads();
     }
     // (the slot last held W_hh of the top layer: layer 0's goes in while the barrier completes)
