@@ -179,3 +179,11 @@ def test_flop_model_matches_the_survey():
   assert abs(bench.flops_per_frame(bench.CONFIGS[4]) / 1e6 - 167.8) < 0.5
   assert abs(bench.flops_per_frame(bench.CONFIGS[2]) / 1e6 - 944) < 10
   assert bench.bytes_per_step(bench.CONFIGS[1]) == 103504
+  # --rnn_depth (not a BASELINE config): every further GRU layer adds its input-side and hidden-side gates,
+  # 2 x 3 H^2 MACs per hypothesis and step each
+  deep = dict(bench.CONFIGS[1], rnn_depth=2)
+  hid, beam, tau = deep['rnn_hidden_size'], deep['beam_size'], deep['test_iteration']
+  extra = tau * 2.0 * (6 * hid * hid) * beam
+  assert abs(bench.flops_per_frame(deep) - bench.flops_per_frame(bench.CONFIGS[1]) - extra) < 1.0
+  args = bench.parse(['--rnn_depth', '2', '--utterances', '3'])
+  assert args.rnn_depth == 2 and args.utterances == 3
