@@ -137,6 +137,11 @@ typedef struct uis_decode_opts {
                                     cluster-wide barriers between GRU, linear_mean1 and linear_mean2 instead of
                                     the per-producer phase words (a consumer wave waits for the four workgroups
                                     that produce its K-slice); A/B switch, results are bit-identical either way */
+#define UIS_FLAG_NO_COHORTS 0x10000u /* one-launch decode with many utterances per XCD: keep ONE lock-step batch per XCD
+                                    with a cluster barrier behind every stage (k_decode_big<WS>) instead of two
+                                    utterance cohorts whose stages alternate on every workgroup, so that one
+                                    cohort's select and hand-off waits are filled with the other's dense stages
+                                    (k_decode_coh, UIS_DK_BIG_COH); A/B switch, results are bit-identical either way */
 #define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */
@@ -180,7 +185,8 @@ enum {
   UIS_DK_BIG_WS = 5,     /* ... with a rank's selects running concurrently (k_decode_big<WS>) */
   UIS_DK_SMALL = 6,      /* one launch, one workgroup per utterance: small models, any rnn_depth, any look_ahead (k_decode_small) */
   UIS_DK_WINDOW = 7,     /* one launch, look_ahead >= 2: a window sub-step as the select stage (k_decode_big<WIN>) */
-  UIS_DK_DEEP = 8        /* one launch, rnn_depth >= 2 at hidden size 128 / 256 / 512: the weight slot refilled per stage (k_decode_deep) */
+  UIS_DK_DEEP = 8,       /* one launch, rnn_depth >= 2 at hidden size 128 / 256 / 512: the weight slot refilled per stage (k_decode_deep) */
+  UIS_DK_BIG_COH = 9     /* one launch, a wave per row tile, two utterance cohorts in flight per XCD (k_decode_coh) */
 };
 /* ... in bits 16..23 for UIS_DK_RS its instantiation: 1 base, 2 base with the shape of BASELINE configs[1] as
  * compile-time constants, 3 two utterances per wave (9 .. 16 per XCD), 4 wide (beam_size <= 32 / observation

@@ -12,6 +12,8 @@ Nothing here is used by the product; the files it writes under tests/golden/ are
   python tests/golden/make_trained.py predict_d256 1000
   python tests/golden/make_trained.py predict_d512 100 # the configs[4] shape: observation_dim 512, beam 20
   python tests/golden/make_trained.py predict_d256_l2 40 # the configs[2] shape: beam 50, look_ahead 2
+  python tests/golden/make_trained.py predict_d256_l2 120  # ... 2 x 120 frames (round 5)
+  python tests/golden/make_trained.py predict_d512 250     # configs[4] shape, 2 x 250 frames (round 5)
   python tests/golden/make_trained.py wholebox         # reference whole-box CPU rate (8 x 1 thread)
 
 Outputs
@@ -53,10 +55,11 @@ sys.path.insert(0, HERE)
 import make_golden  # noqa: E402  pylint: disable=wrong-import-position
 
 D256_TRAIN_SEED = 5000
-D256_TEST_SEED = {100: 6100, 500: 6500, 1000: 7000, 40: 6040}   # 40: the look_ahead-2 fixture (configs[2] shape)
-D256_TEST_COUNT = {100: 4, 500: 2, 1000: 2, 40: 4}
-D512_TEST_SEED = {100: 8100}   # BASELINE configs[4]: observation_dim 512, beam 20
-D512_TEST_COUNT = {100: 4}
+# 40 / 120: the look_ahead-2 fixtures (configs[2] shape; 120 frames = 240 decode steps, round 5)
+D256_TEST_SEED = {100: 6100, 500: 6500, 1000: 7000, 40: 6040, 120: 6120}
+D256_TEST_COUNT = {100: 4, 500: 2, 1000: 2, 40: 4, 120: 2}
+D512_TEST_SEED = {100: 8100, 250: 8250}   # BASELINE configs[4]: observation_dim 512, beam 20 (250 frames: round 5)
+D512_TEST_COUNT = {100: 4, 250: 2}
 
 
 def _seed_all():

@@ -311,15 +311,61 @@ def test_one_launch_decode_with_more_utterances_than_workgroups(dim, hidden, ora
   frames, offsets = oracle_lib.pack(seqs)
   big = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=_capi.UIS_FLAG_RESIDENT)
   assert big['status'] == 0 and big['stats']['kernel_launches']['select'] == 0
-  for flags in (_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_STEPWISE):
+  # (round 5: two utterance cohorts in flight per XCD where the single-wave select applies -- observation dim <= 256)
+  assert big['stats']['decode_kernel'] == ('k_decode_coh' if dim <= 256 else 'k_decode_big'), big['stats']['decode_kernel']
+  for flags in (_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_STEPWISE,
+                _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_NO_COHORTS, _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_OWNER_SELECT):
     other = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=flags)
     assert np.array_equal(big['labels'], other['labels']), flags
     assert np.array_equal(_bits(big['beam_scores']), _bits(other['beam_scores'])), flags
+    assert np.array_equal(_bits(big['scores']), _bits(other['scores'])), flags
+    assert other['stats']['rnn_rows'] == big['stats']['rnn_rows'], flags
+    if flags & _capi.UIS_FLAG_NO_COHORTS:
+      assert other['stats']['decode_kernel'] == ('k_decode_big<WS>' if dim <= 256 else 'k_decode_big')
   sample = [0, 37, 151, 299]
   ref = oracle_lib.decode(params, [seqs[u] for u in sample], 10, 1, 2, n_threads=4)
   for k, u in enumerate(sample):
     assert np.array_equal(big['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
     assert np.array_equal(_bits(big['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
+
+
+@pytest.mark.parametrize('n_utt,beam,tau', [(1024, 10, 2), (520, 10, 1), (263, 7, 3), (700, 11, 2)])
+def test_two_cohorts_in_flight(n_utt, beam, tau, oracle_lib):
+  """k_decode_coh (round 5): an XCD's utterances in two cohorts whose stages alternate on every workgroup,
+  the selects riding on the other cohort's dense phases, row tiles pulled from LDS counters, no workgroup
+  barrier in the step loop.  Against k_decode_big<WS> (UIS_FLAG_NO_COHORTS: one lock-step batch, a cluster
+  barrier behind every stage) and the launch-per-step path bit for bit -- labels, best scores, whole final
+  beams, executed rows -- and a sample of utterances against the oracle.  Shapes: the configs[3] share's
+  1024 utterances (four per rank, two per cohort), ragged lists whose ranks hold one to three utterances,
+  utterances of one frame, cohorts of unequal size, no de-duplication."""
+  import os
+  from uisrnn_amd import weights
+  params = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d256.uisrnn'))
+  lens = [1 + (11 * u) % 37 for u in range(n_utt)]
+  lens[3] = 1; lens[n_utt - 1] = 1; lens[17] = 60
+  seqs, _ = synth.make_utterances(21_000 + n_utt, n_utt, lens, 256)
+  dec = _capi.Decoder(params)
+  frames, offsets = oracle_lib.pack(seqs)
+  res = _capi.UIS_FLAG_RESIDENT
+  for extra in (0, _capi.UIS_FLAG_NO_DEDUP):
+    coh = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | extra)
+    assert coh['status'] == 0 and coh['stats']['decode_kernel'] == 'k_decode_coh', coh['stats']['decode_kernel']
+    for flags in (res | _capi.UIS_FLAG_NO_COHORTS, _capi.UIS_FLAG_STEPWISE):
+      other = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=flags | extra)
+      assert other['stats']['decode_kernel'] != 'k_decode_coh'
+      assert np.array_equal(coh['labels'], other['labels']), flags
+      assert np.array_equal(_bits(coh['scores']), _bits(other['scores'])), flags
+      assert np.array_equal(_bits(coh['beam_scores']), _bits(other['beam_scores'])), flags
+      assert coh['stats']['rnn_rows'] == other['stats']['rnn_rows'], flags
+      assert coh['stats']['candidates'] == other['stats']['candidates'], flags
+  sample = [0, 3, 17, n_utt // 2, n_utt - 2, n_utt - 1]
+  ref = oracle_lib.decode(params, [seqs[u] for u in sample], beam, 1, tau, n_threads=6)
+  for k, u in enumerate(sample):
+    assert np.array_equal(coh['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
+    assert np.array_equal(_bits(coh['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
+  # the same handle again (control words, counters and LDS state are per launch): identical
+  again = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | _capi.UIS_FLAG_NO_DEDUP)
+  assert np.array_equal(again['labels'], coh['labels']) and np.array_equal(_bits(again['beam_scores']), _bits(coh['beam_scores']))
 
 
 def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):

@@ -39,6 +39,7 @@ UIS_FLAG_OWNER_SELECT = 0x800
 UIS_FLAG_REPLICATED_SELECT = 0x1000
 UIS_FLAG_DEBUG_SCORES = 0x2000
 UIS_FLAG_CLUSTER_BARRIERS = 0x8000
+UIS_FLAG_NO_COHORTS = 0x10000
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
@@ -47,7 +48,7 @@ KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
 # uis_stats.decode_kernel (UIS_DK_* | UIS_DF_* << 8): the kernel family that ran the decode steps
 DECODE_KERNELS = {0: 'none', 1: 'stepwise', 2: 'k_decode_rs', 3: 'k_decode_resident', 4: 'k_decode_big',
                   5: 'k_decode_big<WS>', 6: 'k_decode_small',
-                  7: 'k_decode_big<WIN>', 8: 'k_decode_deep'}
+                  7: 'k_decode_big<WIN>', 8: 'k_decode_deep', 9: 'k_decode_coh'}
 DENSE_FAMILIES = {0: '', 1: 'k_dense', 2: 'k_big', 3: 'k_wt'}
 
 

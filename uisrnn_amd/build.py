@@ -17,6 +17,7 @@ DEPENDS = SOURCES + [
     os.path.join(_HERE, 'csrc', 'uis_kernels.hip'),
     os.path.join(_HERE, 'csrc', 'uis_kernels.h'),
     os.path.join(_HERE, 'csrc', 'uis_select_rs.hip'),
+    os.path.join(_HERE, 'csrc', 'uis_decode_coh.hip'),
     os.path.join(_HERE, 'csrc', 'uis_eval.hip'),
     os.path.join(_ROOT, 'include', 'uis_numerics.h'),
     os.path.join(_ROOT, 'include', 'uisrnn_hip.h'),

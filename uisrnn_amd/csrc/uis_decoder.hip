@@ -770,7 +770,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const int ncl = (h->n_cu >= 32 && h->n_cu % 32 == 0 && h->n_cu / 32 <= UIS_MAX_CLUSTERS) ? h->n_cu / 32 : 0;
   const int nclq = std::max(ncl, 1);
   // (rows an utterance can emit per step: beam_size, or a level's capacity inside a look-ahead window)
-  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * (L == 1 ? (long)B : (long)NC) + 15) / 16 * 16);
+  // (+ 16 at look_ahead 1: k_decode_coh cuts a cluster's region into two cohorts, each rounded up to a row tile)
+  const int rx_stride = (int)(((((long)U + nclq - 1) / nclq) * (L == 1 ? (long)B : (long)NC) + 15) / 16 * 16) + (L == 1 ? 16 : 0);
   const long rows_cap = std::max(max_rows + 48L * G, (long)nclq * rx_stride);  // every group's last row tile may run past its rows
   ENSURE(rows, (size_t)rows_cap * sizeof(RnnRow));
   ENSURE(nrows, (size_t)UIS_MAX_GROUPS * 2 * 4);
@@ -1114,20 +1115,41 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       const bool big_ws = big && !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
                           rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
                           big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+      // ... and, where that kernel applies, two utterance cohorts in flight per XCD (k_decode_coh: a cohort's select
+      // and hand-off waits filled with the other cohort's dense stages); UIS_FLAG_NO_COHORTS keeps the lock-step batch
+      const bool coh = big_ws && !(opts->flags & UIS_FLAG_NO_COHORTS) && !getenv("UIS_NO_COHORTS") &&
+                       coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
       const bool rs_two = rs_kind == RS_UPW2 || rs_kind == RS_UPW2_C1, rs_wide = rs_kind == RS_WIDE || rs_kind == RS_WIDE_C4;
       const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_two ? 2 : 1, rs_two || rs_wide)
+                                            : coh    ? coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
                                             : big_ws ? big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
                                             : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
                                             96 * 1024);  // one workgroup per CU
-      decode_kernel = rs ? (UIS_DK_RS | (rs_kind << 16)) : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
+      decode_kernel = rs ? (UIS_DK_RS | (rs_kind << 16)) : coh ? UIS_DK_BIG_COH : big_ws ? UIS_DK_BIG_WS : big ? UIS_DK_BIG : UIS_DK_RESIDENT;
       // the shapes of BASELINE's configs as compile-time constants (unpadded models only; UIS_NO_SHAPE_CLASSES=1
       // keeps the run-time instantiations: A/B switch, bit-identical)
       const bool exact = m.D == m.Dp && m.H == m.Hp && !getenv("UIS_NO_SHAPE_CLASSES");
       const bool cls_c1 = exact && m.Hp == 512 && m.Dp == 256 && B == 10 && Kmax == 16;   // configs[1] / [3]: beam 10, cap 16
       const bool cls_c4 = exact && m.Hp == 512 && m.Dp == 512 && B == 20 && Kmax == 11;   // configs[4]: beam 20, cap 11
+#define UIS_COH_CASE(HPV, DPV, COND, ...)                                                                             \
+  if (m.Hp == HPV && m.Dp == DPV && coh && (COND)) {                                                                 \
+    void (*kern)(DevModel, DecodeState) = &k_decode_coh<HPV, DPV, ##__VA_ARGS__>;                                    \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                               (int)shmem));                                                                         \
+    if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st)))           \
+      return rc;                                                                                                     \
+  }
+      UIS_COH_CASE(512, 256, cls_c1, 10, 16)
+      UIS_COH_CASE(512, 256, !cls_c1)
+      UIS_COH_CASE(512, 128, true)
+      UIS_COH_CASE(256, 256, true)
+      UIS_COH_CASE(256, 128, true)
+      UIS_COH_CASE(128, 256, true)
+      UIS_COH_CASE(128, 128, true)
+#undef UIS_COH_CASE
 #define UIS_BIGWS_CASE(HPV, DPV, COND, ...)                                                                           \
-  if (m.Hp == HPV && m.Dp == DPV && big_ws && (COND)) {                                                              \
+  if (m.Hp == HPV && m.Dp == DPV && big_ws && !coh && (COND)) {                                                              \
     void (*kern)(DevModel, DecodeState) = &k_decode_big<HPV, DPV, true, ##__VA_ARGS__>;                              \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \
@@ -1382,7 +1404,22 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       fprintf(stderr, "\n");
     }
   }
-  if (resident) {
+  if (resident && (decode_kernel & 0xff) == UIS_DK_BIG_COH) {  // k_decode_coh: waves 0 (cohort A), 1 (cohort B) and 7 (no utterance at <= 7 per rank) of workgroup 0
+    unsigned long long tc[96];
+    HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
+    static const char* names[16] = {"wait gruA", "wait gruB", "wait m1A", "wait m1B", "wait m2A", "wait m2B", "gruA", "gruB", "m1A", "m1B",
+                                    "m2A", "m2B", "select", "slot", "arrive", "early mse"};
+    for (int k3 = 0; k3 < 3; ++k3) {
+      fprintf(stderr, "[cohort timing] workgroup 0 wave %d, us per step:", k3 == 0 ? 0 : k3 == 1 ? 1 : 7);
+      double sum = 0.0;
+      for (int k = 0; k < 16; ++k) {
+        const double us = (double)tc[48 + 16 * k3 + k] * 0.01 / (double)maxT;
+        fprintf(stderr, " %s=%.2f", names[k], us);
+        sum += us;
+      }
+      fprintf(stderr, " | total=%.2f\n", sum);
+    }
+  } else if (resident) {
     unsigned long long tc[88];
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
     static const char* names[8] = {"select", "barA", "gru", "barB", "head1", "barC", "head2", "barD"};

@@ -4098,6 +4098,8 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   }
 }
 
+#include "uis_decode_coh.hip"
+
 // rnn_depth >= 2 in ONE launch (round 4): k_decode_big's grid, barriers and wave-per-row-tile stages with one
 // more pair of stages per upper layer.  A workgroup's 96 KB weight slot cannot hold W_hh of every layer and
 // W_ih of the upper ones, so the slot is REFILLED stage by stage from L2 / the Infinity Cache (the price of

@@ -346,6 +346,55 @@ __device__ __forceinline__ RsPrep<NPOS> rs_prep(const DevModel& m, const DecodeS
   return P;
 }
 
+// The weighted MSE of frame row `frame` against the cluster means in the slots of `mask` (utterance u), by one
+// wave: the slots compacted into a list, 16 lanes per mean, eight means in flight per pass; one float per slot
+// into the wave's scratch (sc_mse).  The FULL select's first part; a caller may run it EARLY for the slots
+// the step in flight does not rewrite (their means are final) and leave the rewritten ones to rs_front.
+template <int DP>
+__device__ __forceinline__ void rs_full_mse(const DecodeState& st, const RsLds& L, const RsDims dm, int u, long frame,
+                                            unsigned char* scr, const unsigned long long (&mask)[4], const float* swgt_full) {
+  int lane_ = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane_));
+  const int lane = lane_;
+  const int S = dm.S;
+  float* smse = reinterpret_cast<float*>(scr + L.sc_mse);
+  unsigned char* s_list = scr + L.sc_list;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (64 * k < S) {
+      const bool on = (mask[k] >> lane) & 1ull;
+      if (on) s_list[n + rs_below(mask[k])] = (unsigned char)(lane + 64 * k);
+      n += __popcll(mask[k]);
+    }
+  }
+  rs_lds_fence();
+  if (n > 0) {
+    constexpr int NV = 4 * ((DP + 255) / 256);
+    const __amdgpu_buffer_rsrc_t rs_mean =
+        __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+    const int grp = lane >> 4, p = lane & 15;
+    f32x4 xv[NV];
+    rs_load_frame16<DP>(st.x + (size_t)frame * DP, p, xv);
+    for (int i0 = 0; i0 < n; i0 += 8) {
+      f32x4 mv[2][NV];
+      int sl[2];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int i = i0 + 4 * h2 + grp;
+        sl[h2] = (int)s_list[i < n ? i : 0];
+        rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl[h2], p, mv[h2]);
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const float v = rs_mse16_regs<DP>(dm.D, mv[h2], xv, swgt_full, p);
+        if (p == 0 && i0 + 4 * h2 + grp < n) smse[sl[h2]] = v;
+      }
+    }
+  }
+  rs_lds_fence();
+}
+
 // FRONT: the MSEs, scores, prune, winners, rows -- what the step's dense stages wait for.  One wave
 // (all 64 lanes), utterance u, decode step `step` whose frame is row `frame` of the stream.  pers =
 // the utterance's persistent block, scr = its scratch (rs_prep left the free slots there).
@@ -384,42 +433,9 @@ __device__ __forceinline__ RsWin rs_front(const DevModel& m, const DecodeState& 
   const unsigned long long old[4] = {P.old0, P.old1, P.old2, P.old3};
   const float mse_new = st.mse0[frame];
   if (FULL) {
-    // ---- every live cluster's MSE from its mean: the live slots compacted into a list, 16 lanes
-    // per mean, eight means in flight per pass
-    unsigned char* s_list = scr + L.sc_list;
-    int n = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (64 * k < S) {
-        const bool on = (old[k] >> lane) & 1ull;
-        if (on) s_list[n + rs_below(old[k])] = (unsigned char)(lane + 64 * k);
-        n += __popcll(old[k]);
-      }
-    }
-    rs_lds_fence();
-    if (n > 0) {
-      constexpr int NV = 4 * ((DP + 255) / 256);
-      const __amdgpu_buffer_rsrc_t rs_mean =
-          __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
-      const int grp = lane >> 4, p = lane & 15;
-      f32x4 xv[NV];
-      rs_load_frame16<DP>(st.x + (size_t)frame * DP, p, xv);
-      for (int i0 = 0; i0 < n; i0 += 8) {
-        f32x4 mv[2][NV];
-        int sl[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const int i = i0 + 4 * h2 + grp;
-          sl[h2] = (int)s_list[i < n ? i : 0];
-          rs_load_mean16<DP>(rs_mean, (size_t)u * S + sl[h2], p, mv[h2]);
-        }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const float v = rs_mse16_regs<DP>(dm.D, mv[h2], xv, swgt_full, p);
-          if (p == 0 && i0 + 4 * h2 + grp < n) smse[sl[h2]] = v;
-        }
-      }
-    }
+    // ---- every live cluster's MSE from its mean (P.old*: the slots whose MSE is still to be computed -- all live
+    // ones, unless the caller ran rs_full_mse on some of them earlier)
+    rs_full_mse<DP>(st, L, dm, u, frame, scr, old, swgt_full);
   } else {
   // ---- ONE round trip: the fresh-cluster MSE, the published MSEs of the clusters the previous
   // step left alone, and for the ones it rewrote the tile sums its linear_mean2 epilogue emitted
