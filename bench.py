@@ -435,8 +435,10 @@ def run_extra_config(index, args, rank, dev, dev_index, sync_fn):
   roof = w.roofline(rate)
   # parity against the oracle on a sample it finishes in seconds (wide beams: truncated utterances)
   threads = min(os.cpu_count() or 1, 64)
-  sample = min(w.n_utt, 4 if w.look > 1 else 8)
-  cut = 60 if w.look > 1 else min(cfg['frames'], 250)
+  # (round 5: 16 utterances x 200 frames at look_ahead 2 -- one oracle thread per utterance, about 15 s -- and 16 x 250
+  # otherwise; rounds 2-4 checked 4 x 60 and 8 x 250)
+  sample = min(w.n_utt, 16)
+  cut = min(cfg['frames'], 200 if w.look > 1 else 250)
   cpu_s, parity, _ = w.oracle_check(sample, cut, threads)
   out = {'config': index, 'workload': cfg['workload'], 'value': round(rate, 1), 'unit': 'frames/s',
          'ms_per_step': round(1e3 * el / steps, 3), 'steps': steps, 'setup_passes': passes,

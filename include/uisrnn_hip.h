@@ -137,11 +137,12 @@ typedef struct uis_decode_opts {
                                     cluster-wide barriers between GRU, linear_mean1 and linear_mean2 instead of
                                     the per-producer phase words (a consumer wave waits for the four workgroups
                                     that produce its K-slice); A/B switch, results are bit-identical either way */
-#define UIS_FLAG_NO_COHORTS 0x10000u /* one-launch decode with many utterances per XCD: keep ONE lock-step batch per XCD
-                                    with a cluster barrier behind every stage (k_decode_big<WS>) instead of two
-                                    utterance cohorts whose stages alternate on every workgroup, so that one
-                                    cohort's select and hand-off waits are filled with the other's dense stages
-                                    (k_decode_coh, UIS_DK_BIG_COH); A/B switch, results are bit-identical either way */
+#define UIS_FLAG_COHORTS 0x10000u /* one-launch decode with many utterances per XCD (where k_decode_big<WS> applies): run an
+                                    XCD's utterances as TWO cohorts whose stages alternate on every workgroup, the selects
+                                    riding on the other cohort's dense phases, row tiles pulled from LDS counters, no
+                                    workgroup barrier in the step loop (k_decode_coh, UIS_DK_BIG_COH).  Bit-identical;
+                                    measured SLOWER than the lock-step batch on MI355X (3.8 against 4.0 M frames/s at
+                                    1024 utterances: DESIGN.md / LABNOTES.md), hence opt-in: an A/B switch             */
 #define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */

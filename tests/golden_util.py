@@ -30,6 +30,9 @@ TRAINED_CASES = {
     'trained_d256_n1000': 'trained_d256.uisrnn',
     'trained_d512_n100': 'trained_d512.uisrnn',
     'trained_d256_l2_n40': 'trained_d256.uisrnn',
+    # round 5: the configs[2] shape (beam 50, look_ahead 2) over 2 x 120 frames and the configs[4] shape (D 512, beam 20) over 2 x 250
+    'trained_d256_l2_n120': 'trained_d256.uisrnn',
+    'trained_d512_n250': 'trained_d512.uisrnn',
 }
 
 

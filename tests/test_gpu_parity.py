@@ -311,17 +311,17 @@ def test_one_launch_decode_with_more_utterances_than_workgroups(dim, hidden, ora
   frames, offsets = oracle_lib.pack(seqs)
   big = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=_capi.UIS_FLAG_RESIDENT)
   assert big['status'] == 0 and big['stats']['kernel_launches']['select'] == 0
-  # (round 5: two utterance cohorts in flight per XCD where the single-wave select applies -- observation dim <= 256)
-  assert big['stats']['decode_kernel'] == ('k_decode_coh' if dim <= 256 else 'k_decode_big'), big['stats']['decode_kernel']
+  assert big['stats']['decode_kernel'] == ('k_decode_big<WS>' if dim <= 256 else 'k_decode_big'), big['stats']['decode_kernel']
+  # (round 5: UIS_FLAG_COHORTS = two utterance cohorts in flight per XCD, k_decode_coh, where the single-wave select applies)
   for flags in (_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_STEPWISE,
-                _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_NO_COHORTS, _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_OWNER_SELECT):
+                _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_COHORTS, _capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_OWNER_SELECT):
     other = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True, flags=flags)
     assert np.array_equal(big['labels'], other['labels']), flags
     assert np.array_equal(_bits(big['beam_scores']), _bits(other['beam_scores'])), flags
     assert np.array_equal(_bits(big['scores']), _bits(other['scores'])), flags
     assert other['stats']['rnn_rows'] == big['stats']['rnn_rows'], flags
-    if flags & _capi.UIS_FLAG_NO_COHORTS:
-      assert other['stats']['decode_kernel'] == ('k_decode_big<WS>' if dim <= 256 else 'k_decode_big')
+    if flags & _capi.UIS_FLAG_COHORTS:
+      assert other['stats']['decode_kernel'] == ('k_decode_coh' if dim <= 256 else 'k_decode_big')
   sample = [0, 37, 151, 299]
   ref = oracle_lib.decode(params, [seqs[u] for u in sample], 10, 1, 2, n_threads=4)
   for k, u in enumerate(sample):
@@ -331,13 +331,14 @@ def test_one_launch_decode_with_more_utterances_than_workgroups(dim, hidden, ora
 
 @pytest.mark.parametrize('n_utt,beam,tau', [(1024, 10, 2), (520, 10, 1), (263, 7, 3), (700, 11, 2)])
 def test_two_cohorts_in_flight(n_utt, beam, tau, oracle_lib):
-  """k_decode_coh (round 5): an XCD's utterances in two cohorts whose stages alternate on every workgroup,
-  the selects riding on the other cohort's dense phases, row tiles pulled from LDS counters, no workgroup
-  barrier in the step loop.  Against k_decode_big<WS> (UIS_FLAG_NO_COHORTS: one lock-step batch, a cluster
-  barrier behind every stage) and the launch-per-step path bit for bit -- labels, best scores, whole final
-  beams, executed rows -- and a sample of utterances against the oracle.  Shapes: the configs[3] share's
-  1024 utterances (four per rank, two per cohort), ragged lists whose ranks hold one to three utterances,
-  utterances of one frame, cohorts of unequal size, no de-duplication."""
+  """k_decode_coh (round 5, UIS_FLAG_COHORTS: measured slower than the lock-step batch, an opt-in that stays tested):
+  an XCD's utterances in two cohorts whose stages alternate on every workgroup, the selects riding on the other
+  cohort's dense phases, row tiles pulled from LDS counters, no workgroup barrier in the step loop.  Against
+  k_decode_big<WS> (the default: one lock-step batch, a cluster barrier behind every stage) and the
+  launch-per-step path bit for bit -- labels, best scores, whole final beams, executed rows -- and a sample of
+  utterances against the oracle.  Shapes: the configs[3] share's 1024 utterances (four per rank, two per cohort),
+  ragged lists whose ranks hold one to three utterances, utterances of one frame, cohorts of unequal size, no
+  de-duplication."""
   import os
   from uisrnn_amd import weights
   params = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d256.uisrnn'))
@@ -348,11 +349,11 @@ def test_two_cohorts_in_flight(n_utt, beam, tau, oracle_lib):
   frames, offsets = oracle_lib.pack(seqs)
   res = _capi.UIS_FLAG_RESIDENT
   for extra in (0, _capi.UIS_FLAG_NO_DEDUP):
-    coh = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | extra)
+    coh = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | _capi.UIS_FLAG_COHORTS | extra)
     assert coh['status'] == 0 and coh['stats']['decode_kernel'] == 'k_decode_coh', coh['stats']['decode_kernel']
-    for flags in (res | _capi.UIS_FLAG_NO_COHORTS, _capi.UIS_FLAG_STEPWISE):
+    for flags in (res, _capi.UIS_FLAG_STEPWISE):
       other = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=flags | extra)
-      assert other['stats']['decode_kernel'] != 'k_decode_coh'
+      assert other['stats']['decode_kernel'] == ('k_decode_big<WS>' if flags == res else 'stepwise:k_wt' if n_utt * beam > 1280 else 'stepwise:k_dense'), other['stats']['decode_kernel']
       assert np.array_equal(coh['labels'], other['labels']), flags
       assert np.array_equal(_bits(coh['scores']), _bits(other['scores'])), flags
       assert np.array_equal(_bits(coh['beam_scores']), _bits(other['beam_scores'])), flags
@@ -364,8 +365,36 @@ def test_two_cohorts_in_flight(n_utt, beam, tau, oracle_lib):
     assert np.array_equal(coh['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
     assert np.array_equal(_bits(coh['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
   # the same handle again (control words, counters and LDS state are per launch): identical
-  again = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | _capi.UIS_FLAG_NO_DEDUP)
+  again = dec.decode(frames, offsets, beam, 1, tau, want_beam_scores=True, flags=res | _capi.UIS_FLAG_COHORTS | _capi.UIS_FLAG_NO_DEDUP)
   assert np.array_equal(again['labels'], coh['labels']) and np.array_equal(_bits(again['beam_scores']), _bits(coh['beam_scores']))
+
+
+def test_dispatch_crossovers_name_their_kernels(oracle_lib):
+  """Which one-launch kernel decodes how many utterances (uis_stats.decode_kernel; the library's rule, retuned in
+  round 5 from profiles/r05_usweep_dispatch.json): at most 8 per XCD the replicated select, up to 20 per XCD the
+  owner-select kernel, from 21 on the wave-per-row-tile kernel with concurrent single-wave selects; where those
+  do not apply (observation dim 512) the owner-select kernel up to 32 per XCD.  Every batch against the
+  launch-per-step path bit for bit."""
+  import os
+  from uisrnn_amd import weights
+  ncl = 8  # (a whole MI355X: 256 compute units in clusters of 32)
+  cases = [('trained_d256.uisrnn', 256, 10, 16, [(8 * ncl, 'k_decode_rs'), (8 * ncl + 1, 'k_decode_resident'), (20 * ncl, 'k_decode_resident'),
+                                                 (20 * ncl + 1, 'k_decode_big<WS>'), (32 * ncl + 1, 'k_decode_big<WS>')]),
+           ('trained_d512.uisrnn', 512, 20, 11, [(8 * ncl + 1, 'k_decode_resident'), (32 * ncl, 'k_decode_resident'), (32 * ncl + 1, 'k_decode_big')])]
+  for ckpt, dim, beam, cap, points in cases:
+    params = weights.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, ckpt))
+    dec = _capi.Decoder(params)
+    import torch  # (only for the device's compute-unit count)
+    if torch.cuda.get_device_properties(0).multi_processor_count != 32 * ncl:
+      pytest.skip('not a whole MI355X')
+    for n_utt, want in points:
+      lens = [3 + (5 * u) % 9 for u in range(n_utt)]
+      seqs, _ = synth.make_utterances(31_000 + n_utt, n_utt, lens, dim)
+      frames, offsets = oracle_lib.pack(seqs)
+      one = dec.decode(frames, offsets, beam, 1, 1, max_clusters=cap, want_beam_scores=True)
+      assert one['status'] == 0 and one['stats']['decode_kernel'] == want, (n_utt, one['stats']['decode_kernel'], want)
+      step = dec.decode(frames, offsets, beam, 1, 1, max_clusters=cap, want_beam_scores=True, flags=_capi.UIS_FLAG_STEPWISE)
+      assert np.array_equal(one['labels'], step['labels']) and np.array_equal(_bits(one['beam_scores']), _bits(step['beam_scores'])), n_utt
 
 
 def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):

@@ -29,8 +29,8 @@ def draw(rng):
     depth = 1
     look = int(rng.choice([1, 1, 1, 2, 2, 3]))   # look_ahead >= 2: k_decode_big<WIN>
     beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select
-    # (257 and more: k_decode_coh -- two utterance cohorts in flight -- where the single-wave select applies, k_decode_big elsewhere)
-    n_utt = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 64, 70, 100, 128, 257, 300, 530]))
+    # (161 and more: k_decode_big<WS> where the single-wave select applies -- and k_decode_coh with UIS_FLAG_COHORTS --, 257 and more: k_decode_big elsewhere)
+    n_utt = int(rng.choice([1, 2, 5, 8, 9, 17, 33, 64, 70, 100, 128, 170, 257, 300, 530]))
     if look > 1:
       beam = int(rng.integers(1, 13 if look == 2 else 7))
       n_utt = int(rng.choice([1, 3, 8, 9, 40, 64, 70, 270]))
@@ -74,7 +74,7 @@ def main():
     tag = (dim, hid, depth, beam, look, tau, lengths, seed)
     flag_sets = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_OWNER_SELECT,
                  _capi.UIS_FLAG_REPLICATED_SELECT,  # every class of k_decode_rs, also where it is not the default
-                 _capi.UIS_FLAG_NO_COHORTS,         # k_decode_big<WS> where k_decode_coh is the default
+                 _capi.UIS_FLAG_COHORTS,            # k_decode_coh (two cohorts in flight) where k_decode_big<WS> is the default
 
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]

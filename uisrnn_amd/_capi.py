@@ -39,7 +39,7 @@ UIS_FLAG_OWNER_SELECT = 0x800
 UIS_FLAG_REPLICATED_SELECT = 0x1000
 UIS_FLAG_DEBUG_SCORES = 0x2000
 UIS_FLAG_CLUSTER_BARRIERS = 0x8000
-UIS_FLAG_NO_COHORTS = 0x10000
+UIS_FLAG_COHORTS = 0x10000
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',

@@ -31,6 +31,18 @@
 //     mean1-B / mean2-B, refills the 32 KB mean-head weight slot while the other seven waves go on
 //     (the refill behind mean2-B hides behind the two GRU phases; the one behind mean1-B is exposed);
 //   * no workgroup barrier inside the step loop at all.
+//
+// MEASURED (round 5, configs[3] share, one MI355X, profiles/r05_coh_*): bit-identical, and SLOWER than
+// k_decode_big<WS>: 3.77 M frames/s against 4.03 M (this form), 3.68 M with the selects' old-cluster MSEs computed a
+// phase early and the next phase's counter prefetched, 3.82 M as three merged phases with cohort A's tiles before
+// cohort B's (tools/experiments/r05_cohorts_three_phases.patch).  The stage clocks say why: a workgroup runs two
+// waves per SIMD (256 registers each), and a wave that runs a select is a wave that takes no row tiles -- its
+// partner alone does not keep the SIMD's MFMA pipe busy, the select itself takes 14-22 us next to tile waves
+// instead of 6.3 alone, and six phase starts per step (counter look, tile pull, descriptor and row round trips,
+// store drain) cost more than the four barriers they replace: fixed cost per step 45 us against 18 (257
+// utterances: 71 against 47 us per step).  The hand-off waits do disappear (0.4-1.4 us each); what they were
+// hiding was not idle MFMA time that another cohort could use, but the wave slots.  Hence OPT-IN
+// (UIS_FLAG_COHORTS), kept as a tested experiment; k_decode_big<WS> stays the default.
 #pragma once
 
 // LDS: the select part of k_decode_big<WS> | W_hh slice | mean-head slot | control words
@@ -194,7 +206,6 @@ __global__ __launch_bounds__(512) void k_decode_coh(DevModel m, DecodeState st) 
   const float* bias_1[1] = {m.b1 + ft1 * 16};
   const float* bias_2[1] = {m.b2 + ft2 * 16};
   int nrows_c0 = 0, nrows_c1 = 0;
-  bool early_w = false;  // this wave's scratch holds the early MSEs of its utterance's next select
 
 #if defined(UIS_RESIDENT_TIMING)
   // [ph] dependency wait, [6 + ph] tiles, [12] select (with its wait), [13] slot wait, [14] arrival (store drain, refill)
@@ -219,20 +230,12 @@ __global__ __launch_bounds__(512) void k_decode_coh(DevModel m, DecodeState st) 
         const long frame_w = off0_w + fpos_w;
         const RsDims dm{st.B, st.Kmax, S, m.D};
         RsPrep<3> prep;
-        if (act_w) {
-          prep = rs_prep<true, 3>(m, st, RL, dm, s_sel, pers_w, scr_w, ws_lblk, ws_lden, []() {});
-          if (early_w) {  // the MSEs of the clusters the step in flight does not rewrite are in the scratch already (below)
-            const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_new);
-            prep.old0 &= snew[0]; prep.old1 &= snew[1]; prep.old2 &= snew[2]; prep.old3 &= snew[3];
-          }
-        }
-        early_w = false;
+        if (act_w) prep = rs_prep<true, 3>(m, st, RL, dm, s_sel, pers_w, scr_w, ws_lblk, ws_lden, []() {});
         // every workgroup is through with this cohort's linear_mean2 of step s_sel - 1 (the means it reads,
         // the slots it reuses, the row list and hand-off tiles it overwrites)
         if (coh_wait(st, dbar + cw, 96u * (uint32_t)s_sel, &s_ctl[COH_SEEN + cw])) return;
         RsWin win;
         win.keep = 0; win.C = 0; win.nlead = 0; win.a = 0u; win.b = 0u; win.c = 0u; win.score = 0.0f;
-        __builtin_amdgcn_s_setprio(2);  // (the cohort's next GRU phase waits for this; the waves around it run the other cohort's tiles)
         if (act_w) {
           win = rs_front<DP, true, 3>(m, st, RL, dm, u_w, s_sel, frame_w, pers_w, scr_w, rs_mean /* unused: FULL */, 0u, prep, nullptr, ws_swgt);
           int row_base = 0;
@@ -245,7 +248,6 @@ __global__ __launch_bounds__(512) void k_decode_coh(DevModel m, DecodeState st) 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have reached L2
         if (lane == 0) (void)__hip_atomic_fetch_add(selbar + cw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_s_setprio(0);
         if (act_w) {
           rs_back<3>(m, st, RL, dm, u_w, s_sel, off0_w, pers_w, true, win, []() {});
           fpos_w = fpos_w + 1 == N_w ? 0 : fpos_w + 1;
@@ -253,18 +255,6 @@ __global__ __launch_bounds__(512) void k_decode_coh(DevModel m, DecodeState st) 
         CSTAMP(12);
       }
       if (s < 0) continue;
-      // ---- ... and, one phase before its select, the part of it that waits for nobody: the weighted MSEs of the
-      // next frame against the clusters this step does NOT rewrite (their means have been final since the step
-      // before; what the select itself still has to compute is the at most beam_size rewritten ones)
-      if (has_u && ph == 4 + cw && (long)(s + 1) < T_w) {
-        const unsigned long long* slive = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_live);
-        const unsigned long long* snew = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_new);
-        const unsigned long long keep[4] = {slive[0] & ~snew[0], 64 < S ? slive[1] & ~snew[1] : 0ull,
-                                            128 < S ? slive[2] & ~snew[2] : 0ull, 192 < S ? slive[3] & ~snew[3] : 0ull};
-        rs_full_mse<DP>(st, RL, RsDims{st.B, st.Kmax, S, m.D}, u_w, off0_w + fpos_w, scr_w, keep, ws_swgt);
-        early_w = true;
-        CSTAMP(15);
-      }
 
       // ---- this phase's dependency: the cohort's previous stage, in every workgroup of the XCD
       if (kind == 0) {
@@ -389,14 +379,7 @@ __global__ __launch_bounds__(512) void k_decode_coh(DevModel m, DecodeState st) 
       // ---- this wave is through with the phase; the workgroup's last wave says so to the XCD (its own and
       // the other waves' stores have reached L2: every wave drains before it counts itself) and, behind the
       // phases that end a use of the mean-head slot, refills it
-      {  // (a look at the NEXT phase's counter rides on the store drain: that phase's wait then finds it in LDS)
-        const int nk = ph == 5 ? 0 : (ph + 1) >> 1, nc = (ph + 1) & 1, ns = ph == 5 ? s + 1 : s;
-        const uint32_t* nctr = nk == 0 ? selbar + nc : dbar + nc;
-        const uint32_t pre = __hip_atomic_load(nctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t want = nk == 0 ? (uint32_t)(nc ? n_utt1 : n_utt0) * (uint32_t)(ns + 1) : 32u * (uint32_t)(3 * ns + nk);
-        if (lane == 0 && pre >= want) __hip_atomic_store(&s_ctl[COH_SEEN + (nk == 0 ? 2 : 0) + nc], (int)pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (coh_lds_add(&s_ctl[COH_FIN + ph], 1) == 7) {
         if (lane == 0) {
           __hip_atomic_store(&s_ctl[COH_FIN + ph], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -22,8 +22,11 @@
 #include <string>
 #include <thread>
 #include <vector>
-#if !defined(__HIP_DEVICE_COMPILE__)
-#include <emmintrin.h>  // (host pass only: the float64 -> float32 cast below)
+// (host pass only, x86 only: the float64 -> float32 cast below writes around the cache with SSE2 streaming
+// stores; any other host takes the scalar loop, same rounding)
+#if !defined(__HIP_DEVICE_COMPILE__) && (defined(__SSE2__) || defined(__x86_64__))
+#define UIS_HOST_SSE2 1
+#include <emmintrin.h>
 #endif
 
 #include "uis_kernels.hip"
@@ -536,7 +539,7 @@ struct CastTeam {
     const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
     if (b >= nblocks) return false;
     cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows));
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(UIS_HOST_SSE2)
     _mm_sfence();  // (the streaming stores above are ordered before the flag)
 #endif
     done[(size_t)b].store(1, std::memory_order_release);
@@ -551,7 +554,7 @@ struct CastTeam {
       float* d = dst + (size_t)r * D;
       const int64_t n = (e - r) * D;
       int64_t i = 0;
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(UIS_HOST_SSE2)
       // four values per step, written around the cache (cvtpd2ps rounds like the scalar conversion: MXCSR,
       // to nearest even): the float32 block is read next by the copy engine, not by this core, and an
       // ordinary store would first fetch every destination line -- a third more DRAM traffic on the
@@ -820,8 +823,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                     !(opts->flags & (UIS_FLAG_STEPWISE | UIS_FLAG_GENERIC_SELECT)) &&
                     (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
                     ((double)U * S + 1) * m.depth * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.G * 4.0 < 2.0e9 &&
-                    (double)U * S * m.Dp * 4.0 < 2.0e9 && deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 157 * 1024 &&
-                    !getenv("UIS_NO_DEEP_KERNEL");
+                    (double)U * S * m.Dp * 4.0 < 2.0e9 && (L > 1 || deep_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 157 * 1024) &&
+                    !getenv("UIS_NO_DEEP_KERNEL");  // (look_ahead >= 2: the window's layout, checked above, not the fast select's)
   const bool small = !resident_ok && small_shape &&
                      (L == 1 ? select_fast_ok(B, Kmax, S) && small_lds_bytes(m.Dp, B, Kmax, S) <= 160 * 1024
                              : !cluster_shape && wsl.total <= 128 * 1024 && (double)U * NC * std::max(m.G, m.Hp) * 4.0 < 2.0e9);
@@ -1106,18 +1109,25 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // more utterances than workgroups: the variant whose dense stages give a wave a whole row tile
       // (k_decode_big: +6 % at 288 utterances, +17 % at 768 / 1024; up to 256 the LDS-resident beam of
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
-      const int big_from = getenv("UIS_BIG_MIN_U") ? atoi(getenv("UIS_BIG_MIN_U")) : 32 * ncl + 1;  // (experiments: where k_decode_big takes over)
-      const bool big = U >= big_from && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
-                       big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
       // ... with the selects of a rank's utterances running concurrently, one wave each (k_decode_big<.., true>),
       // where the single-wave select applies; UIS_FLAG_OWNER_SELECT keeps them one after the other
       const int per_rank = (((U + ncl - 1) / ncl) + 31) / 32;
-      const bool big_ws = big && !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
-                          rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
-                          big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
-      // ... and, where that kernel applies, two utterance cohorts in flight per XCD (k_decode_coh: a cohort's select
-      // and hand-off waits filled with the other cohort's dense stages); UIS_FLAG_NO_COHORTS keeps the lock-step batch
-      const bool coh = big_ws && !(opts->flags & UIS_FLAG_NO_COHORTS) && !getenv("UIS_NO_COHORTS") &&
+      const bool ws_shape = !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
+                            rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
+                            big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+      // Where k_decode_big takes over from k_decode_resident (round 5, from the sweep profiles/r05_usweep_dispatch.json:
+      // 128 utterances 2.03 against 1.89 M frames/s, 160: 2.20 / 2.22, 192: 2.31 / 2.46, 224: 2.42 / 2.52, 256: 2.43 /
+      // 2.65): with the concurrent single-wave selects from 21 utterances per XCD on (rounds 2-4 switched at "more
+      // utterances than workgroups", 33 per XCD); without them (observation dim 512, wide beams) the sequential
+      // selects keep the old switch (profiles/r05_usweep_c4_shape.json: a tie at 128).  UIS_BIG_MIN_U: experiments.
+      const int big_from = getenv("UIS_BIG_MIN_U") ? atoi(getenv("UIS_BIG_MIN_U")) : (ws_shape ? 20 : 32) * ncl + 1;
+      const bool big = U >= big_from && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
+                       big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+      const bool big_ws = big && ws_shape;
+      // ... or, on request (UIS_FLAG_COHORTS / UIS_COHORTS=1: measured slower, an experiment that stays tested), as two
+      // utterance cohorts in flight per XCD (k_decode_coh: a cohort's select and hand-off waits filled with the other
+      // cohort's dense stages)
+      const bool coh = big_ws && ((opts->flags & UIS_FLAG_COHORTS) || getenv("UIS_COHORTS")) &&
                        coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
       const bool rs_two = rs_kind == RS_UPW2 || rs_kind == RS_UPW2_C1, rs_wide = rs_kind == RS_WIDE || rs_kind == RS_WIDE_C4;
       const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_two ? 2 : 1, rs_two || rs_wide)
@@ -1407,12 +1417,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if (resident && (decode_kernel & 0xff) == UIS_DK_BIG_COH) {  // k_decode_coh: waves 0 (cohort A), 1 (cohort B) and 7 (no utterance at <= 7 per rank) of workgroup 0
     unsigned long long tc[96];
     HIPCHK(hipMemcpy(tc, h->counters.as<unsigned long long>(), sizeof(tc), hipMemcpyDeviceToHost));
-    static const char* names[16] = {"wait gruA", "wait gruB", "wait m1A", "wait m1B", "wait m2A", "wait m2B", "gruA", "gruB", "m1A", "m1B",
-                                    "m2A", "m2B", "select", "slot", "arrive", "early mse"};
+    static const char* names[16] = {"wait select A", "-", "-", "gru", "mean1", "mean2", "select", "early mse", "slot", "leave", "-", "-", "-", "-", "-", "-"};
     for (int k3 = 0; k3 < 3; ++k3) {
       fprintf(stderr, "[cohort timing] workgroup 0 wave %d, us per step:", k3 == 0 ? 0 : k3 == 1 ? 1 : 7);
       double sum = 0.0;
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < 10; ++k) {
+        if (k == 1 || k == 2) continue;
         const double us = (double)tc[48 + 16 * k3 + k] * 0.01 / (double)maxT;
         fprintf(stderr, " %s=%.2f", names[k], us);
         sum += us;
@@ -1538,7 +1548,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows, &h->hst,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};

@@ -211,12 +211,26 @@ class UISRNN:
           # block the host): the reference's predict takes a list of any size (uisrnn.py:588-589), so
           # the list goes in two halves, one after the other -- alternating members, so that a list
           # dealt longest-first stays even -- and each half may halve again
+          level_full, first_err = [], None
           for part in (pending[0::2], pending[1::2]):
-            part_labels = self._decode_batch([sequences[u] for u in part], args, flags, device, decoder)
+            try:
+              part_labels = self._decode_batch([sequences[u] for u in part], args, flags, device, decoder)
+            except LookAheadWindowError as inner:
+              # (a half whose look-ahead window overflowed: its indices and results are numbered inside
+              # the half -- hand them up in the caller's numbering, and still decode the other half)
+              part_labels = inner.results
+              level_full.extend(part[k] for k in inner.utterances)
+              first_err = first_err or inner
             for u, labels in zip(part, part_labels):
               results[u] = labels
           with self._state_lock:
             self._single_pass = False  # several decodes: no single resident label buffer
+          if first_err is not None:
+            level_full = sorted(level_full)
+            exc = LookAheadWindowError('{} (utterances {})'.format(
+                str(first_err).split(' (utterances')[0], level_full))
+            exc.status, exc.utterances, exc.results = first_err.status, tuple(level_full), results
+            raise exc from first_err
           return results
         if err.status != _capi.UIS_ERR_UNSUPPORTED or args.look_ahead < 2:
           raise
