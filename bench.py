@@ -535,8 +535,11 @@ def main(argv=None):
   #   predict_f64   uis_decode_f64 from the float64 arrays predict() receives (cast + H2D + decode + D2H)
   #   host_buffers  uis_decode from pinned float32 (H2D + decode + D2H)
   #   device        uis_decode_device, frames and labels resident in HBM
+  # (which legs run is a JOB-wide decision -- every leg's timed region issues barriers and gathers, so a rank
+  # without utterances still enters every leg and takes part in its collectives with an empty decode)
+  want_host = not args.no_host_buffers
   host = {}
-  if w.n_utt and not args.no_host_buffers:
+  if w.n_utt and want_host:
     pin = (lambda t: t.pin_memory()) if on_gpu else (lambda t: t)
     host['frames'] = pin(torch.from_numpy(w.frames))
     host['labels'] = pin(torch.empty(max(w.rank_frames, 1), dtype=torch.int32))
@@ -552,6 +555,9 @@ def main(argv=None):
     gather(w.d_labels)
 
   def host_step():
+    if not w.n_utt:
+      gather(w.d_labels)
+      return
     rc = w.decoder.decode_host(host['frames'].data_ptr(), w.offsets, w.beam, w.look, tau,
                                host['labels'].data_ptr(), host['scores'].data_ptr(),
                                max_clusters=w.cap, flags=args.flags)
@@ -563,6 +569,9 @@ def main(argv=None):
 
   f64_out = {}
   def f64_step():
+    if not w.n_utt:
+      gather(w.d_labels)
+      return
     f64_out['r'] = w.decoder.decode_f64(w.seqs, w.beam, w.look, tau, max_clusters=w.cap, flags=args.flags)
     if f64_out['r']['status'] != 0:
       raise RuntimeError('float64-list decode hit the cluster cap')
@@ -571,10 +580,10 @@ def main(argv=None):
       gather(w.d_labels)
 
   legs = {'device': device_step}
-  if host:
+  if want_host:
     legs['host_buffers'] = host_step
     legs['predict_f64'] = f64_step
-  timed_leg = args.timed if args.timed in legs else 'device'   # (--no_host_buffers, or a rank without utterances)
+  timed_leg = args.timed if args.timed in legs else 'device'   # (--no_host_buffers)
 
   setup_passes, setup_ms = w.setup(sync_fn)
   w.timing = True

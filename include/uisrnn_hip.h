@@ -78,7 +78,12 @@ typedef struct uis_decode_opts {
   uint32_t flags;          /* UIS_FLAG_*                                      */
   int32_t n_streams;       /* utterance groups decoded concurrently, each on its
                               own HIP stream; 0 = default (1), at most 8       */
-  int32_t reserved[2];
+  int32_t level_cap;       /* look_ahead >= 2: hypotheses an intermediate level of a window may hold per
+                              utterance; 0 = default (32768), at most 524287.  A window with more live
+                              assignment prefixes sets bit 1 of the utterance's flags and the call returns
+                              UIS_ERR_UNSUPPORTED: decode those utterances again with a larger level_cap
+                              (the Python host does, until the device's memory says UIS_ERR_OOM)      */
+  int32_t reserved[1];
 } uis_decode_opts;
 
 #define UIS_FLAG_NO_DEDUP   0x1u /* run one RNN row per surviving hypothesis even when

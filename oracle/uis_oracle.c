@@ -286,7 +286,8 @@ static int advance(octx* cx, hyp* h, const float* x, int c, int with_state) {
   return 1;
 }
 
-typedef struct { float score; int beam; int path[8]; long order; } cand;
+#define ORACLE_MAX_L 16 /* look_ahead the checker takes (the device path has no such bound; tests go up to 9) */
+typedef struct { float score; int beam; int path[ORACLE_MAX_L]; long order; } cand;
 
 typedef struct { cand* v; long n, cap; } candvec;
 static void cv_push(candvec* cv, const cand* c) {
@@ -307,7 +308,7 @@ static void enumerate(octx* cx, const hyp* base, const float* xs, int Lw, int su
     path[sub] = c;
     if (last_sub) {
       cand cd; cd.score = h.score; cd.beam = beam; cd.order = out->n;
-      for (int i = 0; i < 8; ++i) cd.path[i] = i < Lw ? path[i] : -1;
+      for (int i = 0; i < ORACLE_MAX_L; ++i) cd.path[i] = i < Lw ? path[i] : -1;
       cv_push(out, &cd);
     } else {
       enumerate(cx, &h, xs, Lw, sub + 1, beam, path, out);
@@ -362,7 +363,7 @@ static void decode_one(const omodel* m, const float* seq, long N, int B, int L, 
     for (int j = 0; j < Lw; ++j) /* np.tile(seq, (tau, 1)) */
       memcpy(xs + (size_t)j * m->D, seq + (size_t)((t + j) % N) * m->D, m->D * sizeof(float));
     cv.n = 0;
-    int path[8];
+    int path[ORACLE_MAX_L];
     for (int b = 0; b < nb; ++b) enumerate(&cx, &beam[b], xs, Lw, 0, b, path, &cv);
     info->candidates += cv.n;
     if (dbg) {
@@ -469,7 +470,7 @@ ORACLE_EXPORT int32_t uis_oracle_decode(const uis_model_desc* desc, const float*
                                         float* beam_scores_out, float* margins_out,
                                         int32_t* max_clusters_out, int64_t* counters_out) {
   if (!desc || !offsets || !opts || n_utt < 0) return UIS_ERR_INVALID_ARG;
-  if (opts->beam_size < 1 || opts->look_ahead < 1 || opts->look_ahead > 8 || opts->test_iteration < 1)
+  if (opts->beam_size < 1 || opts->look_ahead < 1 || opts->look_ahead > ORACLE_MAX_L || opts->test_iteration < 1)
     return UIS_ERR_INVALID_ARG;
   omodel* m = model_build(desc);
   job jb;

@@ -88,7 +88,7 @@ _MAIN_SCRIPT = textwrap.dedent('''
                       scores_ptr, max_clusters=0, flags=0):
         return self.decode_device(frames_ptr, offsets, beam_size, look_ahead, test_iteration, labels_ptr,
                                   scores_ptr, max_clusters, flags)
-      def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+      def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0, level_cap=0):
         assert all(s.dtype == np.float64 for s in seqs)
         n = sum(s.shape[0] for s in seqs)
         self.calls += 1

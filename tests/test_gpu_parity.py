@@ -14,6 +14,7 @@ import pytest
 import golden_util
 from uisrnn_amd import _capi
 from uisrnn_amd import synth
+from uisrnn_amd import weights
 
 pytestmark = pytest.mark.gpu
 
@@ -766,7 +767,7 @@ def test_empty_inputs_through_the_c_abi():
   # bad options are rejected, not executed
   lib = _capi.load_library()
   for kwargs in (dict(beam_size=0), dict(look_ahead=0), dict(test_iteration=0),
-                 dict(beam_size=300), dict(look_ahead=9)):
+                 dict(beam_size=40000), dict(look_ahead=2000)):   # (round 5: beam 300 and look_ahead 9 are decoded)
     args = dict(beam_size=10, look_ahead=1, test_iteration=2)
     args.update(kwargs)
     with pytest.raises(_capi.HipLibraryError):
@@ -813,31 +814,93 @@ def test_calculate_score_arrays_on_the_device(oracle_lib):
   assert checked >= 16 + 6 and windows >= 3 * (5 + 8)
 
 
-def test_level_capacity_names_the_utterances_and_keeps_the_others(oracle_lib):
-  """The Python surface on the same limit: LookAheadWindowError names the utterances whose window
-  overflowed an intermediate level and carries the label lists of every other utterance (decoded
-  again on their own) -- nothing valid is thrown away."""
+def test_level_capacity_names_the_utterances_and_keeps_the_others(oracle_lib, monkeypatch):
+  """The Python surface on the level capacity (round 5).  A window whose live prefixes outgrow the default
+  32768 hypotheses per level is no longer an error: predict() decodes the affected utterances again with eight
+  times the room and returns the reference's labels for everybody (the oracle's, bit for bit).  Only a window
+  beyond the largest capacity (524287 per level; lowered for this test) still ends in LookAheadWindowError,
+  which names the utterances and carries the label lists of every other one -- nothing valid is thrown away."""
   import uisrnn_amd
   params, rng = _many_cluster_case()
   model_args, _, inference_args = uisrnn_amd.parse_arguments([])
   model_args.observation_dim = 64
   model = uisrnn_amd.UISRNN(model_args)
   model.load_params(params)
-  wild = rng.standard_normal((14, 64))                      # opens a cluster per frame
+  wild = rng.standard_normal((17, 64))                      # opens a cluster per frame
   calm = np.tile(rng.standard_normal((1, 64)), (9, 1)) + 0.01 * rng.standard_normal((9, 64))
-  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 200, 4, 1
+  # beam 200, look_ahead 3: 200 * (K + 1) * (K + 2) prefixes -- past 32768 from K = 12 on
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 200, 3, 1
   inference_args.max_clusters = 30
+  ref = oracle_lib.decode(params, [calm, wild], 200, 3, 1, n_threads=2)
+  dec = model._get_decoder()  # pylint: disable=protected-access
+  with pytest.raises(_capi.HipLibraryError, match='look-ahead window'):   # (the C ABI with too small a capacity says so)
+    dec.decode(*oracle_lib.pack([calm, wild]), 200, 3, 1, max_clusters=30, level_cap=4096)
+  assert dec.last_overflow()[1] == 2   # (bit 1: an intermediate level was full)
+  inference_args.level_cap = 4096                             # (start the retries low: 4096 -> 32768 -> 262144)
+  got = model.predict([calm, wild], inference_args)          # (the host layer retries the second one with more room)
+  assert got == [ref['labels'][0].tolist(), ref['labels'][1].tolist()]
+  inference_args.level_cap = 0
+  assert model.predict([calm, wild], inference_args) == got   # (the default capacity: with or without a retry)
+  out = dec.decode(*oracle_lib.pack([calm, wild]), 200, 3, 1, max_clusters=30, level_cap=262144, want_beam_scores=True)
+  assert out['status'] == 0 and np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  # the end of the retries (the largest capacity, lowered here so that the test stays small): the error names the
+  # utterance in the caller's numbering and keeps the other one's labels (a one-frame utterance has no intermediate level)
+  from uisrnn_amd import uisrnn as host
+  monkeypatch.setattr(host, '_MAX_LEVEL_CAP', 4096)
+  inference_args.level_cap = 4096
+  one = rng.standard_normal((1, 64))
   with pytest.raises(uisrnn_amd.LookAheadWindowError) as info:
-    model.predict([calm, wild], inference_args)
+    model.predict([one, wild], inference_args)
   assert info.value.utterances == (1,)
   assert info.value.results[1] is None
-  ref = oracle_lib.decode(params, [calm], 200, 4, 1)
-  assert info.value.results[0] == ref['labels'][0].tolist()
+  assert info.value.results[0] == oracle_lib.decode(params, [one], 200, 3, 1)['labels'][0].tolist()
+
+
+def test_no_option_value_the_reference_takes_is_refused(oracle_lib):
+  """Round 5 (the verdict's item 7): beam_size beyond the select kernels' 256, a cluster cap beyond their LDS
+  budget and look_ahead beyond 8 are decoded -- by the window machinery, a launch per sub-step with the candidate
+  lists in HBM (uis_stats.decode_kernel says 'stepwise') -- and agree with the oracle bit for bit.  The reference
+  takes any of them (uisrnn/uisrnn.py:469-476,534-545: it enumerates every tuple)."""
+  import uisrnn_amd
+  rng = np.random.default_rng(77)
+  params = weights.init_params(16, 8, 1, sigma2=0.3, transition_bias=0.4, crp_alpha=1.0, seed=5)
+  # (a) beam 300, look_ahead 1 (and 2), ragged utterances incl. one frame
+  seqs = [rng.standard_normal((n, 16)) for n in (13, 1, 7, 10)]
+  frames, offsets = oracle_lib.pack(seqs)
+  dec = _capi.Decoder(params)
+  for beam, look, tau in ((300, 1, 2), (300, 2, 1), (700, 1, 1)):
+    ref = oracle_lib.decode(params, seqs, beam, look, tau, n_threads=4)
+    cap = int(ref['max_clusters'].max()) + look - 1
+    out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, want_beam_scores=True)
+    assert out['status'] == 0 and out['stats']['decode_kernel'].startswith('stepwise'), out['stats']['decode_kernel']
+    for u in range(len(seqs)):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), (beam, look, u)
+    assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores'])), (beam, look)
+  # (b) a cluster cap the select kernels' LDS does not hold: beam 64, 200 clusters per hypothesis
+  ref = oracle_lib.decode(params, seqs, 64, 1, 1, n_threads=4)
+  out = dec.decode(frames, offsets, 64, 1, 1, max_clusters=200, want_beam_scores=True)
+  assert out['status'] == 0 and np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  assert np.array_equal(out['labels'], np.concatenate(ref['labels']))
+  # (c) look_ahead 9: ONE window of nine frames from the empty beam -- 8! = 40320 prefixes on its last level (past the
+  # default capacity: the C ABI takes it with level_cap, predict() gets there by its retry), 9! candidates pruned to 6
+  nine = [rng.standard_normal((9, 16)), rng.standard_normal((4, 16))]
+  ref = oracle_lib.decode(params, nine, 6, 9, 1, n_threads=2)
+  out = dec.decode(*oracle_lib.pack(nine), 6, 9, 1, max_clusters=10, level_cap=65536, want_beam_scores=True)
+  assert out['status'] == 0 and np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  assert np.array_equal(out['labels'], np.concatenate(ref['labels']))
+  model_args, _, inference_args = uisrnn_amd.parse_arguments([])
+  model_args.observation_dim, model_args.rnn_hidden_size = 16, 8
+  model = uisrnn_amd.UISRNN(model_args)
+  model.load_params(params)
+  inference_args.beam_size, inference_args.look_ahead, inference_args.test_iteration = 6, 9, 1
+  assert model.predict(nine, inference_args) == [l.tolist() for l in ref['labels']]
+  inference_args.beam_size, inference_args.look_ahead = 300, 1
+  assert model.predict(seqs, inference_args) == [l.tolist() for l in oracle_lib.decode(params, seqs, 300, 1, 1, n_threads=4)['labels']]
 
 
 def test_a_refused_decode_leaves_no_stale_flags_behind(oracle_lib):
   """uis_last_decode_info after a decode that was refused for its OPTIONS must not hand out the
-  previous decode's arrays (a 100-utterance batch followed by a 1-utterance call with look_ahead 9
+  previous decode's arrays (a 100-utterance batch followed by a 1-utterance call with a refused look_ahead
   used to copy 100 flags into a buffer of one): the library reports the shape it holds
   (uis_last_decode_shape: 0 x 0) and the Python surface raises the clean error."""
   import uisrnn_amd
@@ -852,7 +915,7 @@ def test_a_refused_decode_leaves_no_stale_flags_behind(oracle_lib):
   assert model.predict(seqs, inference_args) == want
   dec = model._get_decoder()  # pylint: disable=protected-access
   assert dec.last_overflow().shape == (100,)
-  inference_args.look_ahead = 9
+  inference_args.look_ahead = 2000   # (an option value beyond the window records' fields: refused before it starts)
   with pytest.raises(_capi.HipLibraryError) as info:
     model.predict(seqs[:1], inference_args)
   assert info.value.status == _capi.UIS_ERR_UNSUPPORTED and not isinstance(info.value, uisrnn_amd.LookAheadWindowError)

@@ -374,7 +374,7 @@ def test_predict_splits_a_list_that_does_not_fit_the_device():
     def __init__(self, room):
       self.room, self.batches = room, []
 
-    def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0):
+    def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0, level_cap=0):
       if len(seqs) > self.room:
         err = _capi.HipLibraryError('uis_decode_f64 failed (-5): decode state would need 999 GB')
         err.status = _capi.UIS_ERR_OOM
@@ -397,3 +397,67 @@ def test_predict_splits_a_list_that_does_not_fit_the_device():
   with pytest.raises(_capi.HipLibraryError):
     model._decode_batch(seqs[:1], inference_args, decoder=StandIn(room=0))  # pylint: disable=protected-access
   assert host is not None
+
+
+def test_predict_retries_an_overflowing_look_ahead_window_with_more_room():
+  """Round 5 (plumbing test with a stand-in decoder: no device here).  The library reports a look-ahead window whose
+  live prefixes outgrow a level's capacity per utterance (UIS_ERR_UNSUPPORTED + bit 1 of the flags); the host layer
+  decodes the other utterances again at the same capacity and the affected ones with eight times the room, up to
+  the library's maximum, and only then raises LookAheadWindowError -- numbered like the caller's list, with every
+  decodable utterance's labels -- also when the list had to be split first because its state did not fit."""
+  from uisrnn_amd import uisrnn as host
+
+  class StandIn:
+    """Utterance k needs a level capacity of need[k] (its tag); decodes at most `room` utterances at a time."""
+    def __init__(self, room=99):
+      self.room, self.calls, self.flags = room, [], np.zeros(0, dtype=np.int32)
+
+    def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0, level_cap=0):
+      cap = level_cap or 32768
+      self.calls.append((len(seqs), cap))
+      if len(seqs) > self.room:
+        err = _capi.HipLibraryError('uis_decode_f64 failed (-5): decode state would need 999 GB')
+        err.status = _capi.UIS_ERR_OOM
+        self.flags = np.zeros(0, dtype=np.int32)
+        raise err
+      self.flags = np.array([2 if int(s[0, 1]) > cap else 0 for s in seqs], dtype=np.int32)
+      if self.flags.any():
+        err = _capi.HipLibraryError('uis_decode_f64 failed (-7): a look-ahead window held more prefixes than a level')
+        err.status = _capi.UIS_ERR_UNSUPPORTED
+        raise err
+      labels = np.concatenate([np.full(s.shape[0], int(s[0, 0]), dtype=np.int32) for s in seqs])
+      return {'status': 0, 'labels': labels, 'overflow': np.zeros(len(seqs), dtype=np.int32),
+              'stats': {'decode_kernel': 'stand-in'}}
+
+    def last_overflow(self, n_utt=None):
+      return self.flags
+
+  model_args, _, inference_args = arguments.parse_arguments([])
+  model_args.observation_dim = 4
+  inference_args.look_ahead = 3
+  model = uisrnn_amd.UISRNN(model_args)
+  need = [100, 40000, 100, 300000, 100, 100, 9_000_000, 100]
+  seqs = []
+  for k, n in enumerate(need):
+    s = np.zeros((2 + k % 3, 4))
+    s[:, 0], s[:, 1] = k, n
+    seqs.append(s)
+  ok = [k for k, n in enumerate(need) if n <= host._MAX_LEVEL_CAP]  # pylint: disable=protected-access
+  # everything that fits some capacity comes back, in the caller's order; the one that fits none is named
+  for room in (99, 3):
+    dec = StandIn(room)
+    with pytest.raises(uisrnn_amd.LookAheadWindowError) as info:
+      model._decode_batch(seqs, inference_args, decoder=dec)  # pylint: disable=protected-access
+    assert info.value.utterances == (6,), (room, info.value.utterances)
+    assert [None if r is None else r[0] for r in info.value.results] == [k if k in ok else None for k in range(8)]
+    assert max(cap for _, cap in dec.calls) == host._MAX_LEVEL_CAP  # pylint: disable=protected-access
+  # without the hopeless one: no exception at all
+  dec = StandIn()
+  out = model._decode_batch(seqs[:6], inference_args, decoder=dec)  # pylint: disable=protected-access
+  assert [r[0] for r in out] == list(range(6)) and [len(r) for r in out] == [s.shape[0] for s in seqs[:6]]
+  assert sorted({cap for _, cap in dec.calls}) == [32768, 262144, 524287]
+  # args.level_cap: where the retries start
+  inference_args.level_cap = 64
+  dec = StandIn()
+  out = model._decode_batch(seqs[:3], inference_args, decoder=dec)  # pylint: disable=protected-access
+  assert [r[0] for r in out] == [0, 1, 2] and dec.calls[0] == (3, 64)

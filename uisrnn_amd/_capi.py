@@ -96,7 +96,8 @@ class DecodeOpts(ctypes.Structure):
       ('max_clusters', ctypes.c_int32),
       ('flags', ctypes.c_uint32),
       ('n_streams', ctypes.c_int32),
-      ('reserved', ctypes.c_int32 * 2),
+      ('level_cap', ctypes.c_int32),
+      ('reserved', ctypes.c_int32 * 1),
   ]
 
 
@@ -191,8 +192,9 @@ def make_desc(params):
 
 
 def make_opts(beam_size, look_ahead, test_iteration, max_clusters=0, flags=0,
-              n_streams=0):
+              n_streams=0, level_cap=0):
   opts = DecodeOpts()
+  opts.level_cap = int(level_cap)
   opts.n_streams = int(n_streams)
   opts.beam_size = int(beam_size)
   opts.look_ahead = int(look_ahead)
@@ -363,7 +365,7 @@ class Decoder:
     raise err
 
   def decode(self, frames, offsets, beam_size, look_ahead, test_iteration,
-             max_clusters=0, flags=0, want_beam_scores=False, n_streams=0):
+             max_clusters=0, flags=0, want_beam_scores=False, n_streams=0, level_cap=0):
     """Decode packed host utterances.
 
     Args:
@@ -384,7 +386,7 @@ class Decoder:
     labels = np.empty(total, dtype=np.int32)
     scores = np.empty(n_utt, dtype=np.float32)
     opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags,
-                     n_streams)
+                     n_streams, level_cap)
     stats = Stats()
     rc = self._lib.uis_decode(
         self._handle, frames.ctypes.data_as(_fp),
@@ -407,7 +409,7 @@ class Decoder:
     return out
 
   def decode_f64(self, sequences, beam_size, look_ahead, test_iteration,
-                 max_clusters=0, flags=0, want_beam_scores=False, n_streams=0):
+                 max_clusters=0, flags=0, want_beam_scores=False, n_streams=0, level_cap=0):
     """Decode a list of [N_u, D] float64 arrays as predict() receives them (uis_decode_f64:
     the library casts to float32 on its own threads while earlier chunks travel to the device).
 
@@ -423,7 +425,7 @@ class Decoder:
     ptrs = (ctypes.c_void_p * max(n_utt, 1))(*[s.ctypes.data if s.shape[0] else None for s in seqs])
     labels = np.empty(total, dtype=np.int32)
     scores = np.empty(n_utt, dtype=np.float32)
-    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags, n_streams)
+    opts = make_opts(beam_size, look_ahead, test_iteration, max_clusters, flags, n_streams, level_cap)
     stats = Stats()
     rc = self._lib.uis_decode_f64(
         self._handle, ptrs, lens.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n_utt,

@@ -94,7 +94,8 @@ struct Scratch {
 #define UIS_WT_ROWS 1280          // row capacity above which the LDS-weight kernels (k_wt_*) take over at hidden size 256 / 512
 #define UIS_MAX_GROUPS 8
 #define UIS_MAX_CLUSTERS 16         // clusters of 32 CUs the one-launch decode can address
-#define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance
+#define UIS_LEVEL_CAP 32768        // hypotheses per intermediate look-ahead level and utterance: the DEFAULT (uis_decode_opts.level_cap)
+#define UIS_LEVEL_CAP_MAX 524287    // ... and the most a caller may ask for (window_body packs a level's hypothesis index into 19 bits)
 #define UIS_WINDOW_WIDE_LEVEL 256  // level capacity (hypotheses) from which k_window runs with more threads per utterance
 #define UIS_WINDOW_WIDE_NT 512   // (1024 measured the same)
 #define UIS_GRAPH_STEPS 32   // decode steps per captured graph (even)
@@ -498,9 +499,9 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
   const long max_rows = st.max_rows;
   for (int s = 0; s < nsteps; ++s) {
     const int par = s & 1;
-    if (st.L == 1 && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
+    if (!st.wnd && select_fast_ok(st.B, st.Kmax, st.S) && !(st.flags & UIS_FLAG_GENERIC_SELECT))
       LAUNCH(UIS_K_SELECT, k_select_fast, dim3(st.U), dim3(256), (size_t)fast_lds_layout(m.Dp, st.B, st.Kmax, st.S).total, m, st, par);
-    else if (st.L == 1) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
+    else if (!st.wnd) LAUNCH(UIS_K_SELECT, k_select, dim3(st.U), dim3(256), select_lds, m, st, par);
     else if (st.NC >= UIS_WINDOW_WIDE_LEVEL)  // hundreds of hypotheses per level: more threads per utterance
       LAUNCH(UIS_K_EXPAND, k_window<UIS_WINDOW_WIDE_NT>, dim3(st.U), dim3(UIS_WINDOW_WIDE_NT), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
     else LAUNCH(UIS_K_EXPAND, k_window<256>, dim3(st.U), dim3(256), window_lds_bytes(window_scratch_layout(st.S, st.NC, st.Kmax, st.B)), m, st, par);
@@ -654,10 +655,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const DevModel& m = h->m;
   const int B = opts->beam_size, L = opts->look_ahead, tau = opts->test_iteration;
   int Kmax = opts->max_clusters > 0 ? opts->max_clusters : 16;
-  if (B < 1 || B > 256) return fail(UIS_ERR_UNSUPPORTED, "beam_size must be in [1, 256]");
+  // (round 5: no option value the reference takes is refused for its size any more -- a beam beyond the select
+  // kernels' 256, a cluster cap beyond their LDS budget and any look_ahead go through the window machinery, a launch
+  // per sub-step with the candidate lists in HBM; what is left are the widths of the window records' fields)
+  if (B < 1 || B > 32767) return fail(UIS_ERR_UNSUPPORTED, "beam_size must be in [1, 32767]");
   if (L < 1 || tau < 1) return fail(UIS_ERR_INVALID_ARG, "look_ahead and test_iteration must be >= 1");
-  if (L > UIS_MAX_LOOKAHEAD) return fail(UIS_ERR_UNSUPPORTED, "look_ahead must be <= 8");
+  if (L > UIS_MAX_LOOKAHEAD) return fail(UIS_ERR_UNSUPPORTED, "look_ahead must be <= 1024");
   if (Kmax > 4096) return fail(UIS_ERR_UNSUPPORTED, "max_clusters must be <= 4096");
+  if (opts->level_cap < 0) return fail(UIS_ERR_INVALID_ARG, "level_cap must be >= 0");
+  const int64_t level_cap = opts->level_cap > 0 ? std::min<int64_t>(opts->level_cap, UIS_LEVEL_CAP_MAX) : UIS_LEVEL_CAP;
   if (offsets[0] != 0) return fail(UIS_ERR_INVALID_ARG, "offsets[0] must be 0");
   int64_t maxN = 0;
   for (int u = 0; u < n_utt; ++u) {
@@ -685,7 +691,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     int64_t nj = B;
     NC = 0;
     for (int j2 = 1; j2 < L; ++j2) {
-      nj = std::min<int64_t>(nj * (Kmax + j2), UIS_LEVEL_CAP);
+      nj = std::min<int64_t>(nj * (Kmax + j2), level_cap);
       NC = std::max(NC, nj);
       S64 += nj;
     }
@@ -697,16 +703,21 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   Launcher lch{h, h->stream, profile};
   h->prof.used = 0; h->prof.cls.clear();
 
+  // wnd: the window machinery decodes -- look_ahead >= 2, and look_ahead 1 where the select kernels do not apply
+  // (beam_size > 256, or tables beyond their LDS budget): k_window with a window of ONE frame is the prune
+  // sub-step alone, its work arrays in LDS where they fit and in HBM where they do not
   SelectLds lds{};
-  if (L == 1) {
+  bool wnd = L > 1 || B > 256;
+  if (!wnd) {
     lds = select_lds_layout(m.Dp, B, Kmax, S);
-    if (lds.total > 160 * 1024)
-      return fail(UIS_ERR_UNSUPPORTED, "beam_size * max_clusters too large for the select kernel's LDS budget");
+    if (lds.total > 160 * 1024) wnd = true;
   }
+  if (NC * (int64_t)(Kmax + 1) > 0x3fffffff || (int64_t)U * std::max<int64_t>(NC, B) > 0x3fffffff)
+    return fail(UIS_ERR_OOM, "level capacity * max_clusters (or utterances * level capacity) beyond the kernels' 32-bit indices");
   const WindowScratch wsl = window_scratch_layout(S, (int)NC, Kmax, B);
   {  // refuse configurations whose state would not fit the device instead of failing in hipMalloc
     const double bytes = (double)U * S * (m.Dp + (double)m.depth * m.Hp) * 4.0 +
-                         (L > 1 ? (double)U * (wsl.total + 2.0 * NC * (Kmax * 8.0 + 32.0) + NC * (m.Hp + m.G) * 4.0) : 0.0);
+                         (wnd ? (double)U * (wsl.total + 2.0 * NC * (Kmax * 8.0 + 32.0) + NC * (m.Hp + m.G) * 4.0) : 0.0);
     // (UIS_MAX_STATE_BYTES: a smaller ceiling, for tests of the host layer's answer -- it decodes the list in halves)
     const char* lim = getenv("UIS_MAX_STATE_BYTES");
     if (bytes > (lim ? atof(lim) : 200e9))
@@ -738,7 +749,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const long max_rows = (long)U * (L == 1 ? B : (long)NC);
   // back-pointer records per utterance (look_ahead >= 2): windows x B
   std::vector<int64_t> bp_base(U + 1, 0);
-  if (L > 1)
+  if (wnd)
     for (int u = 0; u < U; ++u)
       bp_base[u + 1] = bp_base[u] + (((int64_t)tau * (offsets[u + 1] - offsets[u]) + L - 1) / L) * B;
 
@@ -767,7 +778,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(beam_score, (size_t)2 * U * B * 4);
   ENSURE(beam_slot, (size_t)2 * U * B * Kmax * 4);
   ENSURE(beam_blk, (size_t)2 * U * B * Kmax * 4);
-  ENSURE(bp, L == 1 ? (size_t)std::max<int64_t>(tau * F, 1) * B * 4 : 16);
+  ENSURE(bp, !wnd ? (size_t)std::max<int64_t>(tau * F, 1) * B * 4 : 16);
   // k_decode_resident: the CUs form ncl clusters of 32 (one per XCD: 8 on a whole MI355X, 1 in
   // CPX mode); one row region per cluster, a multiple of 16 rows
   const int ncl = (h->n_cu >= 32 && h->n_cu % 32 == 0 && h->n_cu / 32 <= UIS_MAX_CLUSTERS) ? h->n_cu / 32 : 0;
@@ -882,7 +893,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const size_t dbg_floats = (size_t)dbg_want;
   if (dbg) ENSURE(dbg_scores, std::max<size_t>(dbg_floats, 1) * 4);
   h->dbg_floats = 0;
-  if (L > 1) {
+  if (wnd) {
     ENSURE(lv_n, (size_t)2 * U * 4);
     ENSURE(lv_K, (size_t)2 * U * NC * 4);
     ENSURE(lv_last, (size_t)2 * U * NC * 4);
@@ -944,7 +955,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   HIPCHK(hipMemcpyAsync(h->off.p, offsets, (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->logblk.p, logblk.data(), logblk.size() * 8, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->logden.p, logden.data(), logden.size() * 8, hipMemcpyHostToDevice, h->stream));
-  if (L > 1)
+  if (wnd)
     HIPCHK(hipMemcpyAsync(h->bp_base.p, bp_base.data(), (size_t)(U + 1) * 8, hipMemcpyHostToDevice, h->stream));
 
   HIPCHK(hipEventRecord(h->ev_begin, h->stream));
@@ -1035,7 +1046,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     GroupPlan& gp = plan[g];
     DecodeState& st = gp.st;
     const size_t u0 = (size_t)gp.u0;
-    st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags;
+    st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags; st.wnd = wnd ? 1 : 0;
     st.max_rows = (int)((size_t)gp.U * rows_per_utt);
     st.off = h->off.as<int64_t>() + u0;
     st.utt_step = h->utt_step.as<int32_t>() + u0;
@@ -1076,7 +1087,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
         st.mse_part = reinterpret_cast<float*>(h->mse_tab.as<char>() + mse_tab_bytes);
       }
     }
-    if (L > 1) {  // level buffers: groups back to back, each [2][U_g][NC]...
+    if (wnd) {  // level buffers: groups back to back, each [2][U_g][NC]...
       st.NC = (int)NC;
       st.lv_n = h->lv_n.as<int32_t>() + 2 * u0;
       st.lv_K = h->lv_K.as<int32_t>() + 2 * u0 * NC;
@@ -1316,7 +1327,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       for (int64_t s0 = 0; s0 < nsteps; s0 += 2)
         if ((rc = enqueue_steps(h, gl, gp.st, lds.total, 2))) return rc;
     }
-    if (L == 1)
+    if (!wnd)
       LAUNCH(UIS_K_BACKTRACE, k_backtrace, dim3(gp.U), dim3(64), (size_t)64 * B, gp.st, d_labels,
              d_scores ? d_scores + gp.u0 : nullptr, h->beam_scores_out.as<float>() + (size_t)gp.u0 * B);
     else

@@ -15,7 +15,7 @@
 #include <stdint.h>
 
 #define UIS_MAX_DEPTH 8
-#define UIS_MAX_LOOKAHEAD 8
+#define UIS_MAX_LOOKAHEAD 1024  // (window records are (look_ahead + 1) uint16 per hypothesis; nothing else is sized by it)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -82,6 +82,8 @@ struct DecodeState {
   int U, B, Kmax, S, L, tau;
   int max_rows;           // capacity of `rows` = the most rnn rows one step can emit
   uint32_t flags;
+  int wnd;                // 1: the window machinery decodes (k_window, level buffers, window records): look_ahead >= 2,
+                          // and look_ahead 1 with a beam / cluster cap the select kernels do not take (round 5)
   // utterances
   const int64_t* off;     // [U+1] frame offsets
   int32_t* utt_step;      // [U] next decode step of each utterance

@@ -3405,7 +3405,7 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
     const int i = winv[r];
     const int b = node_of(i);
     const int c = i - cbase[b];
-    wbc[r] = b | (c << 16);
+    wbc[r] = b | (c << 19);  // (hypothesis of the level: < 2^19 = the largest level capacity; cluster: <= 4096)
     const int src = c < in.K[b] ? in.slot[(size_t)b * Kmax + c] : S;
     srcv[r] = src;
     if (!nodedup) atomicMin(&first[src], r);
@@ -3429,7 +3429,7 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
   // ---- write the next level / the next beam
   for (long e = tid; e < (long)keep * Kmax; e += NT) {
     const int r = (int)(e / Kmax), c2 = (int)(e - (long)r * Kmax);
-    const int b = wbc[r] & 0xffff, c = wbc[r] >> 16;
+    const int b = wbc[r] & 0x7ffff, c = (int)((unsigned)wbc[r] >> 19);
     const int Kb = in.K[b];
     const bool is_new = c == Kb;
     const int Knew = Kb + (is_new ? 1 : 0);
@@ -3446,7 +3446,7 @@ __device__ __forceinline__ void window_body(const DevModel& m, const DecodeState
   const int row_base = lds_misc[5];
   for (int r = tid; r < keep; r += NT) {
     const int i = winv[r];
-    const int b = wbc[r] & 0xffff, c = wbc[r] >> 16;
+    const int b = wbc[r] & 0x7ffff, c = (int)((unsigned)wbc[r] >> 19);
     const int Kb = in.K[b];
     const bool is_new = c == Kb;
     int Knew = Kb + (is_new ? 1 : 0);

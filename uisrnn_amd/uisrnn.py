@@ -37,7 +37,9 @@ def _initial_cluster_cap(args):
   if int(args.look_ahead) == 1 and 8 <= fits < _DEFAULT_MAX_CLUSTERS:
     return fits
   return _DEFAULT_MAX_CLUSTERS
-_MAX_CLUSTERS_LIMIT = 1024
+_MAX_CLUSTERS_LIMIT = 4096   # (the library's own limit: uis_decode_opts.max_clusters)
+_DEFAULT_LEVEL_CAP = 32768   # include/uisrnn_hip.h: uis_decode_opts.level_cap's default ...
+_MAX_LEVEL_CAP = 524287      # ... and its maximum
 
 
 class EmptyBeamError(ValueError, IndexError):
@@ -55,9 +57,12 @@ class EmptyBeamError(ValueError, IndexError):
 
 class LookAheadWindowError(_capi.HipLibraryError):
   """look_ahead >= 2: inside a window some utterances had more live assignment prefixes than the
-  device tables hold (beam_size * clusters ^ (look_ahead - 1), include/uisrnn_hip.h UIS_LEVEL_CAP);
-  the reference has no such cap.  A larger max_clusters cannot help: lower look_ahead or beam_size
-  for those utterances.
+  device can hold (beam_size * clusters ^ (look_ahead - 1) hypotheses per intermediate level); the
+  reference has no such bound -- it enumerates them one by one.  Round 5: predict() no longer raises
+  this at the default capacity (32768 per level): the affected utterances are decoded again on
+  their own with eight times the room, up to 524287 hypotheses per level, and only a window beyond
+  THAT -- or beyond the device's memory -- ends here.  Lower look_ahead or beam_size for those
+  utterances.
 
   Attributes:
     utterances: indices (into the list given to predict) of the affected utterances.
@@ -183,13 +188,15 @@ class UISRNN:
       raise ValueError('test_sequence does not match the dimension specified '
                        'by args.observation_dim.')
 
-  def _decode_batch(self, sequences, args, flags=0, device=None, decoder=None):
+  def _decode_batch(self, sequences, args, flags=0, device=None, decoder=None, level_cap=0):
     """Decode a list of validated sequences in one lock-step batch.
 
     `decoder` (a _capi.Decoder built from self.params) overrides the model's own handle for
     `device`; parallel_predict passes one per worker thread.
     """
     decoder = decoder or self._get_decoder(device)
+    # (args.level_cap, like args.max_clusters, is an extension: where the retries of a look-ahead window start)
+    level_cap = level_cap or int(getattr(args, 'level_cap', 0) or 0)
     n_utt = len(sequences)
     results = [None] * n_utt
     pending = list(range(n_utt))
@@ -204,7 +211,7 @@ class UISRNN:
       sub_off[1:] = np.cumsum([s.shape[0] for s in sub])
       try:
         out = decoder.decode_f64(sub, args.beam_size, args.look_ahead,
-                                 args.test_iteration, max_clusters=cap, flags=flags)
+                                 args.test_iteration, max_clusters=cap, flags=flags, level_cap=level_cap)
       except _capi.HipLibraryError as err:
         if err.status == _capi.UIS_ERR_OOM and len(pending) > 1:
           # the decode state of this many utterances does not fit the device (or the pinned staging
@@ -214,7 +221,7 @@ class UISRNN:
           level_full, first_err = [], None
           for part in (pending[0::2], pending[1::2]):
             try:
-              part_labels = self._decode_batch([sequences[u] for u in part], args, flags, device, decoder)
+              part_labels = self._decode_batch([sequences[u] for u in part], args, flags, device, decoder, level_cap)
             except LookAheadWindowError as inner:
               # (a half whose look-ahead window overflowed: its indices and results are numbered inside
               # the half -- hand them up in the caller's numbering, and still decode the other half)
@@ -236,28 +243,52 @@ class UISRNN:
           raise
         # a look-ahead window of some utterances held more assignment prefixes than a level has
         # room for (bit 1 of their flags).  The flags come from the library, sized by the library:
-        # a decode that was refused for its OPTIONS (look_ahead > 8, beam_size > 256) never
+        # a decode that was refused for its OPTIONS (look_ahead > 1024, beam_size > 32767) never
         # started and leaves no flags behind -- that error goes up as it is.
         flags_now = decoder.last_overflow()
         if flags_now.shape[0] != len(pending):
           raise
         level_full = [u for k, u in enumerate(pending) if flags_now[k] & 2]
-        if not level_full or len(level_full) == len(pending):
+        if not level_full:
           raise
-        # name the utterances, and decode the others again on their own: their results are valid
+        # The others' results are valid but were not handed out: decode them again on their own, at the
+        # same capacity.  The affected ones get eight times the room per level (the library's default is
+        # 32768 hypotheses per level, its maximum 524287), again and again; what ends the retries is the
+        # maximum, or the device's memory (UIS_ERR_OOM for a single utterance).
         rest = [u for u in pending if u not in level_full]
-        try:
-          partial = self._decode_batch([sequences[u] for u in rest], args, flags, device, decoder)
-        except LookAheadWindowError as inner:
-          # (an utterance of `rest` that first hit the cluster cap and then, with twice the room, a
-          # full level: its indices are relative to `rest` -- hand them up in the caller's numbering)
-          partial = inner.results
-          level_full = sorted(level_full + [rest[k] for k in inner.utterances])
-        for u, labels in zip(rest, partial):
-          results[u] = labels
-        exc = LookAheadWindowError('{} (utterances {})'.format(err, level_full))
-        exc.status, exc.utterances, exc.results = err.status, tuple(level_full), results
-        raise exc from err
+        failed, first_err = [], None
+        groups = [(rest, level_cap)]
+        now_cap = level_cap or _DEFAULT_LEVEL_CAP
+        if now_cap < _MAX_LEVEL_CAP:
+          groups.append((level_full, min(now_cap * 8, _MAX_LEVEL_CAP)))
+        else:
+          failed, first_err = list(level_full), err
+        for members, cap_level in groups:
+          if not members:
+            continue
+          try:
+            partial = self._decode_batch([sequences[u] for u in members], args, flags, device, decoder, cap_level)
+          except LookAheadWindowError as inner:
+            # (indices and results are numbered inside `members`: hand them up in the caller's numbering)
+            partial = inner.results
+            failed.extend(members[k] for k in inner.utterances)
+            first_err = first_err or inner
+          except _capi.HipLibraryError as inner:
+            if inner.status != _capi.UIS_ERR_OOM or members is rest:
+              raise
+            partial = [None] * len(members)   # (one utterance whose window does not fit the device at this capacity)
+            failed.extend(members)
+            first_err = first_err or inner
+          for u, labels in zip(members, partial):
+            results[u] = labels
+        with self._state_lock:
+          self._single_pass = False
+        if failed:
+          failed = sorted(failed)
+          exc = LookAheadWindowError('{} (utterances {})'.format(str(first_err).split(' (utterances')[0], failed))
+          exc.status, exc.utterances, exc.results = _capi.UIS_ERR_UNSUPPORTED, tuple(failed), results
+          raise exc from first_err
+        return results
       if stats is None:
         stats = out['stats']
       still = []
