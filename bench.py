@@ -35,7 +35,9 @@ What the ONE JSON line (rank 0) says, field by field:
   setup_passes/_ms      untimed decodes before the warm-up (cluster cap, control-word placement)
   per_rank_ms           min / max over ranks of a rank's own time per step
   roofline              the dominant kernel (named by the library: uis_stats.decode_kernel), timed
-                        with HIP events on the decode stream:
+                        with HIP events on the decode stream; `traffic` = its HBM bytes per launch from
+                        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this very command (round 5;
+                        UIS_BENCH_NO_PMC=1 or no rocprofv3: the newest committed record, marked as such):
                         `frac` = what the MFMA pipes EXECUTED (rows after de-duplication) / peak,
                         never above 1; `effective` = the algorithmic rows (one CoreRNN step per
                         surviving hypothesis) / peak -- de-duplication's credit
@@ -134,6 +136,90 @@ def committed_traffic(kernel, avg_launch_us=None):
     except (KeyError, ValueError, OSError):
       continue
   return None
+
+
+def _no_core_dumps():
+  import resource  # pylint: disable=import-outside-toplevel
+  resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+
+
+def measured_traffic(argv, timeout_s=240):
+  """HBM bytes per launch of `kernel`, MEASURED for this very run (round 5): two sub-runs of this script under
+  `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one;
+  MI355X_MICROARCH.md, HBM section), one timed pass each of the same workload with the frames resident, the
+  counters of the dominant kernel's dispatches averaged.  FETCH_SIZE is doubled (gfx950 tallies a 128-byte
+  request of a wide coalesced read at 64 bytes), WRITE_SIZE is taken as reported (uncalibrated), both arrive in
+  KiB.  The sub-runs go FIRST, before this process touches the device: run next to a parent that holds a HIP context
+  and its buffers the same launch showed 1.7x the fetches and 8x the writes (443 / 417 MB against 254 / 49 MB), so
+  they get the GPU to themselves; the kernel they name (their own JSON line's roofline.kernel) comes back with the
+  record and the caller attaches it only if its own run names the same kernel.  None when rocprofv3 is not there,
+  when this process is itself such a sub-run, or when a pass fails -- the caller then keeps the newest committed
+  record and says so."""
+  import csv  # pylint: disable=import-outside-toplevel
+  import glob  # pylint: disable=import-outside-toplevel
+  import shutil  # pylint: disable=import-outside-toplevel
+  import subprocess  # pylint: disable=import-outside-toplevel
+  import tempfile  # pylint: disable=import-outside-toplevel
+  if os.environ.get('UIS_BENCH_CHILD') or os.environ.get('UIS_BENCH_NO_PMC'):
+    return None
+  prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+  if not prof:
+    print('bench.py: rocprofv3 not found; roofline.traffic falls back to the committed record', file=sys.stderr)
+    return None
+  keep = []  # the workload's arguments; everything about timing, legs and extras is set here
+  skip_next = False
+  for a in argv:
+    if skip_next:
+      skip_next = False
+      continue
+    if a in ('--steps', '--warmup', '--gpus', '--timed', '--cpu_sample', '--backend'):
+      skip_next = True
+      continue
+    if a in ('--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs', '--force_dist'):
+      continue
+    keep.append(a)
+  env = dict(os.environ, UIS_BENCH_CHILD='1', TMPDIR='/tmp')
+  sizes, spread, kernel, base = {}, {}, None, None
+  t0 = time.perf_counter()
+  for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    out_dir = tempfile.mkdtemp(prefix='uis_pmc_', dir='/tmp')
+    try:
+      cmd = [prof, '--kernel-trace', '--pmc', counter, '-d', out_dir, '-o', 'p', '--output-format', 'csv', '--',
+             sys.executable, os.path.abspath(__file__)] + keep + [
+                 '--timed', 'device', '--steps', '1', '--warmup', '0', '--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs']
+      # (no check of the exit status: under --pmc the profiled interpreter can die in its exit handlers AFTER the counter
+      # files are complete -- seen on this image, also from a shell; what decides is whether the kernel's rows are there)
+      done = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False,
+                            preexec_fn=_no_core_dumps, text=True)
+      line = [l for l in done.stdout.splitlines() if l.startswith('{')]
+      kernel = json.loads(line[-1])['roofline']['kernel']   # (what the library says ran, in the sub-run's own line)
+      base = kernel.split('<')[0].split(':')[-1]
+      vals = []
+      for path in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as f:
+          for row in csv.DictReader(f):
+            if row.get('Counter_Name') == counter and base + '<' in row.get('Kernel_Name', '') + '<':
+              vals.append(float(row['Counter_Value']))
+      if not vals:
+        print('bench.py: no {} rows of {} in the counter files under {}'.format(counter, base, out_dir), file=sys.stderr)
+        return None
+      # (a launch's counter comes in one row per dispatch; the set-up passes run the same kernel: the median of
+      # what should be all alike, and the spread for whoever reads the line)
+      vals.sort()
+      sizes[counter] = vals[len(vals) // 2]
+      spread[counter] = [round(vals[0], 1), round(vals[-1], 1), len(vals)]
+    except (subprocess.SubprocessError, OSError, ValueError, KeyError, IndexError) as e:
+      print('bench.py: the {} sub-run failed ({}: {}); roofline.traffic falls back to the committed record'.format(
+          counter, type(e).__name__, str(e)[-300:]), file=sys.stderr)
+      return None
+    finally:
+      shutil.rmtree(out_dir, ignore_errors=True)
+  return {'kernel': kernel, 'bytes_per_launch': int((2.0 * sizes['FETCH_SIZE'] + sizes['WRITE_SIZE']) * 1024),
+          'fetch_size_kib': round(sizes['FETCH_SIZE'], 1), 'write_size_kib': round(sizes['WRITE_SIZE'], 1),
+          'source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this script '
+                    '(separate passes, device leg, one timed pass), median over the dispatches of ' + base,
+          'correction': 'FETCH_SIZE x2 (gfx950: 64 B tallied per 128-B request of a wide coalesced read), WRITE_SIZE as reported; KiB per dispatch',
+          'min_max_dispatches': spread, 'seconds': round(time.perf_counter() - t0, 1)}
 
 
 def reference_rates():
@@ -469,6 +555,12 @@ def main(argv=None):
   local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
   rank_cores = pin_rank_to_cores(local_rank, local_world)
 
+  # HBM traffic of the dominant kernel, measured for THIS command where rocprofv3 is there (two counter sub-runs of a
+  # few seconds each, BEFORE this process creates its HIP context); otherwise the newest committed record stays
+  live_traffic = None
+  if world == 1 and rank == 0 and args.device == 'cuda':
+    live_traffic = measured_traffic(sys.argv[1:] if argv is None else list(argv))
+
   import torch  # device memory + torch.distributed only
 
   cfg = dict(CONFIGS[args.config])
@@ -608,6 +700,8 @@ def main(argv=None):
   result = None
   if rank == 0:
     roofline = w.roofline(rates['device'] / world)  # (the path fractions are the HBM-resident leg's)
+    if live_traffic and live_traffic.pop('kernel') == roofline['kernel']:
+      roofline['traffic'] = live_traffic   # (measured for this very command, before this process took the device)
     # ---- CPU baseline: the oracle on this box's cores, bounded sample
     cpu = None
     if not args.no_cpu_baseline and on_gpu:
