@@ -1242,8 +1242,17 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
       const size_t shmem = big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B);
       decode_kernel = UIS_DK_WINDOW;
+      // (BASELINE configs[2]'s shape as compile-time constants: beam 50, cap 12, look_ahead 2, one level of 650 hypotheses;
+      // UIS_NO_SHAPE_CLASSES=1 keeps the run-time instantiation: A/B switch, bit-identical)
+      const bool win_c2 = m.D == m.Dp && m.H == m.Hp && m.Hp == 512 && m.Dp == 256 && B == 50 && Kmax == 12 && L == 2 &&
+                          NC == (int64_t)B * (Kmax + 1) && S == B * Kmax + B + B * (Kmax + 1) && !getenv("UIS_NO_SHAPE_CLASSES");
+      if (win_c2) {
+        void (*kern)(DevModel, DecodeState) = &k_decode_big<512, 256, false, 50, 12, true>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        if ((rc = gl.run_cooperative(UIS_K_GRU, kern, h->n_cu, dim3(32 * ncl), dim3(512), shmem, m, gp.st))) return rc;
+      }
 #define UIS_WIN_CASE(HPV, DPV)                                                                                        \
-  if (m.Hp == HPV && m.Dp == DPV) {                                                                                  \
+  if (m.Hp == HPV && m.Dp == DPV && !win_c2) {                                                                       \
     void (*kern)(DevModel, DecodeState) = &k_decode_big<HPV, DPV, false, 0, 0, true>;                               \
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                (int)shmem));                                                                         \

@@ -3775,7 +3775,10 @@ template <int HP, int DP, bool WS = false, int CB = 0, int CK = 0, bool WIN = fa
 __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) {
   static_assert(!(WIN && WS), "one kind of select stage");
   m.Hp = HP; m.Dp = DP; m.G = 3 * HP;  // (what the template arguments say)
-  if (CB) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }  // (see k_decode_resident)
+  if (CB && !WIN) { st.B = CB; st.Kmax = CK; st.S = CB * CK + CB; m.H = HP; m.D = DP; }  // (see k_decode_resident)
+  // WIN with a fixed shape (round 5: BASELINE configs[2], beam 50 / cap 12): look_ahead 2, one intermediate level of
+  // beam_size * (max_clusters + 1) hypotheses (below the level capacity: the host checks), its slots behind the beam's
+  if (CB && WIN) { st.B = CB; st.Kmax = CK; st.L = 2; st.NC = CB * (CK + 1); st.S = CB * CK + CB + CB * (CK + 1); m.H = HP; m.D = DP; }
   constexpr int NKB = HP / 16;
   constexpr int NFT1 = HP / 16, SH1 = 32 / NFT1;  // ranks sharing one GRU / linear_mean1 feature tile
   constexpr int NFT2 = DP / 16, SH2 = 32 / NFT2;  // ranks sharing one linear_mean2 feature tile
