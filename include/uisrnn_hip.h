@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UIS_ABI_VERSION 5
+#define UIS_ABI_VERSION 6
 
 typedef enum uis_status {
   UIS_OK = 0,
@@ -39,9 +39,12 @@ typedef enum uis_status {
   UIS_ERR_CLUSTER_CAP = -6,   /* a surviving hypothesis needed more than max_clusters
                                  clusters; labels_out of the flagged utterances are
                                  invalid -- retry with a larger cap (the Python host does) */
-  UIS_ERR_UNSUPPORTED = -7    /* option combination outside the built kernels' range; also: a
-                                 look_ahead >= 2 window had more live assignment prefixes than
-                                 the level capacity (a larger max_clusters cannot help)      */
+  UIS_ERR_UNSUPPORTED = -7    /* an option value beyond a field width (beam_size > 32767, look_ahead > 1024,
+                                 max_clusters > 4096), a UIS_FLAG_RESIDENT request where no one-launch kernel
+                                 applies; also: a look_ahead >= 2 window had more live assignment prefixes than
+                                 the level capacity (uis_decode_opts.level_cap: bit 1 of the utterance's flags in
+                                 uis_last_decode_info; decode those again with a larger one -- a larger
+                                 max_clusters cannot help)                                    */
 } uis_status;
 
 /*
@@ -71,8 +74,10 @@ typedef struct uis_model_desc {
 
 /* Inference options (reference: uisrnn/arguments.py:172-193). */
 typedef struct uis_decode_opts {
-  int32_t beam_size;       /* args.beam_size       (>= 1)                     */
-  int32_t look_ahead;      /* args.look_ahead      (>= 1)                     */
+  int32_t beam_size;       /* args.beam_size       (>= 1; beyond 256 -- and wherever max_clusters outgrows the
+                              select kernels' LDS -- the window machinery decodes: a launch per sub-step,
+                              candidate lists in HBM; at most 32767)                                */
+  int32_t look_ahead;      /* args.look_ahead      (>= 1, at most 1024)       */
   int32_t test_iteration;  /* args.test_iteration  (>= 1)                     */
   int32_t max_clusters;    /* per-hypothesis cluster cap; 0 = default (16)    */
   uint32_t flags;          /* UIS_FLAG_*                                      */
@@ -192,7 +197,7 @@ enum {
   UIS_DK_SMALL = 6,      /* one launch, one workgroup per utterance: small models, any rnn_depth, any look_ahead (k_decode_small) */
   UIS_DK_WINDOW = 7,     /* one launch, look_ahead >= 2: a window sub-step as the select stage (k_decode_big<WIN>) */
   UIS_DK_DEEP = 8,       /* one launch, rnn_depth >= 2 at hidden size 128 / 256 / 512: the weight slot refilled per stage (k_decode_deep) */
-  UIS_DK_BIG_COH = 9     /* one launch, a wave per row tile, two utterance cohorts in flight per XCD (k_decode_coh) */
+  UIS_DK_BIG_COH = 9     /* one launch, a wave per row tile, two utterance cohorts in flight per XCD (k_decode_coh; UIS_FLAG_COHORTS) */
 };
 /* ... in bits 16..23 for UIS_DK_RS its instantiation: 1 base, 2 base with the shape of BASELINE configs[1] as
  * compile-time constants, 3 two utterances per wave (9 .. 16 per XCD), 4 wide (beam_size <= 32 / observation

@@ -120,7 +120,7 @@ def test_library_exports_every_declared_symbol():
   lib = _capi.load_library()
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.uis_abi_version() == _capi.UIS_ABI_VERSION == 5
+  assert lib.uis_abi_version() == _capi.UIS_ABI_VERSION == 6
   version = int(re.search(r'#define UIS_NUMERICS_VERSION (\d+)', open(
       os.path.join(ROOT, 'include', 'uis_numerics.h')).read()).group(1))
   assert lib.uis_numerics_version() == version

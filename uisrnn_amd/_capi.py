@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libuisrnn_hip.so')
 
 UIS_OK = 0
-UIS_ABI_VERSION = 5   # include/uisrnn_hip.h
+UIS_ABI_VERSION = 6   # include/uisrnn_hip.h
 UIS_ERR_INVALID_ARG = -1
 UIS_ERR_DIM_MISMATCH = -2
 UIS_ERR_NO_DEVICE = -3
