@@ -115,7 +115,7 @@ class Stats(ctypes.Structure):
       ('n_overflow', ctypes.c_int32),
       ('n_streams', ctypes.c_int32),
       ('decode_kernel', ctypes.c_int32),
-      ('reserved1', ctypes.c_int32),
+      ('decode_launches', ctypes.c_int32),
   ]
 
   def as_dict(self):
@@ -126,6 +126,7 @@ class Stats(ctypes.Structure):
         'rnn_rows_nodedup': self.rnn_rows_nodedup,
         'candidates': self.candidates,
         'decode_ms': self.decode_ms,
+        'decode_launches': self.decode_launches,
         'kernel_ms': {n: self.kernel_ms[i] for i, n in enumerate(KERNEL_NAMES)},
         'kernel_launches': {
             n: self.kernel_launches[i] for i, n in enumerate(KERNEL_NAMES)},

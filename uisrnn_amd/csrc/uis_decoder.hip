@@ -192,7 +192,7 @@ struct uis_handle {
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores, utt_nrows, hst;
   size_t dbg_floats = 0;  // what the last decode left in dbg_scores (UIS_FLAG_DEBUG_SCORES)
-  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl;
+  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl, resume;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
   // uis_decode_f64: the caller's float64 utterances (set for the duration of that call) and the
   // pinned float32 staging buffer they are cast into, chunk by chunk, ahead of each H2D copy
@@ -527,10 +527,20 @@ struct CastTeam {
   int64_t nblocks = 0;
   std::atomic<int64_t> next{0};
   std::vector<std::atomic<unsigned char>> done;
-  CastTeam(const double* const* utt_, const int64_t* offsets_, int n_utt_, int D_, int64_t F_, float* dst_)
-      : utt(utt_), offsets(offsets_), n_utt(n_utt_), D(D_), F(F_), dst(dst_), nblocks((F_ + kBlockRows - 1) / kBlockRows),
-        done((size_t)((F_ + kBlockRows - 1) / kBlockRows)) {
+  // (round 5) `order`, if given: the row ranges to cast, in this order, instead of the packed matrix front to back --
+  // the first frames of EVERY utterance before the later ones, when a decode starts on a time slice
+  std::vector<std::pair<int64_t, int64_t>> order;
+  CastTeam(const double* const* utt_, const int64_t* offsets_, int n_utt_, int D_, int64_t F_, float* dst_,
+           std::vector<std::pair<int64_t, int64_t>> order_ = {})
+      : utt(utt_), offsets(offsets_), n_utt(n_utt_), D(D_), F(F_), dst(dst_),
+        nblocks(order_.empty() ? (F_ + kBlockRows - 1) / kBlockRows : (int64_t)order_.size()),
+        done((size_t)(order_.empty() ? (F_ + kBlockRows - 1) / kBlockRows : (int64_t)order_.size())), order(std::move(order_)) {
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
+  }
+  void wait_blocks(int64_t b1) {  // blocks [0, b1) of `order` are cast when this returns
+    for (int64_t b = 0; b < b1; ++b)
+      while (!done[(size_t)b].load(std::memory_order_acquire))
+        if (!take()) std::this_thread::yield();
   }
   // how many threads are worth waking: >= 1 MB of input each
   unsigned want_threads(unsigned have) const {
@@ -539,7 +549,8 @@ struct CastTeam {
   bool take() {  // one block, if there is one left
     const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
     if (b >= nblocks) return false;
-    cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows));
+    if (order.empty()) cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows));
+    else cast_block(order[(size_t)b].first, order[(size_t)b].second);
 #if defined(UIS_HOST_SSE2)
     _mm_sfence();  // (the streaming stores above are ordered before the flag)
 #endif
@@ -805,6 +816,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 #endif
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   ENSURE(utt_nrows, (size_t)U * 2 * 4);
+  ENSURE(resume, (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16);  // (a decode in two launches: DecodeState::resume)
   // the whole decode in one launch with register-resident weights (k_decode_resident)
   const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) &&
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
@@ -946,6 +958,107 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   if (const char* e = getenv("UIS_CTL_OFFSET")) ctl_off = std::min<size_t>((size_t)atol(e) & ~(size_t)127, ctl_place[3]);  // experiments
   uint32_t* const ctl = reinterpret_cast<uint32_t*>(h->cluster_ctl.as<char>() + ctl_off);
 
+  // ... with the selects of a rank's utterances running concurrently, one wave each (k_decode_big<.., true>),
+  // where the single-wave select applies; UIS_FLAG_OWNER_SELECT keeps them one after the other
+  const int per_rank = (((U + nclq - 1) / nclq) + 31) / 32;
+  const bool ws_shape = !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
+                        rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
+                        big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+  // Where k_decode_big takes over from k_decode_resident (round 5, from the sweep profiles/r05_usweep_dispatch.json:
+  // 128 utterances 2.03 against 1.89 M frames/s, 160: 2.20 / 2.22, 192: 2.31 / 2.46, 224: 2.42 / 2.52, 256: 2.43 /
+  // 2.65): with the concurrent single-wave selects from 21 utterances per XCD on (rounds 2-4 switched at "more
+  // utterances than workgroups", 33 per XCD); without them (observation dim 512, wide beams) the sequential
+  // selects keep the old switch (profiles/r05_usweep_c4_shape.json: a tie at 128).  UIS_BIG_MIN_U: experiments.
+  const int big_from = getenv("UIS_BIG_MIN_U") ? atoi(getenv("UIS_BIG_MIN_U")) : (ws_shape ? 20 : 32) * ncl + 1;
+  const bool big = resident && U >= big_from && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
+                   big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
+  const bool big_ws = big && ws_shape;
+  // ... or, on request (UIS_FLAG_COHORTS / UIS_COHORTS=1: measured slower, an experiment that stays tested), as two
+  // utterance cohorts in flight per XCD (k_decode_coh: a cohort's select and hand-off waits filled with the other
+  // cohort's dense stages)
+  const bool coh = big_ws && ((opts->flags & UIS_FLAG_COHORTS) || getenv("UIS_COHORTS")) &&
+                   coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+  // ---- (round 5) ingestion overlapped with the decode.  The one-launch kernels own every CU, so nothing can be
+  // copied-and-projected "behind" them -- but k_decode_rs / k_decode_big<WS> can stop after any step and pick up again
+  // (DecodeState::step0 / step1 / resume).  For a list of equal-length utterances given in HOST memory the decode is
+  // several launches: the first slice of every utterance's frames travels (one strided copy) and is projected, the
+  // first launch decodes the steps that need nothing else (a step looks one frame ahead: the early MSEs and the
+  // partial sums of the next select), the next slice travels and is projected behind it, and so on.  What is left
+  // exposed of the PCIe leg is the first slice.  UIS_NO_SPLIT=1 keeps one launch (A/B switch, bit-identical).
+  int64_t uniN = n_utt > 0 ? offsets[1] - offsets[0] : 0;
+  for (int u = 1; u < n_utt && uniN > 0; ++u)
+    if (offsets[u + 1] - offsets[u] != uniN) uniN = 0;
+  // slice boundaries 0 < t_1 < t_2 < ... < N: launch k decodes steps [t_k - 1, t_{k+1} - 1) (the first from 0, the last
+  // to the end) while slice k + 1 travels.  Default: 32 frames first (what is exposed), then as many as travel during
+  // the launch before (below); UIS_SPLIT_FRAMES="t1,t2,..." sets them
+  std::vector<int64_t> cuts;
+  if (uniN >= 128) {
+    if (const char* e = getenv("UIS_SPLIT_FRAMES")) {
+      for (const char* p2 = e; *p2;) {
+        char* end = nullptr;
+        const long v = strtol(p2, &end, 10);
+        if (end == p2) break;
+        const int64_t lo = cuts.empty() ? 32 : cuts.back() + 32;
+        if (lo <= uniN - 32) cuts.push_back(std::max<int64_t>(lo, std::min<int64_t>(v, uniN - 32)));
+        p2 = *end ? end + 1 : end;
+      }
+    } else {
+      // A launch must last as long as the next slice travels, and every further launch costs ~0.15 ms (measured:
+      // configs[1] with cuts 32 | 32,128 | 32,96,288: 1.622 / 1.604 / 1.591 M frames/s from pinned float32).  Model:
+      // a decode step takes ~(11.7 + 0.108 U) us (profiles/r05_usweep.json), a frame of every utterance U D 4 bytes at
+      // ~45 GB/s (a quarter more through the float64 cast); slice k + 1 = what travels during 0.9 of launch k, and a
+      // last slice below a quarter of the utterance is not worth a launch of its own.
+      const double step_us = 11.7 + 0.108 * U, frame_us = (double)U * m.D * 4.0 / 45e3 * (h->src64 ? 1.25 : 1.0);
+      int64_t prev = 0, cur = 32;
+      while (cur <= uniN - 32 && (int)cuts.size() < 6) {
+        if (!cuts.empty() && uniN - cur < uniN / 4) break;
+        cuts.push_back(cur);
+        const int64_t next = cur + std::max<int64_t>(32, (int64_t)(0.9 * (double)(cur - prev) * step_us / frame_us));
+        prev = cur; cur = next;
+      }
+    }
+  }
+  const int64_t T1 = cuts.empty() ? 0 : cuts[0];
+  const bool split = T1 > 0 && h_frames && F > 0 && resident && (rs_kind == RS_BASE || rs_kind == RS_C1 || (big_ws && !coh)) && !profile &&
+                     !dbg && m.D == m.Dp && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
+                     !getenv("UIS_NO_SPLIT");
+  std::unique_ptr<CastTeam> team;
+  struct TeamGuard {  // nobody may still be inside the team when it goes out of scope
+    CastPool* pool = nullptr;
+    ~TeamGuard() { if (pool) pool->finish(); }
+  } team_guard;
+  int64_t cast_blocks_a = 0;
+  // (split) what travels as ONE strided copy: a slice, or -- float64 lists, whose cast feeds the copies -- a piece of a
+  // slice, so that a piece is on its way while the next one is cast; slice k = units [unit_first[k], unit_first[k + 1])
+  struct CopyUnit { int64_t t0, t1; };
+  std::vector<CopyUnit> units;
+  std::vector<size_t> unit_first;
+  std::vector<int64_t> cast_blocks_upto;  // blocks of the cast's order that end unit i
+  if (split) {
+    for (size_t k = 0; k <= cuts.size(); ++k) {
+      const int64_t t0 = k ? cuts[k - 1] : 0, t1 = k < cuts.size() ? cuts[k] : uniN;
+      const int np = (k > 0 && h->src64) ? (int)std::max<int64_t>(1, std::min<int64_t>(8, (t1 - t0) / 64)) : 1;
+      unit_first.push_back(units.size());
+      for (int q = 0; q < np; ++q) units.push_back(CopyUnit{t0 + (t1 - t0) * q / np, t0 + (t1 - t0) * (q + 1) / np});
+    }
+    unit_first.push_back(units.size());
+  }
+  if (split && h->src64) {
+    // the cast starts NOW, in the order the frames are needed (every utterance's first slice, then the next ...), while
+    // this thread is still busy with the decode's tables and memsets
+    std::vector<std::pair<int64_t, int64_t>> order;
+    for (size_t un = 0; un < units.size(); ++un) {
+      for (int u = 0; u < n_utt; ++u)
+        for (int64_t r = offsets[u] + units[un].t0; r < offsets[u] + units[un].t1; r += CastTeam::kBlockRows)
+          order.emplace_back(r, std::min(offsets[u] + units[un].t1, r + CastTeam::kBlockRows));
+      cast_blocks_upto.push_back((int64_t)order.size());
+    }
+    cast_blocks_a = cast_blocks_upto[0];
+    if (!h->cast_pool) h->cast_pool = new CastPool();
+    team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast, std::move(order)));
+    team_guard.pool = static_cast<CastPool*>(h->cast_pool);
+    team_guard.pool->post(team.get());
+  }
   // ---- per-decode tables
   std::vector<double> logblk(n_log), logden(n_log);
   for (int64_t n = 0; n < n_log; ++n) {
@@ -982,15 +1095,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       const float* xin = d_x + (size_t)f0 * m.Dp;
       float* gout = h->gi0.as<float>() + (size_t)f0 * m.G;
       const bool pipe = !(opts->flags & UIS_FLAG_SMALL_TILES);  // (the flag keeps the plain walk for A/B runs)
-      if (pipe && m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n);
-      else if (pipe && m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n);
-      else if (pipe && m.Dp == 512) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n);
+      if (pipe && m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
+      else if (pipe && m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
+      else if (pipe && m.Dp == 512) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
       else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_wide, wgrid, dim3(256), 0, m, xin, gout, n);
     } else
       LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
              h->gi0.as<float>() + (size_t)f0 * m.G, n);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m,
-           d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n);
+           d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n, 0L);
     return UIS_OK;
   };
   // From here on DMA from the caller's (or the pinned staging) memory may be in flight: whichever way
@@ -1000,7 +1113,35 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     uis_handle* h;
     ~Drain() { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
   } drain_on_exit{h};
-  if (F > 0 && h_frames) {
+  // a time slice [t0, t1) of every utterance (equal lengths): input projection and fresh-cluster MSE, the
+  // utterances as batches along grid.z
+  auto pre_rows = [&](Launcher& lch, int64_t t0, int64_t t1) -> int {
+    const long n = (long)(t1 - t0);
+    const dim3 wgrid((unsigned)((n + 31) / 32), (unsigned)((m.G / 16 + 15) / 16), (unsigned)U);
+    const float* xin = d_x + (size_t)t0 * m.Dp;
+    float* gout = h->gi0.as<float>() + (size_t)t0 * m.G;
+    if (m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
+    else if (m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
+    else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
+    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4), 1, (unsigned)U), dim3(256), (size_t)5 * m.Dp * 4, m, xin,
+           h->mse0.as<float>() + t0, n, (long)uniN);
+    return UIS_OK;
+  };
+  const size_t pitch = (size_t)uniN * m.D * 4;  // (split: bytes between utterances, in the staging block and on the device)
+  if (split) {
+    while (h->h2d_done.size() < cuts.size() + 1) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->h2d_done.push_back(e);
+    }
+    HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
+    if (team) team->wait_blocks(cast_blocks_a);
+    HIPCHK(hipMemcpy2DAsync(const_cast<float*>(d_frames), pitch, h_frames, pitch, (size_t)T1 * m.D * 4, (size_t)U,
+                            hipMemcpyHostToDevice, h->copy_stream));
+    HIPCHK(hipEventRecord(h->h2d_done[0], h->copy_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->h2d_done[0], 0));
+    if ((rc = pre_rows(lch, 0, T1))) return rc;
+  } else if (F > 0 && h_frames) {
     const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / UIS_H2D_MIN_FRAMES));
     while ((int)h->h2d_done.size() < n_chunks) {
       hipEvent_t e;
@@ -1011,11 +1152,6 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     // float64 utterances: cast into the pinned staging buffer by the handle's pool (and this thread),
     // piece p + 1 while piece p copies / projects.  A projection chunk then travels in several pieces,
     // so that the first copy starts after an eighth of the cast, not half of it.
-    std::unique_ptr<CastTeam> team;
-    struct TeamGuard {  // nobody may still be inside the team when it goes out of scope
-      CastPool* pool = nullptr;
-      ~TeamGuard() { if (pool) pool->finish(); }
-    } team_guard;
     if (h->src64) {
       if (!h->cast_pool) h->cast_pool = new CastPool();
       team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast));
@@ -1073,6 +1209,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     st.cl_abort = ctl + 16;
     st.utt_nrows = h->utt_nrows.as<int32_t>() + 2 * u0;
     st.hst = deep_shape ? h->hst.as<float>() : nullptr;
+    st.step0 = 0; st.step1 = 0; st.resume = h->resume.as<unsigned char>(); st.resume_stride = 0;
     st.hst_elems = (size_t)rows_cap * m.Hp;
     st.dbg_scores = dbg ? h->dbg_scores.as<float>() + 0 : nullptr;  // (one group: groups would need their own utterance offset)
     if (resident || win || deep) {
@@ -1120,26 +1257,6 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // more utterances than workgroups: the variant whose dense stages give a wave a whole row tile
       // (k_decode_big: +6 % at 288 utterances, +17 % at 768 / 1024; up to 256 the LDS-resident beam of
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
-      // ... with the selects of a rank's utterances running concurrently, one wave each (k_decode_big<.., true>),
-      // where the single-wave select applies; UIS_FLAG_OWNER_SELECT keeps them one after the other
-      const int per_rank = (((U + ncl - 1) / ncl) + 31) / 32;
-      const bool ws_shape = !(opts->flags & UIS_FLAG_OWNER_SELECT) && m.Dp <= 256 && per_rank <= 8 &&
-                            rs_select_ok(B, Kmax, S, (long)maxT, 3) &&
-                            big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
-      // Where k_decode_big takes over from k_decode_resident (round 5, from the sweep profiles/r05_usweep_dispatch.json:
-      // 128 utterances 2.03 against 1.89 M frames/s, 160: 2.20 / 2.22, 192: 2.31 / 2.46, 224: 2.42 / 2.52, 256: 2.43 /
-      // 2.65): with the concurrent single-wave selects from 21 utterances per XCD on (rounds 2-4 switched at "more
-      // utterances than workgroups", 33 per XCD); without them (observation dim 512, wide beams) the sequential
-      // selects keep the old switch (profiles/r05_usweep_c4_shape.json: a tie at 128).  UIS_BIG_MIN_U: experiments.
-      const int big_from = getenv("UIS_BIG_MIN_U") ? atoi(getenv("UIS_BIG_MIN_U")) : (ws_shape ? 20 : 32) * ncl + 1;
-      const bool big = U >= big_from && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
-                       big_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024;
-      const bool big_ws = big && ws_shape;
-      // ... or, on request (UIS_FLAG_COHORTS / UIS_COHORTS=1: measured slower, an experiment that stays tested), as two
-      // utterance cohorts in flight per XCD (k_decode_coh: a cohort's select and hand-off waits filled with the other
-      // cohort's dense stages)
-      const bool coh = big_ws && ((opts->flags & UIS_FLAG_COHORTS) || getenv("UIS_COHORTS")) &&
-                       coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
       const bool rs_two = rs_kind == RS_UPW2 || rs_kind == RS_UPW2_C1, rs_wide = rs_kind == RS_WIDE || rs_kind == RS_WIDE_C4;
       const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_two ? 2 : 1, rs_two || rs_wide)
                                             : coh    ? coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
@@ -1153,6 +1270,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       const bool exact = m.D == m.Dp && m.H == m.Hp && !getenv("UIS_NO_SHAPE_CLASSES");
       const bool cls_c1 = exact && m.Hp == 512 && m.Dp == 256 && B == 10 && Kmax == 16;   // configs[1] / [3]: beam 10, cap 16
       const bool cls_c4 = exact && m.Hp == 512 && m.Dp == 512 && B == 20 && Kmax == 11;   // configs[4]: beam 20, cap 11
+      // (round 5) the launch as a function of the step range: once for the whole decode, or twice with the rest of the
+      // frames arriving behind the first launch (split, above)
+      auto launch_resident = [&]() -> int {
 #define UIS_COH_CASE(HPV, DPV, COND, ...)                                                                             \
   if (m.Hp == HPV && m.Dp == DPV && coh && (COND)) {                                                                 \
     void (*kern)(DevModel, DecodeState) = &k_decode_coh<HPV, DPV, ##__VA_ARGS__>;                                    \
@@ -1237,6 +1357,31 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_RESIDENT_CASE(128, 128)
       UIS_RESIDENT_CASE(128, 512)
 #undef UIS_RESIDENT_CASE
+        return UIS_OK;
+      };
+      if (!split) {
+        if ((rc = launch_resident())) return rc;
+      } else {
+        for (size_t k = 0; k <= cuts.size(); ++k) {
+          if (k > 0) {
+            // slice k of every utterance: cast (float64 lists), one strided copy, projection -- behind launch k - 1
+            const int64_t t0 = cuts[k - 1], t1 = k < cuts.size() ? cuts[k] : uniN;
+            for (size_t un = unit_first[k]; un < unit_first[k + 1]; ++un) {
+              if (team) team->wait_blocks(cast_blocks_upto[un]);
+              HIPCHK(hipMemcpy2DAsync(const_cast<float*>(d_frames) + (size_t)units[un].t0 * m.D, pitch, h_frames + (size_t)units[un].t0 * m.D,
+                                      pitch, (size_t)(units[un].t1 - units[un].t0) * m.D * 4, (size_t)U, hipMemcpyHostToDevice, h->copy_stream));
+            }
+            HIPCHK(hipEventRecord(h->h2d_done[k], h->copy_stream));
+            HIPCHK(hipStreamWaitEvent(sg, h->h2d_done[k], 0));
+            if ((rc = pre_rows(gl, t0, t1))) return rc;
+            // (k_decode_big<WS> counts its barriers and rows from zero in every launch; the abort word and the XCC ids stay)
+            if (!rs) HIPCHK(hipMemsetAsync(ctl + 32, 0, (ctl_words - 32) * 4, sg));
+          }
+          gp.st.step0 = k ? (int)cuts[k - 1] - 1 : 0;
+          gp.st.step1 = k < cuts.size() ? (int)cuts[k] - 1 : 0;
+          if ((rc = launch_resident())) return rc;
+        }
+      }
     } else if (win) {
       // h1 into the extra slot, then ONE launch for every sub-step of every window
       HIPCHK(hipMemcpyAsync(gp.st.pool_hid + (size_t)U * S * m.Hp, m.h1, (size_t)m.Hp * 4, hipMemcpyDeviceToDevice, sg));
@@ -1495,6 +1640,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     stats->n_overflow = n_over;
     stats->n_streams = G;
     stats->decode_kernel = decode_kernel;
+    stats->decode_launches = (resident || win || deep || small) ? (split ? (int)cuts.size() + 1 : 1) : 0;
     if (profile) {
       for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
         float t = 0.0f;
@@ -1568,7 +1714,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows, &h->hst,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows, &h->hst, &h->resume,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};
@@ -2300,7 +2446,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   if (!fused) {
     LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-           ss.chunk_mse0.as<float>(), (long)F);
+           ss.chunk_mse0.as<float>(), (long)F, 0L);
   }
   HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
   st.push_F = fused ? (int)F : 0;
@@ -2337,7 +2483,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
       if (fused) {  // ... and they need the chunk's gi0 / mse0
         LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
         LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-               ss.chunk_mse0.as<float>(), (long)F);
+               ss.chunk_mse0.as<float>(), (long)F, 0L);
         st.push_F = 0;
       }
     } else if (rc) return rc;

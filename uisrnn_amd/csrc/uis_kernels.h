@@ -82,6 +82,13 @@ struct DecodeState {
   int U, B, Kmax, S, L, tau;
   int max_rows;           // capacity of `rows` = the most rnn rows one step can emit
   uint32_t flags;
+  // round 5: a decode in TWO launches (k_decode_rs, k_decode_big<WS>): this launch runs decode steps [step0, step1) of
+  // every utterance (step1 = 0: to the end); a launch that stops early leaves the beam state it keeps in LDS in
+  // `resume` (resume_stride bytes per cluster) and the next one picks it up -- so that the later frames of every
+  // utterance may still be on their way to the device while the first launch decodes the earlier ones
+  int step0, step1;
+  unsigned char* resume;
+  size_t resume_stride;
   int wnd;                // 1: the window machinery decodes (k_window, level buffers, window records): look_ahead >= 2,
                           // and look_ahead 1 with a beam / cluster cap the select kernels do not take (round 5)
   // utterances

@@ -320,11 +320,15 @@ __global__ __launch_bounds__(256) void k_dense_input_proj_wide(DevModel m, const
 // requested before the MFMAs of the current one, everything unrolled, two register sets in turn.
 // Without it a segment's loads wait for the previous segment's MFMAs and the MFMAs for the loads.
 // Same order of operations per accumulator as chain_blocks (k-blocks ascending, e = 0..3).
+// (batch_stride: rows between the batches of `nframes` rows that gridDim.z counts -- a time slice [t0, t1) of every
+// utterance of a list of equal-length utterances; one batch and 0 otherwise)
 template <int PER>
 __global__ __launch_bounds__(256) void k_dense_input_proj_pipe(DevModel m, const float* __restrict__ x,
-                                                               float* __restrict__ gi0, long nframes) {
+                                                               float* __restrict__ gi0, long nframes, long batch_stride) {
   constexpr int NA = 4, NB = 2;
   constexpr int STG = PER >= 2 ? 2 : 1, SPS = PER / STG, NS = UIS_KSPLIT * SPS, NKB = UIS_KSPLIT * PER;
+  x += (size_t)blockIdx.z * (size_t)batch_stride * (NKB * 16);
+  gi0 += (size_t)blockIdx.z * (size_t)batch_stride * m.G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
   const int ntiles = m.G / 16;
   const int tile0 = (blockIdx.y * 4 + wave) * NA;
@@ -788,8 +792,10 @@ __device__ __forceinline__ f32x4 load_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
 __global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restrict__ x,
-                                              float* __restrict__ mse0, long nframes) {
+                                              float* __restrict__ mse0, long nframes, long batch_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  x += (size_t)blockIdx.z * (size_t)batch_stride * m.Dp;   // (batches along grid.z: see k_dense_input_proj_pipe)
+  mse0 += (size_t)blockIdx.z * (size_t)batch_stride;
   float* swgt = reinterpret_cast<float*>(smem_raw);
   float* sx = swgt + m.Dp;  // 4 waves x Dp
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3862,6 +3868,15 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   }
   __syncthreads();
   const int nsteps = s_ctl[1];
+  // (round 5, WS only) this launch runs steps [step0, s_end) of the decode: a launch that starts late picks up the
+  // persistent blocks the previous one left in st.resume (one per utterance, by the wave that owns it)
+  const int step0 = WS ? st.step0 : 0;
+  const int s_end = (WS && st.step1 > 0 && st.step1 < nsteps) ? st.step1 : nsteps;
+  if (WS && step0 > 0 && has_u) {
+    const int* src = reinterpret_cast<const int*>(st.resume + (size_t)u_w * RL.persist_stride);
+    for (int i = lane; i < RL.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w)[i] = src[i];
+    fpos_w = N_w > 0 ? (long)step0 % N_w : 0;
+  }
   const f32x4* w1g = reinterpret_cast<const f32x4*>(m.w1) + (size_t)ft1 * NKB * 64;
   const f32x4* w2g = reinterpret_cast<const f32x4*>(m.w2) + (size_t)ft2 * NKB * 64;
 
@@ -3890,7 +3905,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   unsigned long long wv_acc = 0;
   unsigned long long rt_prev = wall_clock64();
 #endif
-  for (int s = 0; s < nsteps; ++s) {
+  for (int s = step0; s < s_end; ++s) {
     const int par = s & 1;
     sink.count = st.rx_nrows + cluster * 32 + par;
     if constexpr (WS) {
@@ -3956,8 +3971,8 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       if (xcd_barrier(st, cluster, 32u * ++bar, s_ctl)) return;
     }
     RSTAMP(1 + (WIN ? 8 * (s & 1) : 0));
-    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
-    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+    if (s == step0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
+    if (s == step0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
     const int nrows = __hip_atomic_load(st.rx_nrows + cluster * 32 + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rank == 0 && t == 0)
@@ -4092,6 +4107,13 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   }
   if (WIN && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 248)) st.counters[80 + (blockIdx.x ? 8 : 0) + w] = wv_acc;
 #endif
+  if (WS && s_end < nsteps) {  // more steps to come in another launch
+    if (has_u) {
+      int* dst = reinterpret_cast<int*>(st.resume + (size_t)u_w * RL.persist_stride);
+      for (int i = lane; i < RL.persist_stride / 4; i += 64) dst[i] = reinterpret_cast<const int*>(pers_w)[i];
+    }
+    return;
+  }
   if (WS && has_u && lane == 0) {  // this utterance's statistics
     const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(pers_w + RL.off_stats);
     atomicAdd(&st.counters[0], acc[0]);

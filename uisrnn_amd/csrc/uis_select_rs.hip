@@ -991,6 +991,28 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   }
   __syncthreads();
   const int nsteps = s_ctl[1];
+  // (round 5) this launch runs steps [step0, s_end) of the decode: a launch that starts late picks up what the
+  // previous one left in st.resume -- per utterance its persistent block, then the rows its last step emitted
+  const int step0 = st.step0;
+  const int s_end = (st.step1 > 0 && st.step1 < nsteps) ? st.step1 : nsteps;
+  if (step0 > 0) {
+    for (int k = 0; k < SLOTS; ++k) {
+      const int u = cluster + ncl * k;
+      if (u >= U) break;
+      const int* src = reinterpret_cast<const int*>(st.resume + (size_t)u * L.persist_stride);
+      int* dst = reinterpret_cast<int*>(s_pers + (size_t)k * L.persist_stride);
+      for (int i = t; i < L.persist_stride / 4; i += 512) dst[i] = src[i];
+      if (t == 0) s_ctl[8 + k] = reinterpret_cast<const int*>(st.resume + (size_t)U * L.persist_stride)[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+      fpos_w[q] = N_w[q] > 0 ? (long)step0 % N_w[q] : 0;
+      int base = 0;
+      for (int k = 0; k < w + UIS_RS_UTT * q; ++k) base += s_ctl[8 + k];
+      prev_base[q] = base;
+    }
+  }
 
   f32x4 wg[3][PER];
   const int ft1 = rank / SH1, tpar1 = rank % SH1;
@@ -1032,8 +1054,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 
   RsPrep<NPOS> prep[UPW];  // (later steps: prepared inside the previous step's last hand-off)
 #pragma unroll
-  for (int q = 0; q < UPW; ++q) prep[q] = rs_prep<false, NPOS>(m, st, L, dm, 0, pers_w[q], scr_w[q], s_lblk, s_lden, []() {});
-  for (int s = 0; s < nsteps; ++s) {
+  for (int q = 0; q < UPW; ++q) prep[q] = rs_prep<false, NPOS>(m, st, L, dm, step0, pers_w[q], scr_w[q], s_lblk, s_lden, []() {});
+  for (int s = step0; s < s_end; ++s) {
     // ---- select, replicated: wave w decides utterance slot w (then w + 8); every workgroup gets the same rows
     RsWin win[UPW];
     bool act_w[UPW];
@@ -1182,8 +1204,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
           rs_flag_wait(st, rs_flags, (uint32_t)(16 * w), 3u * (uint32_t)s + 1u))
         s_ctl[0] = 1;
     }
-    if (s == 0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
-    if (s == 0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
+    if (s == step0 && t == 0 && rank == 1 && (st.flags & 0x100u)) xcc ^= 1u;  // UIS_FLAG_TEST_MISPLACED: pretend
+    if (s == step0 && t == 0 && __hip_atomic_load(st.cl_xcc + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc)
       __hip_atomic_store(st.cl_abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not on one XCD
     RSTAMP(3);
 
@@ -1320,6 +1342,21 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   if (t == 0 && blockIdx.x == 0) for (int k = 0; k < 8; ++k) st.counters[80 + k] = ph_acc[k];
   if (t == 0 && blockIdx.x == 31 * ncl) for (int k = 0; k < 4; ++k) st.counters[72 + k] = ft_acc[k];
 #endif
+  if (s_end < nsteps) {  // more steps to come in another launch: rank 0's copy of the cluster's tables goes to st.resume
+    __syncthreads();
+    if (s_ctl[0]) return;
+    if (rank == 0) {
+      for (int k = 0; k < SLOTS; ++k) {
+        const int u = cluster + ncl * k;
+        if (u >= U) break;
+        const int* src = reinterpret_cast<const int*>(s_pers + (size_t)k * L.persist_stride);
+        int* dst = reinterpret_cast<int*>(st.resume + (size_t)u * L.persist_stride);
+        for (int i = t; i < L.persist_stride / 4; i += 512) dst[i] = src[i];
+        if (t == 0) reinterpret_cast<int*>(st.resume + (size_t)U * L.persist_stride)[u] = s_ctl[8 + k];
+      }
+    }
+    return;
+  }
   if (rank < SLOTS && cluster + ncl * rank < U && t == 0) {  // this utterance's statistics, by its owner rank
     const unsigned long long* acc =
         reinterpret_cast<const unsigned long long*>(s_pers + (size_t)rank * L.persist_stride + L.off_stats);
