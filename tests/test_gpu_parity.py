@@ -411,6 +411,17 @@ def test_resident_decode_falls_back_when_its_placement_check_fails(oracle_lib):
   with pytest.raises(_capi.HipLibraryError):          # demanded explicitly: the failure is reported
     _capi.Decoder(params).decode(*oracle_lib.pack(seqs), 10, 1, 2,
                                  flags=_capi.UIS_FLAG_RESIDENT | _capi.UIS_FLAG_TEST_MISPLACED)
+  # (round 5) ... also when the decode was going to be several launches with the later frames travelling behind the
+  # first: the re-run brings the whole list to the device again
+  same, _ = synth.make_utterances(9200, 12, 150, 256)
+  ref = oracle_lib.decode(params, same, 10, 1, 1, n_threads=6)
+  for entry in ('f32', 'f64'):
+    dec2 = _capi.Decoder(params)
+    cap = max(int(ref['max_clusters'].max()), 4)
+    out = (dec2.decode(*oracle_lib.pack(same), 10, 1, 1, max_clusters=cap, flags=_capi.UIS_FLAG_TEST_MISPLACED, want_beam_scores=True) if entry == 'f32'
+           else dec2.decode_f64(same, 10, 1, 1, max_clusters=cap, flags=_capi.UIS_FLAG_TEST_MISPLACED, want_beam_scores=True))
+    assert out['status'] == 0 and out['stats']['decode_kernel'].startswith('stepwise') and out['stats']['decode_launches'] == 0
+    assert np.array_equal(out['labels'], np.concatenate(ref['labels'])) and np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
 
 
 def test_one_launch_decode_gives_up_on_a_silent_workgroup(oracle_lib):
@@ -1273,7 +1284,46 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
   for k, u in enumerate(sample):
     assert np.array_equal(one['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
     assert np.array_equal(_bits(one['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
-  # ragged lists and device-resident frames keep the single launch
+  # a small ragged list keeps the single launch (a slice of it is a copy per utterance: worth it from 64 MB of frames on)
   ragged = [s[:n_frames - (u % 3)] for u, s in enumerate(seqs)]
   out = dec.decode(*oracle_lib.pack(ragged), beam, 1, 2)
   assert out['status'] == 0 and out['stats']['decode_launches'] == 1
+
+
+def test_ragged_list_in_several_launches(oracle_lib, monkeypatch):
+  """... and a ragged list of 64 MB of frames or more, given as float64 arrays, does take the several launches: the cast lays
+  the staging block out slice after slice (one copy each), a kernel scatters a slice to the utterance-major frame stream,
+  the projection's batches come from a table -- utterances shorter than the first slice, shorter than a later one, of one
+  frame.  Bit for bit the single launch and (a sample) the oracle, float32 and float64 entries."""
+  import os
+  from uisrnn_amd import weights as wts
+  params = wts.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d256.uisrnn'))
+  n_utt = 300
+  lens = [150 + (37 * u) % 140 for u in range(n_utt)]
+  lens[0], lens[1], lens[2], lens[7] = 1, 20, 33, 289
+  seqs, _ = synth.make_utterances(61_000, n_utt, lens, 256)
+  assert sum(lens) * 256 * 4 >= 64e6
+  frames, offsets = oracle_lib.pack(seqs)
+  dec = _capi.Decoder(params)
+  monkeypatch.setenv('UIS_NO_SPLIT', '1')
+  one = dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True)
+  assert one['status'] == 0 and one['stats']['decode_kernel'] == 'k_decode_big<WS>' and one['stats']['decode_launches'] == 1
+  monkeypatch.delenv('UIS_NO_SPLIT')
+  for cuts in (None, '32', '40,100,200'):
+    if cuts is None:
+      monkeypatch.delenv('UIS_SPLIT_FRAMES', raising=False)
+    else:
+      monkeypatch.setenv('UIS_SPLIT_FRAMES', cuts)
+    for entry in ('f32', 'f64'):
+      two = (dec.decode(frames, offsets, 10, 1, 2, want_beam_scores=True) if entry == 'f32'
+             else dec.decode_f64(seqs, 10, 1, 2, want_beam_scores=True))
+      # (the packed float32 entry keeps one launch for a ragged list: its slices would be a copy per utterance -- measured
+      # slower; the float64 entry lays its staging block out slice after slice)
+      assert two['status'] == 0 and (two['stats']['decode_launches'] >= 2) == (entry == 'f64'), (cuts, entry, two['stats']['decode_launches'])
+      assert np.array_equal(two['labels'], one['labels']), (cuts, entry)
+      assert np.array_equal(_bits(two['beam_scores']), _bits(one['beam_scores'])), (cuts, entry)
+  sample = [0, 1, 2, 7, 150, 299]
+  ref = oracle_lib.decode(params, [seqs[u] for u in sample], 10, 1, 2, n_threads=6)
+  for k, u in enumerate(sample):
+    assert np.array_equal(one['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
+    assert np.array_equal(_bits(one['beam_scores'][u]), _bits(ref['beam_scores'][k])), u

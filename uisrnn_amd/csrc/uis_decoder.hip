@@ -192,7 +192,7 @@ struct uis_handle {
   DevBuf beam_n, beam_K, beam_last, beam_sum, beam_score, beam_slot, beam_blk, bp, rows, nrows;
   DevBuf gi_up, a1, counters, beam_scores_out, io_frames, io_labels, io_scores, mse_tab, dbg_scores, utt_nrows, hst;
   size_t dbg_floats = 0;  // what the last decode left in dbg_scores (UIS_FLAG_DEBUG_SCORES)
-  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl, resume;
+  DevBuf lv_n, lv_K, lv_last, lv_sum, lv_score, lv_origin, lv_path, lv_slot, lv_blk, scratch, bp16, bp_base, cluster_ctl, resume, split_tab, scatter_tab, stage;
   DevBuf arena;  // one allocation behind all of the above: the per-step tables share pages (TLB reach)
   // uis_decode_f64: the caller's float64 utterances (set for the duration of that call) and the
   // pinned float32 staging buffer they are cast into, chunk by chunk, ahead of each H2D copy
@@ -530,11 +530,15 @@ struct CastTeam {
   // (round 5) `order`, if given: the row ranges to cast, in this order, instead of the packed matrix front to back --
   // the first frames of EVERY utterance before the later ones, when a decode starts on a time slice
   std::vector<std::pair<int64_t, int64_t>> order;
+  // ... and `dst_rows`, if given: where block b's first row goes in the staging block (a ragged list's slices are laid
+  // out slice after slice, so that a slice is ONE copy); without it a row keeps its place in the packed matrix
+  std::vector<int64_t> dst_rows;
   CastTeam(const double* const* utt_, const int64_t* offsets_, int n_utt_, int D_, int64_t F_, float* dst_,
-           std::vector<std::pair<int64_t, int64_t>> order_ = {})
+           std::vector<std::pair<int64_t, int64_t>> order_ = {}, std::vector<int64_t> dst_rows_ = {})
       : utt(utt_), offsets(offsets_), n_utt(n_utt_), D(D_), F(F_), dst(dst_),
         nblocks(order_.empty() ? (F_ + kBlockRows - 1) / kBlockRows : (int64_t)order_.size()),
-        done((size_t)(order_.empty() ? (F_ + kBlockRows - 1) / kBlockRows : (int64_t)order_.size())), order(std::move(order_)) {
+        done((size_t)(order_.empty() ? (F_ + kBlockRows - 1) / kBlockRows : (int64_t)order_.size())), order(std::move(order_)),
+        dst_rows(std::move(dst_rows_)) {
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
   }
   void wait_blocks(int64_t b1) {  // blocks [0, b1) of `order` are cast when this returns
@@ -549,21 +553,21 @@ struct CastTeam {
   bool take() {  // one block, if there is one left
     const int64_t b = next.fetch_add(1, std::memory_order_relaxed);
     if (b >= nblocks) return false;
-    if (order.empty()) cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows));
-    else cast_block(order[(size_t)b].first, order[(size_t)b].second);
+    if (order.empty()) cast_block(b * kBlockRows, std::min(F, (b + 1) * kBlockRows), -1);
+    else cast_block(order[(size_t)b].first, order[(size_t)b].second, dst_rows.empty() ? -1 : dst_rows[(size_t)b]);
 #if defined(UIS_HOST_SSE2)
     _mm_sfence();  // (the streaming stores above are ordered before the flag)
 #endif
     done[(size_t)b].store(1, std::memory_order_release);
     return true;
   }
-  void cast_block(int64_t r0, int64_t r1) {
+  void cast_block(int64_t r0, int64_t r1, int64_t drow) {  // (drow >= 0: row r0 goes to row drow of the staging block)
     int u = (int)(std::upper_bound(offsets, offsets + n_utt + 1, r0) - offsets) - 1;  // the utterance holding row r0
     for (int64_t r = r0; r < r1;) {
       while (offsets[u + 1] <= r) ++u;  // (empty utterances)
       const int64_t e = std::min(r1, offsets[u + 1]);
       const double* src = utt[u] + (size_t)(r - offsets[u]) * D;
-      float* d = dst + (size_t)r * D;
+      float* d = dst + (size_t)(drow >= 0 ? drow + (r - r0) : r) * D;
       const int64_t n = (e - r) * D;
       int64_t i = 0;
 #if defined(UIS_HOST_SSE2)
@@ -683,6 +687,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     maxN = std::max(maxN, n);
   }
   const int64_t F = n_utt ? offsets[n_utt] : 0;
+  bool ragged_list = false;  // (utterances of different lengths)
+  for (int u = 1; u < n_utt; ++u) ragged_list = ragged_list || offsets[u + 1] - offsets[u] != offsets[1] - offsets[0];
   if (stats) memset(stats, 0, sizeof(*stats));
   h->last_U = n_utt; h->last_B = B;
   h->last_overflow.assign(n_utt, 0);
@@ -816,7 +822,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 #endif
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   ENSURE(utt_nrows, (size_t)U * 2 * 4);
-  ENSURE(resume, (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16);  // (a decode in two launches: DecodeState::resume)
+  ENSURE(resume, (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16);  // (a decode in several launches: DecodeState::resume)
+  ENSURE(split_tab, (size_t)8 * U * 2 * sizeof(long));
+  ENSURE(scatter_tab, (size_t)64 * U * 3 * sizeof(long));                                  // (... and of its copy units: the scatter's tables)
+  if (h->src64 && h_frames && F > 0 && ragged_list && (double)F * m.D * 4.0 >= 64e6) ENSURE(stage, (size_t)F * m.D * 4);                   // (... the device's copy of the time-major staging block)
+                                     // (... of a ragged list: batch tables of up to 8 slices)
   // the whole decode in one launch with register-resident weights (k_decode_resident)
   const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) &&
                            (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && G == 1 &&
@@ -985,12 +995,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // first launch decodes the steps that need nothing else (a step looks one frame ahead: the early MSEs and the
   // partial sums of the next select), the next slice travels and is projected behind it, and so on.  What is left
   // exposed of the PCIe leg is the first slice.  UIS_NO_SPLIT=1 keeps one launch (A/B switch, bit-identical).
-  int64_t uniN = n_utt > 0 ? offsets[1] - offsets[0] : 0;
-  for (int u = 1; u < n_utt && uniN > 0; ++u)
-    if (offsets[u + 1] - offsets[u] != uniN) uniN = 0;
-  // slice boundaries 0 < t_1 < t_2 < ... < N: launch k decodes steps [t_k - 1, t_{k+1} - 1) (the first from 0, the last
-  // to the end) while slice k + 1 travels.  Default: 32 frames first (what is exposed), then as many as travel during
-  // the launch before (below); UIS_SPLIT_FRAMES="t1,t2,..." sets them
+  // (utterances of equal length: a slice is ONE strided copy and the projection's batches are a constant stride apart.
+  // A ragged list: only through the float64 entry, whose staging block the library lays out itself -- slice after
+  // slice, so that a slice is one copy too, scattered to the utterance-major frame stream on the device; a copy per
+  // utterance and slice measured 2.48 against 3.59 M frames/s at a ragged configs[3] share -- and from 64 MB of frames on)
+  const bool uniform = n_utt > 0 && !ragged_list;
+  const int64_t uniN = maxN;  // the longest utterance: slice boundaries are frame indices inside an utterance
+  const bool split_shape = uniform || (h->src64 != nullptr && (double)F * m.D * 4.0 >= 64e6);
   std::vector<int64_t> cuts;
   if (uniN >= 128) {
     if (const char* e = getenv("UIS_SPLIT_FRAMES")) {
@@ -999,7 +1010,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
         const long v = strtol(p2, &end, 10);
         if (end == p2) break;
         const int64_t lo = cuts.empty() ? 32 : cuts.back() + 32;
-        if (lo <= uniN - 32) cuts.push_back(std::max<int64_t>(lo, std::min<int64_t>(v, uniN - 32)));
+        if (lo <= uniN - 32 && cuts.size() < 7) cuts.push_back(std::max<int64_t>(lo, std::min<int64_t>(v, uniN - 32)));
         p2 = *end ? end + 1 : end;
       }
     } else {
@@ -1019,7 +1030,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     }
   }
   const int64_t T1 = cuts.empty() ? 0 : cuts[0];
-  const bool split = T1 > 0 && h_frames && F > 0 && resident && (rs_kind == RS_BASE || rs_kind == RS_C1 || (big_ws && !coh)) && !profile &&
+  const bool split = T1 > 0 && split_shape && h_frames && F > 0 && resident && (rs_kind == RS_BASE || rs_kind == RS_C1 || (big_ws && !coh)) && !profile &&
                      !dbg && m.D == m.Dp && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
                      !getenv("UIS_NO_SPLIT");
   std::unique_ptr<CastTeam> team;
@@ -1034,6 +1045,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   std::vector<CopyUnit> units;
   std::vector<size_t> unit_first;
   std::vector<int64_t> cast_blocks_upto;  // blocks of the cast's order that end unit i
+  std::vector<int64_t> unit_row0;         // (ragged) first row of unit i in the staging block (one more: the end)
+  std::vector<long> scatter_tab_host;     // (ragged) k_scatter_rows' tables, unit after unit, {block row, stream row, rows} per utterance
   if (split) {
     for (size_t k = 0; k <= cuts.size(); ++k) {
       const int64_t t0 = k ? cuts[k - 1] : 0, t1 = k < cuts.size() ? cuts[k] : uniN;
@@ -1047,15 +1060,28 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     // the cast starts NOW, in the order the frames are needed (every utterance's first slice, then the next ...), while
     // this thread is still busy with the decode's tables and memsets
     std::vector<std::pair<int64_t, int64_t>> order;
+    std::vector<int64_t> dst_rows;
+    int64_t cursor = 0;  // (ragged) next free row of the staging block
     for (size_t un = 0; un < units.size(); ++un) {
-      for (int u = 0; u < n_utt; ++u)
-        for (int64_t r = offsets[u] + units[un].t0; r < offsets[u] + units[un].t1; r += CastTeam::kBlockRows)
-          order.emplace_back(r, std::min(offsets[u] + units[un].t1, r + CastTeam::kBlockRows));
+      unit_row0.push_back(cursor);
+      for (int u = 0; u < n_utt; ++u) {
+        const int64_t nu = offsets[u + 1] - offsets[u];
+        const int64_t r0 = offsets[u] + std::min(units[un].t0, nu), r1 = offsets[u] + std::min(units[un].t1, nu);
+        if (!uniform) {  // the scatter's table: {row in the block, row in the stream, rows}
+          scatter_tab_host.push_back((long)cursor); scatter_tab_host.push_back((long)r0); scatter_tab_host.push_back((long)(r1 - r0));
+        }
+        for (int64_t r = r0; r < r1; r += CastTeam::kBlockRows) {
+          order.emplace_back(r, std::min(r1, r + CastTeam::kBlockRows));
+          if (!uniform) dst_rows.push_back(cursor + (r - r0));
+        }
+        cursor += r1 - r0;
+      }
       cast_blocks_upto.push_back((int64_t)order.size());
     }
+    unit_row0.push_back(cursor);
     cast_blocks_a = cast_blocks_upto[0];
     if (!h->cast_pool) h->cast_pool = new CastPool();
-    team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast, std::move(order)));
+    team.reset(new CastTeam(h->src64, offsets, n_utt, m.D, F, h->h_cast, std::move(order), std::move(dst_rows)));
     team_guard.pool = static_cast<CastPool*>(h->cast_pool);
     team_guard.pool->post(team.get());
   }
@@ -1095,15 +1121,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       const float* xin = d_x + (size_t)f0 * m.Dp;
       float* gout = h->gi0.as<float>() + (size_t)f0 * m.G;
       const bool pipe = !(opts->flags & UIS_FLAG_SMALL_TILES);  // (the flag keeps the plain walk for A/B runs)
-      if (pipe && m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
-      else if (pipe && m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
-      else if (pipe && m.Dp == 512) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, 0L);
+      if (pipe && m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, 0L, (const long*)nullptr);
+      else if (pipe && m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, 0L, (const long*)nullptr);
+      else if (pipe && m.Dp == 512) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, 0L, (const long*)nullptr);
       else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_wide, wgrid, dim3(256), 0, m, xin, gout, n);
     } else
       LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(n, m.G / 16), dim3(256), 0, m, d_x + (size_t)f0 * m.Dp,
              h->gi0.as<float>() + (size_t)f0 * m.G, n);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m,
-           d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n, 0L);
+           d_x + (size_t)f0 * m.Dp, h->mse0.as<float>() + f0, n, 0L, (const long*)nullptr);
     return UIS_OK;
   };
   // From here on DMA from the caller's (or the pinned staging) memory may be in flight: whichever way
@@ -1115,19 +1141,44 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   } drain_on_exit{h};
   // a time slice [t0, t1) of every utterance (equal lengths): input projection and fresh-cluster MSE, the
   // utterances as batches along grid.z
-  auto pre_rows = [&](Launcher& lch, int64_t t0, int64_t t1) -> int {
+  std::vector<long> split_tab_host;  // (alive until the decode returns: the source of an asynchronous copy)
+  const size_t pitch = (size_t)uniN * m.D * 4;  // (split, equal lengths: bytes between utterances, in the staging block and on the device)
+  auto pre_rows = [&](Launcher& lch, size_t k, int64_t t0, int64_t t1) -> int {
     const long n = (long)(t1 - t0);
     const dim3 wgrid((unsigned)((n + 31) / 32), (unsigned)((m.G / 16 + 15) / 16), (unsigned)U);
-    const float* xin = d_x + (size_t)t0 * m.Dp;
-    float* gout = h->gi0.as<float>() + (size_t)t0 * m.G;
-    if (m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
-    else if (m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
-    else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN);
-    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4), 1, (unsigned)U), dim3(256), (size_t)5 * m.Dp * 4, m, xin,
-           h->mse0.as<float>() + t0, n, (long)uniN);
+    // (uniform: batch z starts z * uniN rows behind the first; ragged: the slice's table of {first row, rows} per utterance)
+    const long* tab = uniform ? nullptr : h->split_tab.as<long>() + k * (size_t)U * 2;
+    const float* xin = uniform ? d_x + (size_t)t0 * m.Dp : d_x;
+    float* gout = uniform ? h->gi0.as<float>() + (size_t)t0 * m.G : h->gi0.as<float>();
+    float* mout = uniform ? h->mse0.as<float>() + t0 : h->mse0.as<float>();
+    if (m.Dp == 128) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<1>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN, tab);
+    else if (m.Dp == 256) LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<2>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN, tab);
+    else LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj_pipe<4>, wgrid, dim3(256), 0, m, xin, gout, n, (long)uniN, tab);
+    LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((n + 3) / 4), 1, (unsigned)U), dim3(256), (size_t)5 * m.Dp * 4, m, xin, mout, n,
+           (long)uniN, tab);
     return UIS_OK;
   };
-  const size_t pitch = (size_t)uniN * m.D * 4;  // (split: bytes between utterances, in the staging block and on the device)
+  // rows [t0, t1) of every utterance, host -> device
+  auto copy_rows = [&](size_t un) -> int {
+    if (uniform) {
+      const int64_t t0 = units[un].t0, t1 = units[un].t1;
+      HIPCHK(hipMemcpy2DAsync(const_cast<float*>(d_frames) + (size_t)t0 * m.D, pitch, h_frames + (size_t)t0 * m.D, pitch,
+                              (size_t)(t1 - t0) * m.D * 4, (size_t)U, hipMemcpyHostToDevice, h->copy_stream));
+      return UIS_OK;
+    }
+    // ragged (float64 lists only): the unit is one block of the staging buffer -> the same rows of the device's block,
+    // then every utterance's part to its place in the frame stream (on the copy stream too: ordered behind the copy)
+    const int64_t r0 = unit_row0[un], r1 = unit_row0[un + 1];
+    if (r1 > r0) {
+      HIPCHK(hipMemcpyAsync(h->stage.as<float>() + (size_t)r0 * m.D, h_frames + (size_t)r0 * m.D, (size_t)(r1 - r0) * m.D * 4,
+                            hipMemcpyHostToDevice, h->copy_stream));
+      const long max_rows = (long)(units[un].t1 - units[un].t0);
+      hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)std::min<long>(64, (max_rows * (m.D / 4) + 255) / 256), (unsigned)U), dim3(256), 0,
+                         h->copy_stream, h->stage.as<float>(), const_cast<float*>(d_frames), h->scatter_tab.as<long>() + un * (size_t)U * 3, m.D);
+      HIPCHK(hipGetLastError());
+    }
+    return UIS_OK;
+  };
   if (split) {
     while (h->h2d_done.size() < cuts.size() + 1) {
       hipEvent_t e;
@@ -1135,12 +1186,27 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       h->h2d_done.push_back(e);
     }
     HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_begin, 0));
+    if (!uniform) {  // the slices' batch tables: {first row, rows} per utterance and slice
+      split_tab_host.assign((cuts.size() + 1) * (size_t)U * 2, 0L);
+      std::vector<long>& tab = split_tab_host;
+      for (size_t k = 0; k <= cuts.size(); ++k) {
+        const int64_t t0 = k ? cuts[k - 1] : 0, t1 = k < cuts.size() ? cuts[k] : uniN;
+        for (int u = 0; u < n_utt; ++u) {
+          const int64_t nu = offsets[u + 1] - offsets[u], a = std::min(t0, nu);
+          tab[(k * U + u) * 2] = (long)(offsets[u] + a);
+          tab[(k * U + u) * 2 + 1] = (long)(std::min(t1, nu) - a);
+        }
+      }
+      HIPCHK(hipMemcpyAsync(h->split_tab.p, tab.data(), tab.size() * sizeof(long), hipMemcpyHostToDevice, h->stream));
+      // (the scatter runs on the copy stream: its tables go up on that stream, ahead of the first block)
+      HIPCHK(hipMemcpyAsync(h->scatter_tab.p, scatter_tab_host.data(), scatter_tab_host.size() * sizeof(long), hipMemcpyHostToDevice,
+                            h->copy_stream));
+    }
     if (team) team->wait_blocks(cast_blocks_a);
-    HIPCHK(hipMemcpy2DAsync(const_cast<float*>(d_frames), pitch, h_frames, pitch, (size_t)T1 * m.D * 4, (size_t)U,
-                            hipMemcpyHostToDevice, h->copy_stream));
+    if ((rc = copy_rows(0))) return rc;
     HIPCHK(hipEventRecord(h->h2d_done[0], h->copy_stream));
     HIPCHK(hipStreamWaitEvent(h->stream, h->h2d_done[0], 0));
-    if ((rc = pre_rows(lch, 0, T1))) return rc;
+    if ((rc = pre_rows(lch, 0, 0, T1))) return rc;
   } else if (F > 0 && h_frames) {
     const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(UIS_H2D_CHUNKS, F / UIS_H2D_MIN_FRAMES));
     while ((int)h->h2d_done.size() < n_chunks) {
@@ -1368,12 +1434,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
             const int64_t t0 = cuts[k - 1], t1 = k < cuts.size() ? cuts[k] : uniN;
             for (size_t un = unit_first[k]; un < unit_first[k + 1]; ++un) {
               if (team) team->wait_blocks(cast_blocks_upto[un]);
-              HIPCHK(hipMemcpy2DAsync(const_cast<float*>(d_frames) + (size_t)units[un].t0 * m.D, pitch, h_frames + (size_t)units[un].t0 * m.D,
-                                      pitch, (size_t)(units[un].t1 - units[un].t0) * m.D * 4, (size_t)U, hipMemcpyHostToDevice, h->copy_stream));
+              if ((rc = copy_rows(un))) return rc;
             }
             HIPCHK(hipEventRecord(h->h2d_done[k], h->copy_stream));
             HIPCHK(hipStreamWaitEvent(sg, h->h2d_done[k], 0));
-            if ((rc = pre_rows(gl, t0, t1))) return rc;
+            if ((rc = pre_rows(gl, k, t0, t1))) return rc;
             // (k_decode_big<WS> counts its barriers and rows from zero in every launch; the abort word and the XCC ids stay)
             if (!rs) HIPCHK(hipMemsetAsync(ctl + 32, 0, (ctl_words - 32) * 4, sg));
           }
@@ -1672,8 +1737,10 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   int rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats, h_frames);
   if (rc == UIS_ERR_HIP && h && h->inlaunch_failed && opts &&
       !(opts->flags & UIS_FLAG_RESIDENT)) {
-    h->resident_off = true;  // (the frames, if they came from the host, are on the device by now)
-    rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats);
+    // (the frames, if they came from the host, travel again: a decode in several launches that was refused at its
+    // first launch has only the first slice on the device)
+    h->resident_off = true;
+    rc = decode_once(h, d_frames, offsets, n_utt, opts, d_labels, d_scores, stats, h_frames);
   }
   return rc;
 }
@@ -1714,7 +1781,7 @@ UIS_EXPORT void uis_destroy(uis_handle* h) {
   DevBuf* bufs[] = {&h->off, &h->utt_step, &h->overflow, &h->xpad, &h->gi0, &h->mse0, &h->logblk, &h->logden,
                     &h->pool_mean, &h->pool_hid, &h->pool_cnt, &h->beam_n, &h->beam_K, &h->beam_last, &h->beam_sum,
                     &h->beam_score, &h->beam_slot, &h->beam_blk, &h->bp, &h->rows, &h->nrows, &h->gi_up, &h->a1,
-                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows, &h->hst, &h->resume,
+                    &h->counters, &h->beam_scores_out, &h->io_frames, &h->io_labels, &h->io_scores, &h->mse_tab, &h->dbg_scores, &h->utt_nrows, &h->hst, &h->resume, &h->split_tab, &h->scatter_tab, &h->stage,
                     &h->lv_n, &h->lv_K, &h->lv_last, &h->lv_sum, &h->lv_score, &h->lv_origin, &h->lv_path, &h->lv_slot,
                     &h->lv_blk, &h->scratch, &h->bp16, &h->bp_base, &h->cluster_ctl, &h->arena,
                     &h->ev_a, &h->ev_b, &h->ev_off, &h->ev_out};
@@ -2446,7 +2513,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
   if (!fused) {
     LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
     LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-           ss.chunk_mse0.as<float>(), (long)F, 0L);
+           ss.chunk_mse0.as<float>(), (long)F, 0L, (const long*)nullptr);
   }
   HIPCHK(hipMemsetAsync(ss.st.nrows, 0, 8, h->stream));
   st.push_F = fused ? (int)F : 0;
@@ -2483,7 +2550,7 @@ UIS_EXPORT int32_t uis_stream_push(uis_handle* h, const float* frames, const int
       if (fused) {  // ... and they need the chunk's gi0 / mse0
         LAUNCH(UIS_K_INPUT_PROJ, k_dense_input_proj, dense_grid(F, m.G / 16), dim3(256), 0, m, d_x, ss.chunk_gi0.as<float>(), (long)F);
         LAUNCH(UIS_K_INPUT_PROJ, k_mse0, dim3((unsigned)((F + 3) / 4)), dim3(256), (size_t)5 * m.Dp * 4, m, d_x,
-               ss.chunk_mse0.as<float>(), (long)F, 0L);
+               ss.chunk_mse0.as<float>(), (long)F, 0L, (const long*)nullptr);
         st.push_F = 0;
       }
     } else if (rc) return rc;

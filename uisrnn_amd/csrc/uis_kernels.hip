@@ -322,13 +322,22 @@ __global__ __launch_bounds__(256) void k_dense_input_proj_wide(DevModel m, const
 // Same order of operations per accumulator as chain_blocks (k-blocks ascending, e = 0..3).
 // (batch_stride: rows between the batches of `nframes` rows that gridDim.z counts -- a time slice [t0, t1) of every
 // utterance of a list of equal-length utterances; one batch and 0 otherwise)
+// ... or, batch_tab given, batch z = rows [batch_tab[2 z], + batch_tab[2 z + 1]) of x / gi0: a time slice of a list of
+// utterances of any lengths (nframes then only sizes the grid)
 template <int PER>
 __global__ __launch_bounds__(256) void k_dense_input_proj_pipe(DevModel m, const float* __restrict__ x,
-                                                               float* __restrict__ gi0, long nframes, long batch_stride) {
+                                                               float* __restrict__ gi0, long nframes, long batch_stride,
+                                                               const long* __restrict__ batch_tab) {
   constexpr int NA = 4, NB = 2;
   constexpr int STG = PER >= 2 ? 2 : 1, SPS = PER / STG, NS = UIS_KSPLIT * SPS, NKB = UIS_KSPLIT * PER;
-  x += (size_t)blockIdx.z * (size_t)batch_stride * (NKB * 16);
-  gi0 += (size_t)blockIdx.z * (size_t)batch_stride * m.G;
+  if (batch_tab) {
+    x += (size_t)batch_tab[2 * blockIdx.z] * (NKB * 16);
+    gi0 += (size_t)batch_tab[2 * blockIdx.z] * m.G;
+    nframes = batch_tab[2 * blockIdx.z + 1];
+  } else {
+    x += (size_t)blockIdx.z * (size_t)batch_stride * (NKB * 16);
+    gi0 += (size_t)blockIdx.z * (size_t)batch_stride * m.G;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
   const int ntiles = m.G / 16;
   const int tile0 = (blockIdx.y * 4 + wave) * NA;
@@ -792,10 +801,17 @@ __device__ __forceinline__ f32x4 load_sc1(__amdgpu_buffer_rsrc_t rsrc, uint32_t 
 
 // mse0[frame] = weighted MSE(m0, x[frame])   (fresh-cluster score term; one wave per frame)
 __global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restrict__ x,
-                                              float* __restrict__ mse0, long nframes, long batch_stride) {
+                                              float* __restrict__ mse0, long nframes, long batch_stride,
+                                              const long* __restrict__ batch_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  x += (size_t)blockIdx.z * (size_t)batch_stride * m.Dp;   // (batches along grid.z: see k_dense_input_proj_pipe)
-  mse0 += (size_t)blockIdx.z * (size_t)batch_stride;
+  if (batch_tab) {  // (batches along grid.z: see k_dense_input_proj_pipe)
+    x += (size_t)batch_tab[2 * blockIdx.z] * m.Dp;
+    mse0 += (size_t)batch_tab[2 * blockIdx.z];
+    nframes = batch_tab[2 * blockIdx.z + 1];
+  } else {
+    x += (size_t)blockIdx.z * (size_t)batch_stride * m.Dp;
+    mse0 += (size_t)blockIdx.z * (size_t)batch_stride;
+  }
   float* swgt = reinterpret_cast<float*>(smem_raw);
   float* sx = swgt + m.Dp;  // 4 waves x Dp
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -811,6 +827,17 @@ __global__ __launch_bounds__(256) void k_mse0(DevModel m, const float* __restric
 }
 
 // Zero-pad the frame stream to Dp columns when D is not a multiple of 16.
+// (round 5) A ragged list's time slice arrives from the host as ONE block (the cast writes it utterance after
+// utterance); row i of utterance z's part goes to its place in the utterance-major frame stream.  tab[3 z] = first row
+// in the block, [3 z + 1] = first row in the stream, [3 z + 2] = rows.  16 bytes per thread.
+__global__ __launch_bounds__(256) void k_scatter_rows(const float* __restrict__ block, float* __restrict__ x,
+                                                      const long* __restrict__ tab, int D) {
+  const long s0 = tab[3 * blockIdx.y], d0 = tab[3 * blockIdx.y + 1], n = tab[3 * blockIdx.y + 2];
+  const long per_row = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * per_row; i += (long)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(x + (size_t)d0 * D)[i] = reinterpret_cast<const f32x4*>(block + (size_t)s0 * D)[i];
+}
+
 __global__ void k_pad_frames(const float* __restrict__ src, float* __restrict__ dst, long nframes, int D, int Dp) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = nframes * Dp;
