@@ -8,6 +8,7 @@ and a streaming session fed the same utterances in random chunks has to match to
 import sys
 import time
 sys.path.insert(0, '.')
+import os
 import numpy as np
 from uisrnn_amd import _capi, weights
 from oracle import oracle
@@ -47,13 +48,20 @@ def draw(rng):
   if big:  # keep the oracle (a CPU) at a second or two per case
     max_len = int(np.clip(12000 // (n_utt * beam * tau * (1 if look == 1 else 6 ** (look - 1))), 3, 48))
   lengths = [int(v) for v in rng.integers(1, max_len + 1, size=n_utt)]
+  if big and look == 1 and dim in (128, 256) and rng.random() < 0.25:
+    # (round 5) a list of equal-length utterances of 128 frames or more, given in host memory: the decode runs as several
+    # launches with the later frames travelling behind the earlier ones (k_decode_rs / k_decode_big<WS> resume); main()
+    # draws the slice boundaries
+    n_utt = int(rng.choice([1, 3, 8, 9]))
+    beam = int(rng.integers(1, 11))
+    lengths = [int(rng.integers(128, 200))] * n_utt
   return dim, hid, depth, beam, look, tau, lengths
 
 
 def main():
   rng = np.random.default_rng(SEED)
   t_end = time.time() + SECONDS
-  n_case = n_decode = n_stream = 0
+  n_case = n_decode = n_stream = n_multi = 0
   while time.time() < t_end:
     dim, hid, depth, beam, look, tau, lengths = draw(rng)
     seed = int(rng.integers(1 << 30))
@@ -78,6 +86,12 @@ def main():
 
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]
+    if len(set(lengths)) == 1 and lengths[0] >= 128:  # the several-launch decode: random slice boundaries (or the library's own)
+      cuts = sorted(set(int(v) for v in rng.integers(20, lengths[0], size=int(rng.integers(0, 4)))))
+      if cuts:
+        os.environ['UIS_SPLIT_FRAMES'] = ','.join(str(c) for c in cuts)
+      else:
+        os.environ.pop('UIS_SPLIT_FRAMES', None)
     for fl in flag_sets:
       out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, flags=fl, want_beam_scores=True)
       assert out['status'] == 0, ('status', out['status'], fl, tag)
@@ -85,6 +99,7 @@ def main():
         assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), ('labels', fl, u, tag)
       assert np.array_equal(bits(out['beam_scores']), bits(ref['beam_scores'])), ('scores', fl, tag)
       n_decode += 1
+      n_multi += out['stats']['decode_launches'] >= 2
     out = dec.decode_f64(seqs, beam, look, tau, max_clusters=cap, want_beam_scores=True)  # predict()'s own input type
     assert out['status'] == 0 and np.array_equal(bits(out['beam_scores']), bits(ref['beam_scores'])), ('f64', tag)
     assert np.array_equal(out['labels'], np.concatenate([ref['labels'][u] for u in range(len(seqs))])), ('f64 labels', tag)
@@ -116,7 +131,8 @@ def main():
         n_stream += 1
     dec.close()
     n_case += 1
-  print('fuzz: cases', n_case, 'decodes', n_decode, 'streaming sessions', n_stream, 'mismatching 0', flush=True)
+  print('fuzz: cases', n_case, 'decodes', n_decode, '(of them in several launches:', n_multi, ') streaming sessions', n_stream,
+        'mismatching 0', flush=True)
 
 
 if __name__ == '__main__':
