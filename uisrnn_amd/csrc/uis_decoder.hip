@@ -825,7 +825,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   ENSURE(resume, (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16);  // (a decode in several launches: DecodeState::resume)
   ENSURE(split_tab, (size_t)8 * U * 2 * sizeof(long));
   ENSURE(scatter_tab, (size_t)64 * U * 3 * sizeof(long));                                  // (... and of its copy units: the scatter's tables)
-  if (h->src64 && h_frames && F > 0 && ragged_list && (double)F * m.D * 4.0 >= 64e6) ENSURE(stage, (size_t)F * m.D * 4);                   // (... the device's copy of the time-major staging block)
+  if (h->src64 && h_frames && F > 0 && ragged_list && (double)F * m.D * 4.0 >= (getenv("UIS_SPLIT_MIN_MB") ? 1e6 * atof(getenv("UIS_SPLIT_MIN_MB")) : 64e6))
+    ENSURE(stage, (size_t)F * m.D * 4);                   // (... the device's copy of the time-major staging block)
                                      // (... of a ragged list: batch tables of up to 8 slices)
   // the whole decode in one launch with register-resident weights (k_decode_resident)
   const bool resident_ok = L == 1 && m.depth == 1 && (m.Hp == 128 || m.Hp == 256 || m.Hp == 512) &&
@@ -998,10 +999,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // (utterances of equal length: a slice is ONE strided copy and the projection's batches are a constant stride apart.
   // A ragged list: only through the float64 entry, whose staging block the library lays out itself -- slice after
   // slice, so that a slice is one copy too, scattered to the utterance-major frame stream on the device; a copy per
-  // utterance and slice measured 2.48 against 3.59 M frames/s at a ragged configs[3] share -- and from 64 MB of frames on)
+  // utterance and slice measured 2.48 against 3.59 M frames/s at a ragged configs[3] share -- and from 64 MB of frames on:
+  // a ragged configs[1] (24 MB) loses 3-5 % to the extra launches, 256 ragged utterances (96 MB) gain 2 %)
   const bool uniform = n_utt > 0 && !ragged_list;
   const int64_t uniN = maxN;  // the longest utterance: slice boundaries are frame indices inside an utterance
-  const bool split_shape = uniform || (h->src64 != nullptr && (double)F * m.D * 4.0 >= 64e6);
+  const double ragged_min_bytes = getenv("UIS_SPLIT_MIN_MB") ? 1e6 * atof(getenv("UIS_SPLIT_MIN_MB")) : 64e6;  // (experiments)
+  const bool split_shape = uniform || (h->src64 != nullptr && (double)F * m.D * 4.0 >= ragged_min_bytes);
   std::vector<int64_t> cuts;
   if (uniN >= 128) {
     if (const char* e = getenv("UIS_SPLIT_FRAMES")) {
