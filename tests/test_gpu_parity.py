@@ -1243,22 +1243,25 @@ def test_deep_models_decode_in_one_launch(dim, hidden, depth, oracle_lib):
     assert np.array_equal(_bits(big['beam_scores']), _bits(step['beam_scores']))
 
 
-@pytest.mark.parametrize('n_utt,n_frames,beam,want', [(64, 160, 10, 'k_decode_rs'), (23, 131, 7, 'k_decode_rs'), (300, 130, 10, 'k_decode_big<WS>')])
+@pytest.mark.parametrize('n_utt,n_frames,beam,want', [(64, 160, 10, 'k_decode_rs'), (23, 131, 7, 'k_decode_rs'), (300, 130, 10, 'k_decode_big<WS>'),
+                                                      (100, 140, 10, 'k_decode_resident'), (40, 150, 20, 'k_decode_resident')])
 def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_first(n_utt, n_frames, beam, want, oracle_lib, monkeypatch):
   """Round 5 (the verdict's item 4): a list of equal-length utterances given in HOST memory is decoded in two or more
   launches of the one-launch kernel -- the first slice of every utterance's frames travels and is projected, the first launch
   decodes the steps that need nothing else, the rest of the frames travel and are projected behind it, the second
-  launch picks the beam state up from DecodeState::resume.  Bit for bit the single launch (UIS_NO_SPLIT=1), the
+  launch picks the beam state up (k_decode_rs / k_decode_big<WS>: DecodeState::resume; k_decode_resident: the global beam tables).  Bit for bit the single launch (UIS_NO_SPLIT=1), the
   launch-per-step path and the oracle, for every split point incl. the smallest and the largest, through the packed
   float32 entry and the float64 list (uis_decode_f64: the cast in the order the frames are needed)."""
   import os
   from uisrnn_amd import weights as wts
-  params = wts.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d256.uisrnn'))
-  seqs, _ = synth.make_utterances(51_000 + n_utt, n_utt, n_frames, 256)
+  dim = 512 if beam == 20 else 256   # (beam 20: the configs[4] shape -- the model the reference trained at D = 512, cap 11)
+  cap = 11 if beam == 20 else 0
+  params = wts.load_checkpoint(os.path.join(golden_util.GOLDEN_DIR, 'trained_d{}.uisrnn'.format(dim)))
+  seqs, _ = synth.make_utterances(51_000 + n_utt, n_utt, n_frames, dim)
   frames, offsets = oracle_lib.pack(seqs)
   dec = _capi.Decoder(params)
   monkeypatch.setenv('UIS_NO_SPLIT', '1')
-  one = dec.decode(frames, offsets, beam, 1, 2, want_beam_scores=True)
+  one = dec.decode(frames, offsets, beam, 1, 2, max_clusters=cap, want_beam_scores=True)
   assert one['status'] == 0 and one['stats']['decode_kernel'] == want and one['stats']['decode_launches'] == 1
   monkeypatch.delenv('UIS_NO_SPLIT')
   for t1, launches in ((None, None), ('32', 2), ('33', 2), ('77', 2), (str(n_frames - 32), 2), ('40,81', 3), ('32,64,96', 4)):
@@ -1267,8 +1270,8 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
     else:
       monkeypatch.setenv('UIS_SPLIT_FRAMES', t1)
     for entry in ('f32', 'f64'):
-      two = (dec.decode(frames, offsets, beam, 1, 2, want_beam_scores=True) if entry == 'f32'
-             else dec.decode_f64(seqs, beam, 1, 2, want_beam_scores=True))
+      two = (dec.decode(frames, offsets, beam, 1, 2, max_clusters=cap, want_beam_scores=True) if entry == 'f32'
+             else dec.decode_f64(seqs, beam, 1, 2, max_clusters=cap, want_beam_scores=True))
       assert two['status'] == 0 and (two['stats']['decode_launches'] == launches if launches else two['stats']['decode_launches'] >= 2), (t1, entry, two['stats']['decode_launches'])
       assert two['stats']['decode_kernel'] == want
       assert np.array_equal(two['labels'], one['labels']), (t1, entry)
@@ -1276,7 +1279,7 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
       assert np.array_equal(_bits(two['beam_scores']), _bits(one['beam_scores'])), (t1, entry)
       assert two['stats']['rnn_rows'] == one['stats']['rnn_rows'] and two['stats']['candidates'] == one['stats']['candidates']
   monkeypatch.delenv('UIS_SPLIT_FRAMES', raising=False)
-  step = dec.decode(frames, offsets, beam, 1, 2, want_beam_scores=True, flags=_capi.UIS_FLAG_STEPWISE)
+  step = dec.decode(frames, offsets, beam, 1, 2, max_clusters=cap, want_beam_scores=True, flags=_capi.UIS_FLAG_STEPWISE)
   assert step['stats']['decode_launches'] == 0
   assert np.array_equal(step['labels'], one['labels']) and np.array_equal(_bits(step['beam_scores']), _bits(one['beam_scores']))
   sample = [0, n_utt // 2, n_utt - 1]
@@ -1286,7 +1289,7 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
     assert np.array_equal(_bits(one['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
   # a small ragged list keeps the single launch (a slice of it is a copy per utterance: worth it from 64 MB of frames on)
   ragged = [s[:n_frames - (u % 3)] for u, s in enumerate(seqs)]
-  out = dec.decode(*oracle_lib.pack(ragged), beam, 1, 2)
+  out = dec.decode(*oracle_lib.pack(ragged), beam, 1, 2, max_clusters=cap)
   assert out['status'] == 0 and out['stats']['decode_launches'] == 1
 
 

@@ -990,7 +990,8 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   const bool coh = big_ws && ((opts->flags & UIS_FLAG_COHORTS) || getenv("UIS_COHORTS")) &&
                    coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
   // ---- (round 5) ingestion overlapped with the decode.  The one-launch kernels own every CU, so nothing can be
-  // copied-and-projected "behind" them -- but k_decode_rs / k_decode_big<WS> can stop after any step and pick up again
+  // copied-and-projected "behind" them -- but k_decode_rs / k_decode_big<WS> / k_decode_resident (one utterance per
+  // workgroup) can stop after any step and pick up again
   // (DecodeState::step0 / step1 / resume).  For a list of equal-length utterances given in HOST memory the decode is
   // several launches: the first slice of every utterance's frames travels (one strided copy) and is projected, the
   // first launch decodes the steps that need nothing else (a step looks one frame ahead: the early MSEs and the
@@ -1033,7 +1034,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     }
   }
   const int64_t T1 = cuts.empty() ? 0 : cuts[0];
-  const bool split = T1 > 0 && split_shape && h_frames && F > 0 && resident && (rs_kind == RS_BASE || rs_kind == RS_C1 || (big_ws && !coh)) && !profile &&
+  const bool split = T1 > 0 && split_shape && h_frames && F > 0 && resident && (rs_kind == RS_BASE || rs_kind == RS_C1 || (big_ws && !coh) || (!rs && !big && U <= 32 * nclq)) && !profile &&
                      !dbg && m.D == m.Dp && (m.Dp == 128 || m.Dp == 256 || m.Dp == 512) && !(opts->flags & UIS_FLAG_SMALL_TILES) &&
                      !getenv("UIS_NO_SPLIT");
   std::unique_ptr<CastTeam> team;

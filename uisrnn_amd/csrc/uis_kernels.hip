@@ -1370,8 +1370,9 @@ __device__ __forceinline__ void select_fast_body(const DevModel& m, const Decode
       if (has_e) { sslot[tid] = r_slot; sblk[tid] = r_blk; }
       if (has_b) { sK[tid] = myK; slast[tid] = r_last; ssum[tid] = r_sum; sscore[tid] = r_score; }
       if (KEEP) {
-        // frames per slot: none yet at the start of a decode; a streaming session continues
-        for (int sl = tid; sl < S; sl += NT) spcnt[sl] = st.avail ? st.pool_cnt[(size_t)u * S + sl] : 0;
+        // frames per slot: none yet at the start of a decode; a streaming session -- or a decode in several launches
+        // past its first (round 5) -- continues
+        for (int sl = tid; sl < S; sl += NT) spcnt[sl] = (st.avail || step_in > 0) ? st.pool_cnt[(size_t)u * S + sl] : 0;
         if (tid == 0) *reinterpret_cast<int*>(set_cur + L.off_nb) = nb;
       }
     } else {
@@ -2308,10 +2309,16 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (myT > 0) atomicMax(&s_ctl[1], myT);
   }
   __syncthreads();
-  const int nsteps = s_ctl[1];
+  // (round 5) an ordinary decode in several launches (DecodeState::step0 / step1, with at most one utterance per
+  // workgroup): this launch runs steps [step0, step0 + nsteps) of every utterance; like a streaming launch it fetches the
+  // beam tables from their global copies at its first step and, if steps are left, writes them back at its end
+  const int total_steps = s_ctl[1];
+  const int range0 = (!PERSIST && !st.avail) ? st.step0 : 0;
+  const int range1 = (!PERSIST && !st.avail && st.step1 > 0 && st.step1 < total_steps) ? st.step1 : total_steps;
+  const int nsteps = (!PERSIST && !st.avail) ? (range1 > range0 ? range1 - range0 : 0) : total_steps;
   // a streaming session (st.avail): the utterance continues at its own step count; the beam
   // tables are fetched from their global copies at the launch's first step and written back at its end
-  int my_step0 = 0;
+  int my_step0 = range0;
   if (keep_beam && did_select && st.avail) my_step0 = PERSIST ? my_cur : st.utt_step[cluster + ncl * rank];
   const int first_step = PERSIST ? launch_step0 : my_step0;
   if (push_F > 0) {
@@ -2407,7 +2414,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
 #endif
 
   for (int s = 0; s < nsteps; ++s) {
-    const int par = PERSIST ? (int)((gstep + (uint32_t)s) & 1u) : (s & 1);
+    const int par = PERSIST ? (int)((gstep + (uint32_t)s) & 1u) : ((range0 + s) & 1);
     sink.count = st.rx_nrows + cluster * 32 + par;
 #if defined(UIS_RESIDENT_PROBE)  // diagnostic: dependent-load latencies seen by thread 0 at the top of a step
     if (t == 0 && blockIdx.x == 0) {
@@ -2656,6 +2663,8 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
       long done = (long)st.avail[cluster + ncl * rank] - my_step0;
       done = done < 0 ? 0 : (done > nsteps ? nsteps : done);
       if (done > 0) write_back(my_step0 + (int)done);
+    } else if (!st.avail && keep_beam && did_select && range1 < total_steps) {
+      write_back(range1);  // (a decode in several launches: the next one fetches the tables at its first step)
     }
     break;
   }
