@@ -868,8 +868,11 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
                    (U <= 32 * ncl || !getenv("UIS_WINDOW_LAUNCH_ONE_EACH")) &&
                    cluster_shape &&
                    !(opts->flags & UIS_FLAG_STEPWISE) && (!h->resident_off || (opts->flags & UIS_FLAG_RESIDENT)) &&
-                   ((double)U * S + 1) * m.Hp * 4.0 < 2.0e9 && (double)rows_cap * m.Hp * 4.0 < 2.0e9 &&
-                   (double)U * S * m.Dp * 4.0 < 2.0e9 && big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
+                   // (k_decode_big addresses its state through 4 GB descriptors with unsigned offsets since round 5; element
+                   // counts stay below 2^31 for its int arithmetic)
+                   ((double)U * S + 1) * m.Hp * 4.0 < 4.0e9 && (double)rows_cap * m.Hp * 4.0 < 4.0e9 &&
+                   ((double)U * S + 1) * m.Hp < 2.0e9 && (double)U * S * m.Dp * 4.0 < 4.0e9 &&
+                   big_win_lds_bytes(m.Hp, S, (int)NC, Kmax, B) <= 157 * 1024 &&
                    !getenv("UIS_NO_WINDOW_LAUNCH");
   if ((opts->flags & UIS_FLAG_RESIDENT) && !resident && !small && !win && !deep)
     return fail(UIS_ERR_UNSUPPORTED, "UIS_FLAG_RESIDENT needs (look_ahead 1:) one stream, beam_size * (max_clusters + 1) <= 256, no "

@@ -3918,14 +3918,17 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 
   const __amdgpu_buffer_rsrc_t rs_rows =
       __builtin_amdgcn_make_buffer_rsrc((void*)st.rows, (short)0, 0x7fffffff, 0x00020000);
+  // (round 5: the cluster states, hand-off tiles and means are addressed with UNSIGNED 32-bit byte offsets through
+  // descriptors of 4 GB - 1: a look-ahead decode of 1024 utterances at beam 50 -- 2.7 GB of hidden states -- stays in
+  // one launch; rounds 2-4 stopped at 2 GB)
   const __amdgpu_buffer_rsrc_t rs_hid =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_hid, (short)0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a1 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.a1, (short)0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mean =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.pool_mean, (short)0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_hst =
-      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)st.gi_up, (short)0, 0xffffffff, 0x00020000);
   // (hand-off buffers h' -> linear_mean1, a1 -> linear_mean2: k-block major: rs_hst, rs_a1)
   const size_t tile0 = (size_t)(cluster * st.rx_stride) >> 4;  // first row tile of this cluster
   const int rbase = cluster * st.rx_stride;   // this cluster's rows of `rows`
@@ -4060,7 +4063,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             out[i] = j4 + i < m.H ? uis_gru_unit(gir[i], giz[i], gin[i], gh[0][i], gh[1][i], gh[2][i], hprev[i]) : 0.0f;
-          rs_buf_store_f32x4(rs_hid, (uint32_t)(((rh.utt * S + rh.dst) * HP + j4) * 4), out);
+          rs_buf_store_f32x4(rs_hid, (uint32_t)((rh.utt * S + rh.dst) * HP + j4) * 4u, out);
           // ... and the copy linear_mean1 streams: [row tile][feature tile][16 rows][16], so that a
           // consumer wave's 16-byte-per-lane load is one contiguous KiB (plain rows cost one 64-byte L2
           // request per row and k-block: the request rate, not the MFMA chain, bounded the heads)
@@ -4106,7 +4109,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       const RowHead rh = load_row_head(rs_rows, rbase + (valid ? row : 16 * tile));
       const int f4 = ft2 * 16 + 4 * q;
       f32x4 old = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)(((rh.utt * S + rh.src) * DP + f4) * 4));
+      if (valid && rh.src >= 0) old = load_sc1(rs_mean, (uint32_t)((rh.utt * S + rh.src) * DP + f4) * 4u);
       f32x4 v[1], bfirst2[GBH];
       rows_first_group<GBH, 1024>(rs_a1, stage_off(tile), bfirst2);
       fullk_rows_sc1<1, NKB, 4, 1024>(s_wm, 0, bias_2, rs_a1, stage_off(tile), v, bfirst2, 0u, false);
@@ -4116,7 +4119,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
           if (rh.src >= 0) v[0][i] = uis_mean_update(old[i], v[0][i], rh.nprev);
           if (f4 + i >= m.D) v[0][i] = 0.0f;
         }
-        rs_buf_store_f32x4(rs_mean, (uint32_t)(((rh.utt * S + rh.dst) * DP + f4) * 4), v[0]);
+        rs_buf_store_f32x4(rs_mean, (uint32_t)((rh.utt * S + rh.dst) * DP + f4) * 4u, v[0]);
       }
     }
     RSTAMP(6 + (WIN ? 8 * (s & 1) : 0));
