@@ -895,7 +895,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   int rs_kind = RS_NONE;
   if (resident && !(opts->flags & UIS_FLAG_OWNER_SELECT) && (UIS_RS_DEFAULT || (opts->flags & UIS_FLAG_REPLICATED_SELECT))) {
     const int per_xcd = (U + ncl - 1) / ncl;
-    const bool base_shape = m.Dp <= 256 && rs_select_ok(B, Kmax, S, (long)maxT, 3);
+    const bool base_shape = m.Dp <= 256 && rs_select_ok(B, Kmax, S, (long)maxT, 3) && F < 0x7fffffffLL;  // (k_decode_rs keeps frame numbers in 32 bits)
     if (base_shape && per_xcd <= UIS_RS_UTT && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S) <= 160 * 1024)
       rs_kind = (m.Hp == 512 && m.Dp == 256 && m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && !getenv("UIS_RS_NO_C1") && !getenv("UIS_NO_SHAPE_CLASSES")) ? RS_C1 : RS_BASE;
     else if (base_shape && per_xcd <= 2 * UIS_RS_UTT && m.Hp == 512 && m.Dp == 256 &&
@@ -904,7 +904,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       rs_kind = (m.H == 512 && m.D == 256 && B == 10 && Kmax == 16 && getenv("UIS_RS_UPW2_C1")) ? RS_UPW2_C1 : RS_UPW2;
     else if (per_xcd <= UIS_RS_UTT && m.Hp == 512 && (m.Dp == 256 || m.Dp == 512) &&
              ((UIS_RS_WIDE_DEFAULT && !getenv("UIS_RS_NO_WIDE")) || (opts->flags & UIS_FLAG_REPLICATED_SELECT)) &&
-             rs_select_ok(B, Kmax, S, (long)maxT, 4) && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 1, true) <= 160 * 1024)
+             rs_select_ok(B, Kmax, S, (long)maxT, 4) && F < 0x7fffffffLL && resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, 1, true) <= 160 * 1024)
       rs_kind = (m.Dp == 512 && m.D == 512 && m.H == 512 && B == 20 && Kmax == 11 && getenv("UIS_RS_WIDE_C4")) ? RS_WIDE_C4 : RS_WIDE;
   }
   const bool rs = rs_kind != RS_NONE;

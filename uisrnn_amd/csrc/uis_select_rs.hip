@@ -905,6 +905,11 @@ __device__ __forceinline__ bool rs_xcd_wait(const DecodeState& st, int cluster, 
 //   CB, CK  beam_size and max_clusters as compile-time constants (0: run-time values) -- the instantiation
 //           of a shape whose LDS layout then folds into the instruction stream
 //   SPLIT2  the GRU's split-K partial tiles in two rounds (rs_tile_nv): 24 KB of LDS for the larger tables
+#if defined(UIS_RS_LONG_SCALARS)  // (A/B: rounds 3-4 kept the per-wave frame numbers in 64 bits)
+typedef long rs_idx_t;
+#else
+typedef int rs_idx_t;
+#endif
 template <int HP, int DP, int NPOS = 3, int UPW = 1, int CB = 0, int CK = 0, bool SPLIT2 = false>
 __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   constexpr int NKB = HP / 16, PER = NKB / UIS_KSPLIT, RC = UIS_RES_RC;
@@ -958,7 +963,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
   bool has_u[UPW];
   unsigned char* pers_w[UPW];
   unsigned char* scr_w[UPW];
-  long off0_w[UPW], N_w[UPW], T_w[UPW], fpos_w[UPW];
+  // (32-bit: the one-launch path decodes fewer than 2^31 frames -- the host checks -- and fewer than 65535 steps)
+  rs_idx_t off0_w[UPW], N_w[UPW], T_w[UPW], fpos_w[UPW];
   int prev_base[UPW];  // first row of the slot's utterance in the previous step's row list
 #pragma unroll
   for (int q = 0; q < UPW; ++q) {
@@ -968,8 +974,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     pers_w[q] = s_pers + (size_t)slot * L.persist_stride;
     scr_w[q] = s_scr + (size_t)slot * L.scratch_stride;
     off0_w[q] = 0; N_w[q] = 0; fpos_w[q] = 0; prev_base[q] = 0;
-    if (has_u[q]) { off0_w[q] = (long)st.off[u_w[q]]; N_w[q] = (long)st.off[u_w[q] + 1] - off0_w[q]; }
-    T_w[q] = (long)st.tau * N_w[q];
+    if (has_u[q]) { off0_w[q] = (rs_idx_t)st.off[u_w[q]]; N_w[q] = (rs_idx_t)st.off[u_w[q] + 1] - off0_w[q]; }
+    T_w[q] = st.tau * N_w[q];
     // beam_set = [BeamState()] (uisrnn.py:528): one empty hypothesis, nothing live
     for (int i = lane; i < L.persist_stride / 4; i += 64) reinterpret_cast<int*>(pers_w[q])[i] = 0;
   }
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
-      fpos_w[q] = N_w[q] > 0 ? (long)step0 % N_w[q] : 0;
+      fpos_w[q] = N_w[q] > 0 ? step0 % N_w[q] : 0;
       int base = 0;
       for (int k = 0; k < w + UIS_RS_UTT * q; ++k) base += s_ctl[8 + k];
       prev_base[q] = base;
@@ -1062,8 +1068,8 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
       win[q].keep = 0; win[q].C = 0; win[q].nlead = 0; win[q].a = 0u; win[q].b = 0u; win[q].c = 0u; win[q].score = 0.0f;
-      act_w[q] = has_u[q] && (long)s < T_w[q];
-      const long frame_w = off0_w[q] + fpos_w[q];
+      act_w[q] = has_u[q] && s < T_w[q];
+      const long frame_w = (long)(off0_w[q] + fpos_w[q]);
       if (act_w[q]) {
 #if defined(UIS_RESIDENT_TIMING)
         win[q] = rs_front<DP, false, NPOS>(m, st, L, dm, u_w[q], s, frame_w, pers_w[q], scr_w[q], rs_part, (uint32_t)(prev_base[q] * PSTR * 4),
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
         const int slot = w + UIS_RS_UTT * q;
         s_ctl[8 + slot] = win[q].nlead;
         s_wframe[slot] = frame_w;
-        s_wnext[slot] = off0_w[q] + (fpos_w[q] + 1 == N_w[q] ? 0 : fpos_w[q] + 1);  // (after the last step: some frame of the utterance, unused)
+        s_wnext[slot] = (long)(off0_w[q] + (fpos_w[q] + 1 == N_w[q] ? 0 : fpos_w[q] + 1));  // (after the last step: some frame of the utterance, unused)
       }
     }
     RSTAMP(0);
@@ -1243,12 +1249,12 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       bool peeked = false;
 #pragma unroll
       for (int q = 0; q < UPW; ++q) {
-        if (has_u[q] && (long)s + 1 < T_w[q]) {
+        if (has_u[q] && s + 1 < T_w[q]) {
           if (!peeked) {
-            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, off0_w[q] + fpos_w[q], pers_w[q], swgt, rank, w, peek);
+            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, (long)(off0_w[q] + fpos_w[q]), pers_w[q], swgt, rank, w, peek);
             peeked = true;
           } else {
-            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, off0_w[q] + fpos_w[q], pers_w[q], swgt, rank, w, []() {});
+            rs_early_mse<DP>(m, st, L, dm, u_w[q], s, (long)(off0_w[q] + fpos_w[q]), pers_w[q], swgt, rank, w, []() {});
           }
         }
       }
@@ -1322,7 +1328,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
       bool peeked = false;
 #pragma unroll
       for (int q = 0; q < UPW; ++q) {
-        if (has_u[q] && (long)s + 1 < T_w[q]) {
+        if (has_u[q] && s + 1 < T_w[q]) {
           if (!peeked) {
             prep[q] = rs_prep<false, NPOS>(m, st, L, dm, s + 1, pers_w[q], scr_w[q], s_lblk, s_lden, peek);
             peeked = true;
