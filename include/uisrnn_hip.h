@@ -251,6 +251,9 @@ void uis_destroy(uis_handle* h);
  *   scores_out : host, float32, [n_utt] or NULL -- neg_likelihood of the best hypothesis
  *   stats    : optional
  * Empty utterances (N == 0) are allowed and produce no labels.
+ * The frames travel to the device inside the call; where the one-launch kernels apply and the utterances are
+ * equally long, the decode runs as a few launches with the later frames of every utterance copied and
+ * projected behind the earlier launches (uis_stats.decode_launches; identical results).
  */
 int32_t uis_decode(uis_handle* h, const float* frames, const int64_t* offsets,
                    int32_t n_utt, const uis_decode_opts* opts,
