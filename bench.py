@@ -143,7 +143,7 @@ def _no_core_dumps():
   resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
 
 
-def measured_traffic(argv, timeout_s=240):
+def measured_traffic(argv, timeout_s=90):
   """HBM bytes per launch of `kernel`, MEASURED for this very run (round 5): two sub-runs of this script under
   `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one;
   MI355X_MICROARCH.md, HBM section), one timed pass each of the same workload with the frames resident, the
