@@ -51,7 +51,6 @@ __host__ __device__ inline size_t coh_lds_bytes(int Hp, int Dp, int B, int Kmax,
   return ((big_ws_select_bytes(Dp, B, Kmax, S, nws) + 255) & ~(size_t)255) + (size_t)4 * (Hp / 16) * 64 * 16 + UIS_COH_CTL_BYTES;
 }
 // control words (int32 view)
-#define COH_ABORT 0
 #define COH_NSTEPS 1
 #define COH_NUTT 2     // + cohort: utterances of the cohort in this cluster
 #define COH_TILE 4     // + phase: next row tile of the phase (reset by the phase's last wave)
