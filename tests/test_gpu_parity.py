@@ -1260,6 +1260,7 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
   seqs, _ = synth.make_utterances(51_000 + n_utt, n_utt, n_frames, dim)
   frames, offsets = oracle_lib.pack(seqs)
   dec = _capi.Decoder(params)
+  monkeypatch.setenv('UIS_SPLIT_MIN_MB', '0')   # (the smallest list here is 3 MB: below what the library spends a launch on)
   monkeypatch.setenv('UIS_NO_SPLIT', '1')
   one = dec.decode(frames, offsets, beam, 1, 2, max_clusters=cap, want_beam_scores=True)
   assert one['status'] == 0 and one['stats']['decode_kernel'] == want and one['stats']['decode_launches'] == 1
@@ -1287,7 +1288,10 @@ def test_decode_in_two_launches_with_the_later_frames_travelling_behind_the_firs
   for k, u in enumerate(sample):
     assert np.array_equal(one['labels'][offsets[u]:offsets[u + 1]], ref['labels'][k]), u
     assert np.array_equal(_bits(one['beam_scores'][u]), _bits(ref['beam_scores'][k])), u
-  # a small ragged list keeps the single launch (a slice of it is a copy per utterance: worth it from 64 MB of frames on)
+  # a small ragged list keeps the single launch (worth it from 64 MB of frames on), and so does a small list of equal lengths
+  monkeypatch.delenv('UIS_SPLIT_MIN_MB')
+  tiny = dec.decode(*oracle_lib.pack(seqs[:2]), beam, 1, 2, max_clusters=cap)
+  assert tiny['status'] == 0 and tiny['stats']['decode_launches'] == 1
   ragged = [s[:n_frames - (u % 3)] for u, s in enumerate(seqs)]
   out = dec.decode(*oracle_lib.pack(ragged), beam, 1, 2, max_clusters=cap)
   assert out['status'] == 0 and out['stats']['decode_launches'] == 1

@@ -86,6 +86,7 @@ def main():
 
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]
+    os.environ['UIS_SPLIT_MIN_MB'] = '0'                # (the lists here are far below the size the library spends a launch on)
     if len(set(lengths)) == 1 and lengths[0] >= 128:  # the several-launch decode: random slice boundaries (or the library's own)
       cuts = sorted(set(int(v) for v in rng.integers(20, lengths[0], size=int(rng.integers(0, 4)))))
       if cuts:

@@ -1007,8 +1007,10 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // a ragged configs[1] (24 MB) loses 3-5 % to the extra launches, 256 ragged utterances (96 MB) gain 2 %)
   const bool uniform = n_utt > 0 && !ragged_list;
   const int64_t uniN = maxN;  // the longest utterance: slice boundaries are frame indices inside an utterance
-  const double ragged_min_bytes = getenv("UIS_SPLIT_MIN_MB") ? 1e6 * atof(getenv("UIS_SPLIT_MIN_MB")) : 64e6;  // (experiments)
-  const bool split_shape = uniform || (h->src64 != nullptr && (double)F * m.D * 4.0 >= ragged_min_bytes);
+  // (... and a list too small to spend a launch on keeps one: below 8 MB of frames the whole copy takes less than the
+  // ~0.15 ms a further launch costs.  UIS_SPLIT_MIN_MB moves both sizes: tests, experiments)
+  const double split_min_bytes = getenv("UIS_SPLIT_MIN_MB") ? 1e6 * atof(getenv("UIS_SPLIT_MIN_MB")) : (uniform ? 8e6 : 64e6);
+  const bool split_shape = (uniform || h->src64 != nullptr) && (double)F * m.D * 4.0 >= split_min_bytes;
   std::vector<int64_t> cuts;
   if (uniN >= 128) {
     if (const char* e = getenv("UIS_SPLIT_FRAMES")) {
