@@ -143,7 +143,7 @@ def _no_core_dumps():
   resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
 
 
-def measured_traffic(argv, timeout_s=90):
+def measured_traffic(argv, timeout_s=180):
   """HBM bytes per launch of `kernel`, MEASURED for this very run (round 5): two sub-runs of this script under
   `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one;
   MI355X_MICROARCH.md, HBM section), one timed pass each of the same workload with the frames resident, the
@@ -189,9 +189,21 @@ def measured_traffic(argv, timeout_s=90):
                  '--timed', 'device', '--steps', '1', '--warmup', '0', '--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs']
       # (no check of the exit status: under --pmc the profiled interpreter can die in its exit handlers AFTER the counter
       # files are complete -- seen on this image, also from a shell; what decides is whether the kernel's rows are there)
-      done = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, check=False,
-                            preexec_fn=_no_core_dumps, text=True)
-      line = [l for l in done.stdout.splitlines() if l.startswith('{')]
+      # (a group of its own: on a timeout the profiler AND the interpreter under it go, so that nothing of a sub-run
+      # is still on the device when the timed passes start)
+      proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, preexec_fn=_no_core_dumps,
+                              start_new_session=True, text=True)
+      try:
+        stdout, _ = proc.communicate(timeout=timeout_s)
+      except subprocess.TimeoutExpired:
+        import signal  # pylint: disable=import-outside-toplevel
+        try:
+          os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+          pass
+        proc.communicate()
+        raise
+      line = [l for l in stdout.splitlines() if l.startswith('{')]
       kernel = json.loads(line[-1])['roofline']['kernel']   # (what the library says ran, in the sub-run's own line)
       base = kernel.split('<')[0].split(':')[-1]
       vals = []

@@ -187,3 +187,57 @@ def test_flop_model_matches_the_survey():
   assert abs(bench.flops_per_frame(deep) - bench.flops_per_frame(bench.CONFIGS[1]) - extra) < 1.0
   args = bench.parse(['--rnn_depth', '2', '--utterances', '3'])
   assert args.rnn_depth == 2 and args.utterances == 3
+
+
+_FAKE_PROFILER = textwrap.dedent('''\
+    #!{python}
+    # a stand-in for rocprofv3: writes the counter file the real one writes and runs nothing
+    import json, os, sys, time
+    args = sys.argv[1:]
+    out_dir = args[args.index('-d') + 1]
+    counter = args[args.index('--pmc') + 1]
+    cmd = args[args.index('--') + 1:]
+    assert '--kernel-trace' in args and os.environ.get('UIS_BENCH_CHILD') == '1'
+    assert cmd[-9:] == ['--timed', 'device', '--steps', '1', '--warmup', '0', '--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs'], cmd
+    assert '--utterances' in cmd and '--gpus' not in cmd
+    if os.environ.get('FAKE_PROFILER_HANGS'):
+      time.sleep(60)
+    os.makedirs(os.path.join(out_dir, 'host', '123'))
+    with open(os.path.join(out_dir, 'host', '123', 'p_counter_collection.csv'), 'w') as f:
+      f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\\n')
+      values = {{'FETCH_SIZE': [1000.0, 1002.0, 5000.0], 'WRITE_SIZE': [300.0, 301.0, 302.0]}}[counter]
+      for k, v in enumerate(values):
+        f.write('%d,"void k_decode_rs<512, 256, 3, 1, 10, 16, false>(DevModel, DecodeState)","%s",%r\\n' % (k, counter, v))
+      f.write('9,"k_backtrace(DecodeState, int*, float*, float*)","%s",77.0\\n' % counter)
+      f.write('10,"void k_decode_rs<512, 256, 3, 1, 10, 16, false>(DevModel, DecodeState)","GRBM_GUI_ACTIVE",5.0\\n')
+    print('noise')
+    print(json.dumps({{'roofline': {{'kernel': 'k_decode_rs'}}}}))
+    sys.exit(139)   # (the profiled interpreter is seen to die in its exit handlers: the rows decide, not the status)
+''')
+
+
+def test_traffic_sub_runs_read_the_counter_files(tmp_path, monkeypatch):
+  """`roofline.traffic` as bench.py measures it: the sub-run's command line, the dominant kernel's rows of the counter
+  file (median over its dispatches, FETCH_SIZE doubled, KiB), a sub-run that hangs (its whole process group goes, the
+  committed record takes over) -- with a stand-in for rocprofv3."""
+  sys.path.insert(0, ROOT)
+  import bench
+  fake = tmp_path / 'rocprofv3'
+  fake.write_text(_FAKE_PROFILER.format(python=sys.executable))
+  fake.chmod(0o755)
+  monkeypatch.setenv('PATH', str(tmp_path) + os.pathsep + os.environ['PATH'])
+  monkeypatch.delenv('UIS_BENCH_CHILD', raising=False)
+  monkeypatch.delenv('UIS_BENCH_NO_PMC', raising=False)
+  rec = bench.measured_traffic(['--gpus', '1', '--steps', '7', '--utterances', '64', '--no_cpu_baseline'], timeout_s=30)
+  assert rec['kernel'] == 'k_decode_rs'
+  assert rec['fetch_size_kib'] == 1002.0 and rec['write_size_kib'] == 301.0
+  assert rec['bytes_per_launch'] == int((2 * 1002.0 + 301.0) * 1024)
+  assert rec['min_max_dispatches'] == {'FETCH_SIZE': [1000.0, 5000.0, 3], 'WRITE_SIZE': [300.0, 302.0, 3]}
+  monkeypatch.setenv('FAKE_PROFILER_HANGS', '1')
+  import time
+  t0 = time.time()
+  assert bench.measured_traffic(['--utterances', '64'], timeout_s=2) is None
+  assert time.time() - t0 < 20
+  # ... and a sub-run never starts sub-runs of its own
+  monkeypatch.setenv('UIS_BENCH_CHILD', '1')
+  assert bench.measured_traffic(['--utterances', '64']) is None
