@@ -15,7 +15,10 @@
  * Threading: a handle is bound to one HIP device and is not thread-safe; use
  * one handle per thread / per rank.  All calls are blocking.
  * Errors: every function returns UIS_OK (0) or a negative uis_status;
- * uis_last_error() returns a thread-local message for the last failure.
+ * uis_last_error() returns a thread-local message for the last failure; the
+ * pointer is good until this thread's next failing call (copy the text if it
+ * is to be kept, and call it AFTER the call it explains -- as an argument of
+ * the same printf its evaluation order is unspecified in C).
  */
 #ifndef UISRNN_HIP_H_
 #define UISRNN_HIP_H_

@@ -126,6 +126,54 @@ def test_library_exports_every_declared_symbol():
   assert lib.uis_numerics_version() == version
 
 
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+  """The drop-in boundary is a C ABI (plain pointers and sizes, no C++ or torch types): the header
+  compiles as pedantic C99, and a C program built with gcc -- no hipcc, no Python -- links against
+  libuisrnn_hip.so and gets the library's own answers from the entry points that need no GPU
+  (versions, device count, argument checks and their error text).  No compute call."""
+  import shutil
+  import subprocess
+  gcc = shutil.which('gcc')
+  if gcc is None:
+    pytest.skip('no gcc')
+  _capi.load_library()  # (built)
+  src = tmp_path / 'abi_check.c'
+  src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "uisrnn_hip.h"
+int main(void) {
+  uis_decode_opts opts;
+  uis_stats stats;
+  uis_handle* h = NULL;
+  int64_t offsets[1] = {0};
+  memset(&opts, 0, sizeof opts);
+  memset(&stats, 0, sizeof stats);
+  printf("abi %d numerics %d devices %d\n", (int)uis_abi_version(), (int)uis_numerics_version(), (int)uis_device_count());
+  printf("create(NULL) %d\n", (int)uis_create(NULL, 0, &h));
+  {  /* (the message is read AFTER the call it explains: two statements, not two arguments of one printf) */
+    const int rc = (int)uis_decode(NULL, NULL, offsets, 0, &opts, NULL, NULL, &stats);
+    printf("decode(NULL) %d [%s]\n", rc, uis_last_error());
+  }
+  printf("sizes %d %d\n", (int)sizeof(uis_decode_opts), (int)sizeof(uis_stats));
+  uis_destroy(NULL);
+  return uis_abi_version() == UIS_ABI_VERSION ? 0 : 1;
+}
+''')
+  exe = tmp_path / 'abi_check'
+  lib_dir = os.path.dirname(_capi.LIB_PATH)
+  subprocess.check_call([gcc, '-std=c99', '-pedantic', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                         str(src), '-o', str(exe), '-L', lib_dir, '-luisrnn_hip', '-Wl,-rpath,' + lib_dir])
+  out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+  assert out.returncode == 0, (out.stdout, out.stderr)
+  lines = out.stdout.strip().splitlines()
+  assert lines[0].startswith('abi {} numerics '.format(_capi.UIS_ABI_VERSION)), lines
+  assert lines[1] == 'create(NULL) {}'.format(_capi.UIS_ERR_INVALID_ARG), lines
+  assert lines[2].startswith('decode(NULL) {} ['.format(_capi.UIS_ERR_INVALID_ARG)) and 'null handle' in lines[2], lines
+  # the ctypes mirror of the two structs has the C compiler's sizes
+  assert lines[3] == 'sizes {} {}'.format(ctypes.sizeof(_capi.DecodeOpts), ctypes.sizeof(_capi.Stats)), lines
+
+
 def test_driver_build_entry_point():
   """__graft_entry__.build() is what the driver runs as its "does it build" check."""
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
