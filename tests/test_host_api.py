@@ -509,3 +509,39 @@ def test_predict_retries_an_overflowing_look_ahead_window_with_more_room():
   dec = StandIn()
   out = model._decode_batch(seqs[:3], inference_args, decoder=dec)  # pylint: disable=protected-access
   assert [r[0] for r in out] == [0, 1, 2] and dec.calls[0] == (3, 64)
+
+
+_REFERENCE_TESTS = '/root/reference/tests'
+
+
+@pytest.mark.skipif(not os.path.isdir(_REFERENCE_TESTS), reason='the reference checkout is not on this machine')
+def test_the_references_own_fit_free_tests_pass_against_this_package():
+  """Drop-in at the Python surface: google/uis-rnn's OWN unit tests -- the files as they lie under
+  /root/reference/tests, unmodified, nothing copied -- run with `uisrnn` resolving to this package: all of
+  evals_test.py (get_list_inverse_index, compute_sequence_match_accuracy: values, symmetry, error cases)
+  and uisrnn_test.py's test_save_and_load (UISRNN(args).save / .load round trip through the torch-free
+  checkpoint writer).  The others in uisrnn_test.py / integration_test.py call fit(): out of scope
+  (SURVEY.md section 8).  A subprocess: the reference's tests call parse_arguments() on sys.argv."""
+  import subprocess
+  prog = r'''
+import sys, unittest
+sys.path.insert(0, {root!r})
+import uisrnn_amd
+from uisrnn_amd import evals
+sys.modules['uisrnn'] = uisrnn_amd          # `import uisrnn` / `from uisrnn import evals` in the reference's files
+sys.modules['uisrnn.evals'] = evals
+sys.path.insert(0, {ref!r})
+sys.argv = ['reference-tests']
+import evals_test, uisrnn_test
+loader = unittest.TestLoader()
+suite = unittest.TestSuite([loader.loadTestsFromModule(evals_test),
+                            loader.loadTestsFromName('uisrnn_test.TestUISRNN.test_save_and_load')])
+result = unittest.TextTestRunner(verbosity=0, stream=sys.stderr).run(suite)
+assert sys.modules['uisrnn'] is uisrnn_amd and evals_test.evals is evals
+print('ran', result.testsRun, 'failures', len(result.failures), 'errors', len(result.errors), 'skipped', len(result.skipped))
+sys.exit(0 if result.wasSuccessful() else 1)
+'''.format(root=ROOT, ref=_REFERENCE_TESTS)
+  out = subprocess.run([sys.executable, '-c', prog], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       cwd='/tmp')  # (not the reference's directory: `uisrnn` must resolve through sys.modules only)
+  assert out.returncode == 0, (out.stdout, out.stderr[-3000:])
+  assert out.stdout.strip().splitlines()[-1] == 'ran 8 failures 0 errors 0 skipped 0', (out.stdout, out.stderr[-2000:])

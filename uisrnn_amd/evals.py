@@ -9,6 +9,18 @@ import numpy as np
 from scipy import optimize
 
 
+def get_list_inverse_index(unique_ids):
+  """Position of every value of a list of distinct ids: {value: position} (uisrnn/evals.py:20-37;
+  the reference's tests call it directly).
+
+  Raises:
+    TypeError: unique_ids is not a list.
+  """
+  if not isinstance(unique_ids, list):
+    raise TypeError('unique_ids must be a list')
+  return {value: position for position, value in enumerate(unique_ids)}
+
+
 def compute_sequence_match_accuracy(sequence1, sequence2):
   """Accuracy between two label sequences under the best label permutation.
 
@@ -23,8 +35,8 @@ def compute_sequence_match_accuracy(sequence1, sequence2):
         'sequence1 and sequence2 must be non-empty and of the same size')
   uniq1 = sorted(set(sequence1))
   uniq2 = sorted(set(sequence2))
-  index1 = {lab: i for i, lab in enumerate(uniq1)}
-  index2 = {lab: i for i, lab in enumerate(uniq2)}
+  index1 = get_list_inverse_index(uniq1)
+  index2 = get_list_inverse_index(uniq2)
   # a square matrix (zero padded): the optimum equals that of the reference's rectangular one
   size = max(len(uniq1), len(uniq2))
   overlap = np.zeros((size, size), dtype=np.int64)
