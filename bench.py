@@ -175,7 +175,8 @@ def measured_traffic(argv, timeout_s=180):
     if a in ('--steps', '--warmup', '--gpus', '--timed', '--cpu_sample', '--backend'):
       skip_next = True
       continue
-    if a in ('--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs', '--force_dist'):
+    if a in ('--no_cpu_baseline', '--no_host_buffers', '--no_extra_configs', '--force_dist', '--check_gather',
+             '--allow_shared_device'):
       continue
     keep.append(a)
   env = dict(os.environ, UIS_BENCH_CHILD='1', TMPDIR='/tmp')
@@ -287,6 +288,14 @@ def parse(argv=None):
                        '(exercises the RCCL calls on a single-GPU box)')
   ap.add_argument('--streams', type=int, default=0,
                   help='utterance groups decoded concurrently (0 = library default)')
+  ap.add_argument('--allow_shared_device', action='store_true',
+                  help='REHEARSAL ONLY (tests/test_gpu_scale.py): ranks beyond the visible devices fold onto them '
+                       '(rank r -> device r mod #devices), so that the multi-rank job runs the real decoder on a '
+                       'one-GPU box.  The line then carries "shared_device": true, `n_gpus` = the number of DEVICES '
+                       'and `ranks` = the world size: it can never pass for a scaling number')
+  ap.add_argument('--check_gather', action='store_true',
+                  help='rank 0 compares the gathered labels of EVERY rank, all utterances, with the CPU oracle '
+                       '(outside the timed regions) and puts the verdict into the line (`gather_check`)')
   return ap.parse_args(argv)
 
 
@@ -373,27 +382,41 @@ def load_model(cfg, which):
           'closed-form tracker (uisrnn_amd.synth)')
 
 
+def rank_sequences(cfg, args, rank, world):
+  """(this rank's utterances, frames of the whole job): deterministic in (cfg, args, rank, world), so that any rank
+  can regenerate any other rank's list (--check_gather)."""
+  from uisrnn_amd import distributed, synth  # pylint: disable=import-outside-toplevel
+  n_utt, n_frames, dim = cfg['utterances_per_gpu'], cfg['frames'], cfg['observation_dim']
+  if args.ragged:
+    # the WHOLE job's utterances (same list on every rank), dealt longest first
+    rng = np.random.default_rng(4242)
+    lengths = rng.integers(max(n_frames // 2, 1), n_frames + 1, size=n_utt * world)
+    mine = distributed.shard_utterances(lengths, world)[rank]
+    return [synth.make_utterance(10_000 + int(i), int(lengths[i]), dim)[0] for i in mine], int(lengths.sum())
+  return synth.make_utterances(10_000 + rank * n_utt, n_utt, n_frames, dim)[0], world * n_utt * n_frames
+
+
+def host_bytes_per_rank(cfg):
+  """Host memory one rank of this benchmark holds at its peak (bytes, an upper bound for equal-length utterances):
+  the float64 list predict() receives, its packed float32 copy, the pinned float32 block of the host-buffer leg, the
+  library's own pinned staging block (float32 frames, allocated on the first host-side decode) and the label /
+  offset arrays.  8 ranks of the configs[3] share: 8 x 5.3 GB (tests/test_bench_dist.py asserts the bound)."""
+  frames = cfg['utterances_per_gpu'] * cfg['frames']
+  dim = cfg['observation_dim']
+  return frames * dim * (8 + 4 + 4 + 4) + frames * 4 * 3 + (cfg['utterances_per_gpu'] + 1) * 8 * 2
+
+
 class Workload:
   """One BASELINE config on this rank: the model, this rank's utterances, the buffers in HBM."""
 
   def __init__(self, cfg, args, rank, world, dev, dev_index):
     import torch  # pylint: disable=import-outside-toplevel
-    from uisrnn_amd import _capi, distributed, synth  # pylint: disable=import-outside-toplevel
+    from uisrnn_amd import _capi  # pylint: disable=import-outside-toplevel
     self.cfg, self.args, self.torch, self.capi = cfg, args, torch, _capi
     self.dim, self.hid = cfg['observation_dim'], cfg['rnn_hidden_size']
     self.beam, self.look, self.tau = cfg['beam_size'], cfg['look_ahead'], cfg['test_iteration']
-    n_utt, n_frames = cfg['utterances_per_gpu'], cfg['frames']
     self.params, cfg['model'] = load_model(cfg, args.model)
-    if args.ragged:
-      # the WHOLE job's utterances (same list on every rank), dealt longest first
-      rng = np.random.default_rng(4242)
-      lengths = rng.integers(max(n_frames // 2, 1), n_frames + 1, size=n_utt * world)
-      mine = distributed.shard_utterances(lengths, world)[rank]
-      self.seqs = [synth.make_utterance(10_000 + int(i), int(lengths[i]), self.dim)[0] for i in mine]
-      self.job_frames = int(lengths.sum())
-    else:
-      self.seqs, _ = synth.make_utterances(10_000 + rank * n_utt, n_utt, n_frames, self.dim)
-      self.job_frames = world * n_utt * n_frames
+    self.seqs, self.job_frames = rank_sequences(cfg, args, rank, world)
     self.n_utt = len(self.seqs)
     lens = np.array([s.shape[0] for s in self.seqs], dtype=np.int64)
     self.offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -521,6 +544,32 @@ class Workload:
     return cpu_s, bool(parity), int(sum(s.shape[0] for s in sample_seqs))
 
 
+def check_gathered_labels(cfg, args, world, w, gathered, width):
+  """--check_gather: what the LAST pass left in the gathered buffer (every rank's labels; with one rank: this rank's
+  label buffer) against the CPU oracle, every utterance of every rank.  Returns a small record for the line."""
+  from oracle import oracle  # pylint: disable=import-outside-toplevel
+  threads = max(min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 64), 1)
+  got_all = (gathered.cpu().numpy().reshape(world, max(width, 1)) if gathered is not None
+             else w.d_labels.cpu().numpy()[None, :])
+  t0 = time.perf_counter()
+  bad, n_utt, n_frames = [], 0, 0
+  for r in range(world):
+    seqs = w.seqs if r == 0 and world == 1 else rank_sequences(cfg, args, r, world)[0]
+    if not seqs:
+      continue
+    ref = oracle.decode(w.params, seqs, w.beam, w.look, w.tau, n_threads=threads)
+    pos = 0
+    for u, s in enumerate(seqs):
+      n = s.shape[0]
+      if not np.array_equal(got_all[r, pos:pos + n], ref['labels'][u]):
+        bad.append((r, u))
+      pos += n
+    n_utt += len(seqs)
+    n_frames += pos
+  return {'identical': not bad, 'ranks': world, 'utterances': n_utt, 'frames': n_frames, 'mismatching': bad[:8],
+          'oracle_threads': threads, 'seconds': round(time.perf_counter() - t0, 1)}
+
+
 def run_extra_config(index, args, rank, dev, dev_index, sync_fn):
   """A few passes of another BASELINE config at its stated size: rate, frac, parity."""
   cfg = dict(CONFIGS[index])
@@ -555,7 +604,7 @@ def main(argv=None):
   if env_world is None and args.gpus is not None and args.gpus > 1:
     import torch  # pylint: disable=import-outside-toplevel
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not (args.allow_shared_device and n_dev >= 1):
       raise SystemExit('bench.py --gpus {}: only {} HIP device(s) visible; one rank per GPU is '
                        'required (no folding of ranks onto one device)'.format(args.gpus, n_dev))
     respawn_under_torchrun(args.gpus, sys.argv[1:] if argv is None else argv)
@@ -598,17 +647,18 @@ def main(argv=None):
     n_dev = torch.cuda.device_count()
     if n_dev < 1:
       raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
-    if local_rank >= n_dev:
+    if local_rank >= n_dev and not args.allow_shared_device:
       raise RuntimeError('rank {} (local rank {}) has no GPU of its own: {} HIP device(s) visible, '
                          'one rank per GPU is required'.format(rank, local_rank, n_dev))
-    dev_index = local_rank
+    dev_index = local_rank % n_dev   # (--allow_shared_device: the rehearsal folds ranks onto the devices there are)
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     sync_fn = torch.cuda.synchronize
   else:
     if args.backend != 'gloo':
       raise SystemExit('--device cpu is test plumbing: it needs --backend gloo and a stand-in decoder')
-    dev_index, dev, sync_fn = 0, torch.device('cpu'), (lambda: None)
+    dev_index, dev, sync_fn, n_dev = 0, torch.device('cpu'), (lambda: None), world
+  shared_device = bool(on_gpu and local_world > n_dev)
   use_dist = world > 1 or args.force_dist
   if use_dist:
     import torch.distributed as dist
@@ -737,6 +787,9 @@ def main(argv=None):
              'reference': ref or None,
              'sample': '{} of the {} utterances ({} frames each), {} threads, {:.1f}s; GPU labels '
                        'identical: {}'.format(sample, w.n_utt, sample_frames, threads, cpu_s, parity)}
+    gather_check = None
+    if args.check_gather:
+      gather_check = check_gathered_labels(cfg, args, world, w, gathered, width)
     extras = None
     if (not args.no_extra_configs and world == 1 and on_gpu and args.config == 1 and not args.ragged and
         args.utterances is None and args.frames is None and args.beam_size is None and args.rnn_depth is None):
@@ -751,7 +804,9 @@ def main(argv=None):
       w.last, w.cap = first, w_cap
     result = {
         'metric': 'diarization frames/sec (whole node), beam=10, 256-dim',
-        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world,
+        'value': round(value, 1), 'unit': 'frames/s',
+        # (a rehearsal on fewer devices than ranks says so, and counts DEVICES: never a scaling number)
+        'n_gpus': min(world, n_dev) if shared_device else world, 'ranks': world, 'shared_device': shared_device,
         'steps': steps, 'warmup': warmup,
         'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
@@ -772,6 +827,8 @@ def main(argv=None):
         'setup_passes': setup_passes, 'setup_ms': round(setup_ms, 1),
         'per_rank_ms': {'min': round(1e3 * min(per_rank) / steps, 3), 'max': round(1e3 * max(per_rank) / steps, 3)},
         'rank_host_cores': rank_cores,
+        'per_rank_host_gb': round(host_bytes_per_rank(cfg) / 1e9, 2),
+        'gather_check': gather_check,
         'per_rank_memory_gb': round((w.rank_frames * w.dim * 4 + w.rank_frames * 3 * w.hid * 4) / 1e9, 2),
         'decode_ms_device': round(stats.get('decode_ms', 0.0), 3),
         'n_streams': stats.get('n_streams', 0),

@@ -241,3 +241,45 @@ def test_traffic_sub_runs_read_the_counter_files(tmp_path, monkeypatch):
   # ... and a sub-run never starts sub-runs of its own
   monkeypatch.setenv('UIS_BENCH_CHILD', '1')
   assert bench.measured_traffic(['--utterances', '64']) is None
+
+
+def test_host_memory_of_eight_ranks_of_the_configs3_share():
+  """The driver's 8-GPU run: 8 processes x (float64 list + packed float32 + pinned float32 + the library's pinned
+  staging block) of the configs[3] share must fit a node's host memory with room to spare (the bound bench.py reports
+  as `per_rank_host_gb`)."""
+  sys.path.insert(0, ROOT)
+  import bench
+  per_rank = bench.host_bytes_per_rank(bench.CONFIGS[3])
+  frames = 1024 * 1000
+  assert per_rank >= frames * 256 * (8 + 4 + 4 + 4)
+  assert 8 * per_rank < 48e9, per_rank          # 8 x 5.3 GB
+  assert 8 * bench.host_bytes_per_rank(bench.CONFIGS[1]) < 2e9
+
+
+def test_a_rehearsal_on_a_shared_device_can_never_pass_for_a_scaling_line():
+  """`--allow_shared_device` is parsed, is dropped from the counter sub-runs' command, and without it `--gpus 2` on a
+  one-device box still refuses (test_gpus_flag_refuses_to_fold_ranks_onto_one_device)."""
+  sys.path.insert(0, ROOT)
+  import bench
+  args = bench.parse(['--gpus', '2', '--allow_shared_device', '--check_gather'])
+  assert args.allow_shared_device and args.check_gather
+  assert not bench.parse([]).allow_shared_device
+  src = open(os.path.join(ROOT, 'bench.py')).read()
+  assert "'n_gpus': min(world, n_dev) if shared_device else world" in src and "'shared_device': shared_device" in src
+
+
+def test_rank_sequences_are_reproducible_from_any_rank():
+  """--check_gather: rank 0 regenerates every rank's utterances; ragged lists are ONE job-wide list dealt longest
+  first, equal-length ones are seeded by the rank."""
+  sys.path.insert(0, ROOT)
+  import bench
+  import numpy as np
+  cfg = dict(bench.CONFIGS[1], utterances_per_gpu=3, frames=20)
+  for ragged in (False, True):
+    args = bench.parse(['--ragged'] if ragged else [])
+    a0, job = bench.rank_sequences(cfg, args, 0, 2)
+    a1, job1 = bench.rank_sequences(cfg, args, 1, 2)
+    b1, _ = bench.rank_sequences(cfg, args, 1, 2)
+    assert job == job1 == sum(s.shape[0] for s in a0 + a1)
+    assert all(np.array_equal(x, y) for x, y in zip(a1, b1)) and len(a1) == len(b1)
+    assert not np.array_equal(a0[0][:10], a1[0][:10])

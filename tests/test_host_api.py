@@ -545,3 +545,23 @@ sys.exit(0 if result.wasSuccessful() else 1)
                        cwd='/tmp')  # (not the reference's directory: `uisrnn` must resolve through sys.modules only)
   assert out.returncode == 0, (out.stdout, out.stderr[-3000:])
   assert out.stdout.strip().splitlines()[-1] == 'ran 8 failures 0 errors 0 skipped 0', (out.stdout, out.stderr[-2000:])
+
+
+def test_library_and_torch_share_one_hip_runtime_in_either_load_order():
+  """Round 6: loading libuisrnn_hip.so BEFORE PyTorch used to bring two HIP runtimes into the process (torch then finds
+  no GPU).  _capi.share_hip_runtime_with_torch() preloads torch's bundled libamdhip64.so (same SONAME as the system
+  one) where a torch installation exists: ONE runtime mapped whichever comes first; UIS_HIP_RUNTIME=system opts out."""
+  import subprocess
+  probe = ('import sys; sys.path.insert(0, {root!r})\n'
+           '{first}\n'
+           'from uisrnn_amd import _capi\n'
+           '_capi.load_library()\n'
+           '{second}\n'
+           'maps = sorted(set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l))\n'
+           'print(len(maps), _capi._hip_runtime)\n')
+  for first, second, env, want in (('', 'import torch', {}, '1 torch (preloaded'),
+                                   ('import torch', '', {}, '1 torch (imported before'),
+                                   ('', '', {'UIS_HIP_RUNTIME': 'system'}, '1 system (UIS_HIP_RUNTIME)')):
+    out = subprocess.run([sys.executable, '-c', probe.format(root=ROOT, first=first, second=second)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert out.returncode == 0 and out.stdout.startswith(want), (first, second, out.stdout, out.stderr[-2000:])

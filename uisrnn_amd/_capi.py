@@ -9,6 +9,7 @@ library is missing or no gfx950 device is usable, the calls raise.
 
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -211,6 +212,39 @@ class HipLibraryError(RuntimeError):
 
 
 _lib = None
+_hip_runtime = None   # what share_hip_runtime_with_torch() did, for whoever asks (tests, bench.py)
+
+
+def share_hip_runtime_with_torch():
+  """ONE HIP runtime per process, whichever of {this library, PyTorch} is loaded first (round 6).
+
+  The PyTorch-ROCm wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7, the system ROCm's too).  With
+  torch imported FIRST the dynamic linker resolves this library's `NEEDED libamdhip64.so.7` to torch's copy, already
+  loaded under that SONAME: one runtime, everything works.  With this library first the system runtime is loaded, a
+  later `import torch` brings a SECOND runtime (its NEEDED name is `libamdhip64.so`: no SONAME match) and
+  torch.cuda.init() reports "No HIP GPUs are available" (measured, round 4).  So: where a torch installation is found
+  and not yet imported, its libamdhip64.so is dlopen()ed (RTLD_GLOBAL, by path, WITHOUT importing torch) before this
+  library -- both load orders then end in the first situation.  UIS_HIP_RUNTIME=system keeps the system runtime (for
+  processes that never import torch)."""
+  global _hip_runtime
+  if _hip_runtime is not None:
+    return _hip_runtime
+  if os.environ.get('UIS_HIP_RUNTIME', 'auto') == 'system':
+    _hip_runtime = 'system (UIS_HIP_RUNTIME)'
+  elif 'torch' in sys.modules:
+    _hip_runtime = 'torch (imported before this library)'
+  else:
+    _hip_runtime = 'system (no torch installation found)'
+    try:
+      import importlib.util  # pylint: disable=import-outside-toplevel
+      spec = importlib.util.find_spec('torch')
+      bundled = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so') if spec and spec.origin else None
+      if bundled and os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+        _hip_runtime = 'torch (preloaded: ' + bundled + ')'
+    except (ImportError, OSError, ValueError) as e:
+      _hip_runtime = 'system (torch\'s runtime could not be preloaded: {})'.format(e)
+  return _hip_runtime
 
 
 def load_library(path=None):
@@ -223,6 +257,7 @@ def load_library(path=None):
     raise HipLibraryError(
         '{} not found: build it with `python -m uisrnn_amd.build` (hipcc, '
         'gfx950). There is no CPU fallback for the decode path.'.format(path))
+  share_hip_runtime_with_torch()
   lib = ctypes.CDLL(path)
   lib.uis_abi_version.restype = ctypes.c_int32
   lib.uis_abi_version.argtypes = []

@@ -1683,6 +1683,18 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     fprintf(stderr, "[resident timing] gru fine (wg 248): other=%.2f tile=%.2f combine=%.2f sync=%.2f\n",
             (double)tc[72] * 0.01 / (double)maxT, (double)tc[73] * 0.01 / (double)maxT, (double)tc[74] * 0.01 / (double)maxT,
             (double)tc[75] * 0.01 / (double)maxT);
+    if ((decode_kernel & 0xff) == UIS_DK_BIG || (decode_kernel & 0xff) == UIS_DK_BIG_WS) {  // k_decode_big: the GRU stage wave by wave, the row tiles per step
+      unsigned long long wv[32];
+      HIPCHK(hipMemcpy(wv, h->counters.as<unsigned long long>() + 96, sizeof(wv), hipMemcpyDeviceToHost));
+      for (int wg = 0; wg < 2; ++wg) {
+        fprintf(stderr, "[resident timing] workgroup %3d, gru us per step by wave:", wg ? 248 : 0);
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " %.1f", (double)wv[8 * wg + w] * 0.01 / (double)maxT);
+        fprintf(stderr, "\n");
+      }
+      fprintf(stderr, "[resident timing] cluster 0: row tiles per step mean %.2f; steps by (row tiles mod 8):", (double)wv[24] / (double)maxT);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %d:%llu", k, wv[16 + k]);
+      fprintf(stderr, "\n");
+    }
   }
 #endif
   if (resident && !rs && tn.sig != 0 && tn.phase <= 4 && !getenv("UIS_NO_CTL_TUNE")) {  // the decode's device time goes to the placement it ran with

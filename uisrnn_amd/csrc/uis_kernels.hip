@@ -3942,6 +3942,7 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
 #if defined(UIS_RESIDENT_TIMING)
   unsigned long long rt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (WIN: [8 ..) the odd sub-steps)
   unsigned long long wv_acc = 0;
+  unsigned long long nrt_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // row tiles mod 8 per step, and their sum (workgroup 0)
   unsigned long long rt_prev = wall_clock64();
 #endif
   for (int s = step0; s < s_end; ++s) {
@@ -4073,7 +4074,8 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
       }
     }
 #if defined(UIS_RESIDENT_TIMING)
-    if (WIN && !(s & 1)) wv_acc += wall_clock64() - wv_t0;  // this wave's own GRU time (even sub-steps)
+    if (!WIN || !(s & 1)) wv_acc += wall_clock64() - wv_t0;  // this wave's own GRU time (WIN: even sub-steps)
+    if (!WIN && t == 0 && blockIdx.x == 0) { ++nrt_hist[nrt & 7]; nrt_hist[8] += nrt; }
 #endif
     RSTAMP(2 + (WIN ? 8 * (s & 1) : 0));
     // ---- linear_mean1 + relu -> a1 (same staging layout); its weight slice takes the LDS slot
@@ -4144,7 +4146,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
     st.counters[96 + 512 + blockIdx.x] = rt_acc[4];
     st.counters[96 + 768 + blockIdx.x] = rt_acc[6];
   }
-  if (WIN && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 248)) st.counters[80 + (blockIdx.x ? 8 : 0) + w] = wv_acc;
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 248)) st.counters[(WIN ? 80 : 96) + (blockIdx.x ? 8 : 0) + w] = wv_acc;
+  if (!WIN && t == 0 && blockIdx.x == 0)
+    for (int k = 0; k < 9; ++k) st.counters[112 + k] = nrt_hist[k];
 #endif
   if (WS && s_end < nsteps) {  // more steps to come in another launch
     if (has_u) {
