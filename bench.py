@@ -127,6 +127,7 @@ def committed_traffic(kernel, avg_launch_us=None):
       kernels = json.load(open(path))['kernels']
       entry = kernels[kernel] if kernel in kernels else kernels[base]  # (an instantiation's own record first)
       out = {'bytes_per_launch': int((2.0 * entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
+             'bytes_per_launch_raw': int((entry['fetch_size_kib'] + entry['write_size_kib']) * 1024),
              'source': os.path.relpath(path, ROOT)}
       then = entry.get('avg_launch_us')
       if then and avg_launch_us:
@@ -228,10 +229,15 @@ def measured_traffic(argv, timeout_s=180):
     finally:
       shutil.rmtree(out_dir, ignore_errors=True)
   return {'kernel': kernel, 'bytes_per_launch': int((2.0 * sizes['FETCH_SIZE'] + sizes['WRITE_SIZE']) * 1024),
+          # (the counters as rocprofv3 reports them, no correction: the lower bound if part of the kernel's reads -- narrow or
+          # sc1 loads -- were tallied at their full size; `bytes_per_launch` is the guide's corrected figure)
+          'bytes_per_launch_raw': int((sizes['FETCH_SIZE'] + sizes['WRITE_SIZE']) * 1024),
           'fetch_size_kib': round(sizes['FETCH_SIZE'], 1), 'write_size_kib': round(sizes['WRITE_SIZE'], 1),
           'source': 'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this script '
                     '(separate passes, device leg, one timed pass), median over the dispatches of ' + base,
-          'correction': 'FETCH_SIZE x2 (gfx950: 64 B tallied per 128-B request of a wide coalesced read), WRITE_SIZE as reported; KiB per dispatch',
+          'correction': 'bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM: gfx950 tallies 64 B per 128-B request of a '
+                        '16-byte-per-lane coalesced read -- this kernel\'s loads; WRITE_SIZE uncalibrated, as reported); '
+                        'bytes_per_launch_raw = FETCH_SIZE + WRITE_SIZE untouched; the truth lies between them; KiB per dispatch',
           'min_max_dispatches': spread, 'seconds': round(time.perf_counter() - t0, 1)}
 
 
@@ -258,6 +264,8 @@ def parse(argv=None):
   ap.add_argument('--utterances', type=int, default=None, help='utterances per GPU')
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--beam_size', type=int, default=None)
+  ap.add_argument('--look_ahead', type=int, default=None)
+  ap.add_argument('--max_clusters', type=int, default=None, help='cluster cap the decode starts with (it doubles on overflow)')
   ap.add_argument('--rnn_depth', type=int, default=None,
                   help='GRU layers of the model (not a BASELINE config: the closed-form tracker weights at that depth)')
   ap.add_argument('--ragged', action='store_true',
@@ -633,9 +641,14 @@ def main(argv=None):
     cfg['beam_size'] = args.beam_size
   if args.rnn_depth is not None:
     cfg['rnn_depth'] = args.rnn_depth
-  if args.utterances is not None or args.frames is not None or args.beam_size is not None or args.rnn_depth is not None:
-    cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}, rnn_depth {}]'.format(
-        cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'], cfg['rnn_depth'])
+  if args.look_ahead is not None:
+    cfg['look_ahead'] = args.look_ahead
+  if args.max_clusters is not None:
+    cfg['max_clusters'] = args.max_clusters
+  if (args.utterances is not None or args.frames is not None or args.beam_size is not None or args.rnn_depth is not None or
+      args.look_ahead is not None or args.max_clusters is not None):
+    cfg['workload'] += ' [overridden: {} utt x {} frames, beam {}, look_ahead {}, rnn_depth {}, cluster cap {}]'.format(
+        cfg['utterances_per_gpu'], cfg['frames'], cfg['beam_size'], cfg['look_ahead'], cfg['rnn_depth'], cfg['max_clusters'])
   if args.ragged:
     cfg['workload'] += ' [ragged: lengths uniform in [frames / 2, frames], longest-first sharding]'
   big = cfg['utterances_per_gpu'] * cfg['frames'] > 200_000 or cfg['look_ahead'] > 1
@@ -792,7 +805,8 @@ def main(argv=None):
       gather_check = check_gathered_labels(cfg, args, world, w, gathered, width)
     extras = None
     if (not args.no_extra_configs and world == 1 and on_gpu and args.config == 1 and not args.ragged and
-        args.utterances is None and args.frames is None and args.beam_size is None and args.rnn_depth is None):
+        args.utterances is None and args.frames is None and args.beam_size is None and args.rnn_depth is None and
+        args.look_ahead is None and args.max_clusters is None):
       first = w.last
       w_cap = w.cap
       extras = []

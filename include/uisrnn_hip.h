@@ -155,7 +155,15 @@ typedef struct uis_decode_opts {
                                     riding on the other cohort's dense phases, row tiles pulled from LDS counters, no
                                     workgroup barrier in the step loop (k_decode_coh, UIS_DK_BIG_COH).  Bit-identical;
                                     measured SLOWER than the lock-step batch on MI355X (3.8 against 4.0 M frames/s at
-                                    1024 utterances: DESIGN.md / LABNOTES.md), hence opt-in: an A/B switch             */
+                                    1024 utterances: DESIGN.md / LABNOTES.md): since round 6 the kernel is compiled only
+                                    into builds with -DUIS_WITH_COHORTS (uis_build_flags() & UIS_BUILD_COHORTS; the test
+                                    variant build/variants/cohorts.so); the product library ignores the flag          */
+#define UIS_FLAG_AGENT_FLAGS 0x20000u /* one-launch decode: publish the per-producer phase words of the dense-stage hand-offs
+                                    with an AGENT-scope store (`global_store sc1`: the HIP memory model's by-the-book form for
+                                    a word other workgroups read) instead of the workgroup-scope store that stays in the
+                                    XCD's L2 (uis_kernels.hip: rs_flag_publish).  A run-time choice in one binary since round
+                                    6 (the environment's UIS_AGENT_FLAGS=1 does the same); bit-identical; its cost is on
+                                    record: profiles/r06_agent_flags_ab.txt -- it is NOT small, hence opt-in          */
 #define UIS_FLAG_DEBUG_SCORES 0x2000u /* test hook: keep every candidate score of every window (step) --
                                     the arrays _calculate_score returns (uisrnn/uisrnn.py:455-477) -- for
                                     uis_debug_scores(); costs device memory and one store per candidate */
@@ -228,6 +236,10 @@ int32_t uis_abi_version(void);
 
 /* UIS_NUMERICS_VERSION of include/uis_numerics.h this library was built with. */
 int32_t uis_numerics_version(void);
+
+/* What this binary was built with (round 6): a mask of UIS_BUILD_*. */
+#define UIS_BUILD_COHORTS 0x1u  /* -DUIS_WITH_COHORTS: k_decode_coh is there and UIS_FLAG_COHORTS selects it */
+uint32_t uis_build_flags(void);
 
 /* Number of visible HIP devices (0 if none / runtime unusable). */
 int32_t uis_device_count(void);

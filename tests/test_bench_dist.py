@@ -232,6 +232,7 @@ def test_traffic_sub_runs_read_the_counter_files(tmp_path, monkeypatch):
   assert rec['kernel'] == 'k_decode_rs'
   assert rec['fetch_size_kib'] == 1002.0 and rec['write_size_kib'] == 301.0
   assert rec['bytes_per_launch'] == int((2 * 1002.0 + 301.0) * 1024)
+  assert rec['bytes_per_launch_raw'] == int((1002.0 + 301.0) * 1024)   # (the counters untouched, beside the guide's corrected figure)
   assert rec['min_max_dispatches'] == {'FETCH_SIZE': [1000.0, 5000.0, 3], 'WRITE_SIZE': [300.0, 302.0, 3]}
   monkeypatch.setenv('FAKE_PROFILER_HANGS', '1')
   import time

@@ -114,7 +114,7 @@ def test_product_never_imports_the_oracle():
 
 def test_library_exports_every_declared_symbol():
   header = open(os.path.join(ROOT, 'include', 'uisrnn_hip.h')).read()
-  declared = set(re.findall(r'^\s*(?:const\s+char\*|int32_t|void)\s+(uis_\w+)\s*\(',
+  declared = set(re.findall(r'^\s*(?:const\s+char\*|int32_t|uint32_t|void)\s+(uis_\w+)\s*\(',
                             header, re.M))
   assert declared == set(_capi.EXPORTED_SYMBOLS)
   lib = _capi.load_library()
@@ -504,6 +504,22 @@ def test_predict_retries_an_overflowing_look_ahead_window_with_more_room():
   out = model._decode_batch(seqs[:6], inference_args, decoder=dec)  # pylint: disable=protected-access
   assert [r[0] for r in out] == list(range(6)) and [len(r) for r in out] == [s.shape[0] for s in seqs[:6]]
   assert sorted({cap for _, cap in dec.calls}) == [32768, 262144, 524287]
+  # one utterance whose window does not fit the DEVICE at the larger capacity (UIS_ERR_OOM from a single-utterance decode):
+  # only that one is named, the others of its retry group come back (round 6)
+  class TightDevice(StandIn):
+    def decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters=0, flags=0, level_cap=0):
+      if (level_cap or 32768) > 32768 and any(int(s[0, 0]) == 3 for s in seqs):
+        self.calls.append((len(seqs), level_cap))
+        err = _capi.HipLibraryError('uis_decode_f64 failed (-5): decode state would need 999 GB')
+        err.status = _capi.UIS_ERR_OOM
+        self.flags = np.zeros(0, dtype=np.int32)
+        raise err
+      return StandIn.decode_f64(self, seqs, beam_size, look_ahead, test_iteration, max_clusters, flags, level_cap)
+  dec = TightDevice()
+  with pytest.raises(uisrnn_amd.LookAheadWindowError) as info:
+    model._decode_batch(seqs[:6], inference_args, decoder=dec)  # pylint: disable=protected-access
+  assert info.value.utterances == (3,), info.value.utterances
+  assert [None if r is None else r[0] for r in info.value.results] == [0, 1, 2, None, 4, 5]
   # args.level_cap: where the retries start
   inference_args.level_cap = 64
   dec = StandIn()

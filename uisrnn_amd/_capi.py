@@ -41,6 +41,8 @@ UIS_FLAG_REPLICATED_SELECT = 0x1000
 UIS_FLAG_DEBUG_SCORES = 0x2000
 UIS_FLAG_CLUSTER_BARRIERS = 0x8000
 UIS_FLAG_COHORTS = 0x10000
+UIS_FLAG_AGENT_FLAGS = 0x20000
+UIS_BUILD_COHORTS = 0x1
 
 UIS_N_KERNELS = 8
 KERNEL_NAMES = ('input_proj', 'select', 'gru', 'head1', 'head2', 'backtrace',
@@ -273,6 +275,8 @@ def load_library(path=None):
   lib.uis_abi_version.argtypes = []
   lib.uis_numerics_version.restype = i32
   lib.uis_numerics_version.argtypes = []
+  lib.uis_build_flags.restype = ctypes.c_uint32
+  lib.uis_build_flags.argtypes = []
   lib.uis_device_count.restype = i32
   lib.uis_device_count.argtypes = []
   lib.uis_create.restype = i32
@@ -327,7 +331,7 @@ def load_library(path=None):
 
 
 EXPORTED_SYMBOLS = (
-    'uis_abi_version', 'uis_numerics_version', 'uis_device_count', 'uis_create', 'uis_destroy',
+    'uis_abi_version', 'uis_numerics_version', 'uis_build_flags', 'uis_device_count', 'uis_create', 'uis_destroy',
     'uis_decode', 'uis_decode_f64', 'uis_decode_device', 'uis_last_decode_info', 'uis_last_decode_shape',
     'uis_debug_scores',
     'uis_model_constants', 'uis_rnn_step', 'uis_stream_begin', 'uis_stream_push',

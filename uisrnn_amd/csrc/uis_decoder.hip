@@ -517,6 +517,10 @@ int enqueue_steps(uis_handle* h, Launcher& lch, const DecodeState& st, size_t se
 // the threads are started once and take blocks of rows in order; the caller asks for a prefix of the
 // rows (`wait_rows`), helping with blocks while it waits, and hands each finished piece to the copy
 // engine while the team is already in the next.
+static bool agent_flags_env() {  // UIS_AGENT_FLAGS=1: the conforming phase-word stores (UIS_FLAG_AGENT_FLAGS) for every decode of the process
+  static const bool v = getenv("UIS_AGENT_FLAGS") != nullptr && atoi(getenv("UIS_AGENT_FLAGS")) != 0;
+  return v;
+}
 static bool getenv_flag_no_stream() {  // UIS_CAST_PLAIN_STORES=1: the scalar loop with ordinary stores (A/B)
   static const bool v = getenv("UIS_CAST_PLAIN_STORES") != nullptr;
   return v;
@@ -729,8 +733,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     lds = select_lds_layout(m.Dp, B, Kmax, S);
     if (lds.total > 160 * 1024) wnd = true;
   }
-  if (NC * (int64_t)(Kmax + 1) > 0x3fffffff || (int64_t)U * std::max<int64_t>(NC, B) > 0x3fffffff)
-    return fail(UIS_ERR_OOM, "level capacity * max_clusters (or utterances * level capacity) beyond the kernels' 32-bit indices");
+  // (a field-width limit that no smaller list cures is UNSUPPORTED -- the Python host halves a list on UIS_ERR_OOM, which
+  // only helps the term that grows with the number of utterances)
+  if (NC * (int64_t)(Kmax + 1) > 0x3fffffff)
+    return fail(UIS_ERR_UNSUPPORTED, "level capacity * max_clusters beyond the kernels' 32-bit indices");
+  if ((int64_t)U * std::max<int64_t>(NC, B) > 0x3fffffff)
+    return fail(UIS_ERR_OOM, "utterances * level capacity beyond the kernels' 32-bit indices");
   const WindowScratch wsl = window_scratch_layout(S, (int)NC, Kmax, B);
   {  // refuse configurations whose state would not fit the device instead of failing in hipMalloc
     const double bytes = (double)U * S * (m.Dp + (double)m.depth * m.Hp) * 4.0 +
@@ -822,7 +830,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 #endif
   ENSURE(beam_scores_out, (size_t)U * B * 4);
   ENSURE(utt_nrows, (size_t)U * 2 * 4);
-  ENSURE(resume, (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16);  // (a decode in several launches: DecodeState::resume)
+  // (a decode in several launches: DecodeState::resume -- only lists given in host memory can split, and never through
+  // the window machinery: wide beams, large caps and look-ahead decodes do not pay for it)
+  ENSURE(resume, (h_frames && !wnd) ? (size_t)U * (rs_lds_layout(B, Kmax, S).persist_stride + 4) + 16 : (size_t)16);
   ENSURE(split_tab, (size_t)8 * U * 2 * sizeof(long));
   ENSURE(scatter_tab, (size_t)64 * U * 3 * sizeof(long));                                  // (... and of its copy units: the scatter's tables)
   if (h->src64 && h_frames && F > 0 && ragged_list && (double)F * m.D * 4.0 >= (getenv("UIS_SPLIT_MIN_MB") ? 1e6 * atof(getenv("UIS_SPLIT_MIN_MB")) : 64e6))
@@ -990,8 +1000,12 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // ... or, on request (UIS_FLAG_COHORTS / UIS_COHORTS=1: measured slower, an experiment that stays tested), as two
   // utterance cohorts in flight per XCD (k_decode_coh: a cohort's select and hand-off waits filled with the other
   // cohort's dense stages)
+#if defined(UIS_WITH_COHORTS)
   const bool coh = big_ws && ((opts->flags & UIS_FLAG_COHORTS) || getenv("UIS_COHORTS")) &&
                    coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank) <= 160 * 1024;
+#else
+  const bool coh = false;  // (round 6: the cohort kernel lost every measurement; it lives on in the -DUIS_WITH_COHORTS test variant)
+#endif
   // ---- (round 5) ingestion overlapped with the decode.  The one-launch kernels own every CU, so nothing can be
   // copied-and-projected "behind" them -- but k_decode_rs / k_decode_big<WS> / k_decode_resident (one utterance per
   // workgroup) can stop after any step and pick up again
@@ -1144,13 +1158,13 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
   // From here on DMA from the caller's (or the pinned staging) memory may be in flight: whichever way
   // this function is left -- an error return inside the chunk loop included -- both streams are
   // drained first, so the caller never gets its buffers back while the copy engine still reads them.
+  std::vector<long> split_tab_host;  // (the source of an asynchronous copy: declared BEFORE the drain, so that it outlives the stream sync on every way out)
   struct Drain {
     uis_handle* h;
     ~Drain() { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); }
   } drain_on_exit{h};
   // a time slice [t0, t1) of every utterance (equal lengths): input projection and fresh-cluster MSE, the
   // utterances as batches along grid.z
-  std::vector<long> split_tab_host;  // (alive until the decode returns: the source of an asynchronous copy)
   const size_t pitch = (size_t)uniN * m.D * 4;  // (split, equal lengths: bytes between utterances, in the staging block and on the device)
   auto pre_rows = [&](Launcher& lch, size_t k, int64_t t0, int64_t t1) -> int {
     const long n = (long)(t1 - t0);
@@ -1257,7 +1271,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
     GroupPlan& gp = plan[g];
     DecodeState& st = gp.st;
     const size_t u0 = (size_t)gp.u0;
-    st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags; st.wnd = wnd ? 1 : 0;
+    st.U = gp.U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = L; st.tau = tau; st.flags = opts->flags | (agent_flags_env() ? UIS_FLAG_AGENT_FLAGS : 0u); st.wnd = wnd ? 1 : 0;
     st.max_rows = (int)((size_t)gp.U * rows_per_utt);
     st.off = h->off.as<int64_t>() + u0;
     st.utt_step = h->utt_step.as<int32_t>() + u0;
@@ -1334,7 +1348,9 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // k_decode_resident wins); UIS_FLAG_SMALL_TILES keeps the split-K passes (A/B switch, bit-identical)
       const bool rs_two = rs_kind == RS_UPW2 || rs_kind == RS_UPW2_C1, rs_wide = rs_kind == RS_WIDE || rs_kind == RS_WIDE_C4;
       const size_t shmem = std::max<size_t>(rs       ? resident_rs_lds_bytes(m.Hp, m.Dp, B, Kmax, S, rs_two ? 2 : 1, rs_two || rs_wide)
+#if defined(UIS_WITH_COHORTS)
                                             : coh    ? coh_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
+#endif
                                             : big_ws ? big_ws_lds_bytes(m.Hp, m.Dp, B, Kmax, S, per_rank)
                                             : big    ? big_lds_bytes(m.Hp, m.Dp, B, Kmax, S)
                                                      : resident_lds_bytes(m.Hp, m.Dp, B, Kmax, S),
@@ -1348,6 +1364,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // (round 5) the launch as a function of the step range: once for the whole decode, or twice with the rest of the
       // frames arriving behind the first launch (split, above)
       auto launch_resident = [&]() -> int {
+#if defined(UIS_WITH_COHORTS)
 #define UIS_COH_CASE(HPV, DPV, COND, ...)                                                                             \
   if (m.Hp == HPV && m.Dp == DPV && coh && (COND)) {                                                                 \
     void (*kern)(DevModel, DecodeState) = &k_decode_coh<HPV, DPV, ##__VA_ARGS__>;                                    \
@@ -1364,6 +1381,7 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       UIS_COH_CASE(128, 256, true)
       UIS_COH_CASE(128, 128, true)
 #undef UIS_COH_CASE
+#endif
 #define UIS_BIGWS_CASE(HPV, DPV, COND, ...)                                                                           \
   if (m.Hp == HPV && m.Dp == DPV && big_ws && !coh && (COND)) {                                                              \
     void (*kern)(DevModel, DecodeState) = &k_decode_big<HPV, DPV, true, ##__VA_ARGS__>;                              \
@@ -1770,6 +1788,13 @@ int decode_impl(uis_handle* h, const float* d_frames, const int64_t* offsets, in
 
 UIS_EXPORT int32_t uis_abi_version(void) { return UIS_ABI_VERSION; }
 UIS_EXPORT int32_t uis_numerics_version(void) { return UIS_NUMERICS_VERSION; }
+UIS_EXPORT uint32_t uis_build_flags(void) {
+  uint32_t f = 0;
+#if defined(UIS_WITH_COHORTS)
+  f |= UIS_BUILD_COHORTS;
+#endif
+  return f;
+}
 
 UIS_EXPORT int32_t uis_device_count(void) {
   int n = 0;
@@ -2279,7 +2304,7 @@ UIS_EXPORT int32_t uis_stream_begin(uis_handle* h, int32_t n_utt, const uis_deco
   ss.U = U; ss.B = B; ss.Kmax = Kmax; ss.S = S; ss.cap = max_frames;
   ss.have.assign(U, 0);
   DecodeState& st = ss.st;
-  st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = 1; st.tau = 1; st.flags = opts->flags;
+  st.U = U; st.B = B; st.Kmax = Kmax; st.S = S; st.L = 1; st.tau = 1; st.flags = opts->flags | (agent_flags_env() ? UIS_FLAG_AGENT_FLAGS : 0u);
   st.max_rows = U * B;
   // a push advances the session with ONE launch of the resident decode kernel where that kernel
   // applies (same conditions as uis_decode); UIS_FLAG_STEPWISE keeps the four kernels per step

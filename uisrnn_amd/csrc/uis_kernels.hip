@@ -1806,22 +1806,26 @@ __device__ __forceinline__ bool xcd_barrier(const DecodeState& st, int cluster, 
 // linear_mean1, + 3 behind linear_mean2) and a consumer wave polls the four words of its producers
 // -- one 16-byte load -- instead of everybody waiting for the slowest of 32 and for thread 0 to
 // tell the rest.  No atomic, no counter: a word has one writer.
-__device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint32_t phase) {
+__device__ __forceinline__ void rs_flag_publish(uint32_t* flags, int rank, uint32_t phase, bool agent_scope = false) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have reached L2
   __syncthreads();
   // Scope of the store.  The pollers are other workgroups of the SAME XCD (checked at run time,
   // HW_REG_XCC_ID), reading with sc1 (L1 bypass) from the L2 all 32 share.  An agent-scope store is
   // `global_store_dword sc1`: a scalar fabric write that also DROPS the line from that L2
-  // (MI355X_MICROARCH.md, "stores of each flavour") -- every poll of 32 workgroups would then go
+  // (MI355X_MICROARCH.md, "stores of each flavour") -- every poll of 32 workgroups then goes
   // beyond L2.  A plain store stays in the shared L2, which is the point of coherence that matters
   // here; that is outside what the HIP memory model promises for workgroup scope, hence the placement
-  // check, the give-up timer and the fallback path.  -DUIS_RS_FLAG_AGENT builds the
-  // by-the-book variant for A/B runs.
+  // check, the give-up timer and the fallback path.  The by-the-book variant is a
+  // run-time choice in one binary (round 6: UIS_FLAG_AGENT_FLAGS / UIS_AGENT_FLAGS=1; -DUIS_RS_FLAG_AGENT
+  // still forces it) and its cost is on record (profiles/r06_agent_flags_ab.txt): a decode step of
+  // k_decode_rs 25.7 against 18.7 us, of k_decode_resident 29.5 against 22.1 us -- so it stays opt-in.
 #if defined(UIS_RS_FLAG_AGENT)
-  if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  if (threadIdx.x == 0) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  agent_scope = true;
 #endif
+  if (threadIdx.x == 0) {
+    if (agent_scope) __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(flags + rank, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 }
 // The first look at the phase words, split in two so that the load can be requested early (from
 // inside the work a wave does between publishing and waiting) and examined late.
@@ -2543,7 +2547,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     if (flag_handoff) {
       // publish; the first half of the next step's select preparation (this workgroup's own LDS tables:
       // nobody else's data); then every wave waits for the four producers of its K-slice
-      rs_flag_publish(flags_c, rank, fphase);
+      rs_flag_publish(flags_c, rank, fphase, (st.flags & 0x20000u) != 0u);
       if (prep_next)
         select_fast_body<512, true, true, DP, 1>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
                                                  SelectNoHook(), first_step);
@@ -2586,7 +2590,7 @@ __global__ __launch_bounds__(512) void k_decode_resident(DevModel m, DecodeState
     RSTAMP(4);
     ++fphase;
     if (flag_handoff) {  // ... and the second half inside the next hand-off
-      rs_flag_publish(flags_c, rank, fphase);
+      rs_flag_publish(flags_c, rank, fphase, (st.flags & 0x20000u) != 0u);
       if (prep_next)
         select_fast_body<512, true, true, DP, 4>(m, st, upar ^ 1, cluster + ncl * rank, smem_raw, sink, ustep + 1, my_off0, my_off1,
                                                  SelectNoHook(), first_step);
@@ -4166,7 +4170,9 @@ __global__ __launch_bounds__(512) void k_decode_big(DevModel m, DecodeState st) 
   }
 }
 
+#if defined(UIS_WITH_COHORTS)
 #include "uis_decode_coh.hip"
+#endif
 
 // rnn_depth >= 2 in ONE launch (round 4): k_decode_big's grid, barriers and wave-per-row-tile stages with one
 // more pair of stages per upper layer.  A workgroup's 96 KB weight slot cannot hold W_hh of every layer and

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // for); the first look at the producers' words is requested from inside it, so that its round
     // trip is over when the wave gets there; then wait
     {
-      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 1u) & live_mask);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 1u) & live_mask, (st.flags & 0x20000u) != 0u);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
       bool peeked = false;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // publish; then the next step's MSEs of the clusters this step did not rewrite (every workgroup
     // its share of every utterance's; visible to all behind the step's last hand-off); then wait
     {
-      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 2u) & live_mask);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 2u) & live_mask, (st.flags & 0x20000u) != 0u);
       u32x4 pk = u32x4{0u, 0u, 0u, 0u};
       auto peek = [&]() { pk = rs_flag_peek4(rs_flags, (uint32_t)(16 * w)); };
       bool peeked = false;
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(512) void k_decode_rs(DevModel m, DecodeState st) {
     // publish; then the next step's candidate grid (this wave's own tables: nobody else's data); then
     // wait -- every wave, every step, for all 32 producers (rs_flag_wait_all)
     {
-      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 3u) & live_mask);
+      rs_flag_publish(flags_c, rank, (3u * (uint32_t)s + 3u) & live_mask, (st.flags & 0x20000u) != 0u);
       uint32_t pk = 0u;
       auto peek = [&]() { pk = rs_flag_peek_all(flags_c); };
       bool peeked = false;

@@ -276,9 +276,24 @@ class UISRNN:
           except _capi.HipLibraryError as inner:
             if inner.status != _capi.UIS_ERR_OOM or members is rest:
               raise
-            partial = [None] * len(members)   # (one utterance whose window does not fit the device at this capacity)
-            failed.extend(members)
-            first_err = first_err or inner
+            # One utterance's window does not fit the device at this capacity (the halving inside that call got down
+            # to a single utterance and still met UIS_ERR_OOM).  Which one is not known here: the others of this group
+            # would fit -- decode the members one by one and name only those that do not (round 6).
+            partial = []
+            for u in members:
+              try:
+                one = [None] if len(members) == 1 else self._decode_batch([sequences[u]], args, flags, device, decoder, cap_level)
+                one_err = inner if len(members) == 1 else None
+              except LookAheadWindowError as e1:
+                one, one_err = [None], e1
+              except _capi.HipLibraryError as e1:
+                if e1.status != _capi.UIS_ERR_OOM:
+                  raise
+                one, one_err = [None], e1
+              partial.extend(one)
+              if one_err is not None:
+                failed.append(u)
+                first_err = first_err or one_err
           for u, labels in zip(members, partial):
             results[u] = labels
         with self._state_lock:
