@@ -945,8 +945,9 @@ def test_no_option_value_the_reference_takes_is_refused(oracle_lib):
 
 @pytest.mark.parametrize('beam,look,tau', [(300, 1, 2), (10, 4, 2), (40, 3, 1)], ids=['beam300_L1', 'beam10_L4', 'beam40_L3'])
 def test_generic_window_path_at_a_real_model_size(beam, look, tau, oracle_lib):
-  """Round 6 (the verdict's item 6): the window machinery that decodes what the one-launch shapes do not take -- a
-  launch per sub-step, candidate lists in HBM (uis_stats.decode_kernel 'stepwise...') -- at the BASELINE model's size:
+  """Round 6 (the verdict's item 6): the window machinery -- the launch-per-sub-step form with candidate lists in HBM
+  (uis_stats.decode_kernel 'stepwise...', what decodes whatever the one-launch shapes do not take) and, where it
+  applies, the one-launch k_decode_big<WIN> -- at the BASELINE model's size:
   the checkpoint the reference trained (D 256 / H 512), 4 x 40 frames, beam 300 at look_ahead 1 and beam 10 / 40 at
   look_ahead 4 / 3, against the oracle bit for bit: labels, best scores, whole final beams (uisrnn/uisrnn.py:469-476,534-545)."""
   import os
@@ -957,12 +958,15 @@ def test_generic_window_path_at_a_real_model_size(beam, look, tau, oracle_lib):
   frames, offsets = oracle_lib.pack(seqs)
   cap = max(int(ref['max_clusters'].max()) + look - 1, 4)
   dec = _capi.Decoder(params)
-  out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, want_beam_scores=True)
-  assert out['status'] == 0 and out['stats']['decode_kernel'].startswith('stepwise'), out['stats']['decode_kernel']
-  for u in range(len(seqs)):
-    assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), u
-  assert np.array_equal(_bits(out['scores']), _bits(ref['scores']))
-  assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores']))
+  # the default dispatch (beam 300: launch per step, k_window + k_wt_*; look_ahead 3 / 4 at these beams: the one-launch
+  # window kernel's run-time instantiation) and the launch-per-sub-step window path demanded outright
+  for flags, want in ((0, 'stepwise' if look == 1 else 'k_decode_big<WIN>'), (_capi.UIS_FLAG_STEPWISE, 'stepwise')):
+    out = dec.decode(frames, offsets, beam, look, tau, max_clusters=cap, want_beam_scores=True, flags=flags)
+    assert out['status'] == 0 and out['stats']['decode_kernel'].startswith(want), (flags, out['stats']['decode_kernel'])
+    for u in range(len(seqs)):
+      assert np.array_equal(out['labels'][offsets[u]:offsets[u + 1]], ref['labels'][u]), (flags, u)
+    assert np.array_equal(_bits(out['scores']), _bits(ref['scores'])), flags
+    assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores'])), flags
 
 
 def test_a_refused_decode_leaves_no_stale_flags_behind(oracle_lib):
