@@ -265,6 +265,8 @@ def parse(argv=None):
   ap.add_argument('--frames', type=int, default=None)
   ap.add_argument('--beam_size', type=int, default=None)
   ap.add_argument('--look_ahead', type=int, default=None)
+  ap.add_argument('--rnn_hidden_size', type=int, default=None,
+                  help='hidden size of the model (not a BASELINE config: the closed-form tracker weights at that size)')
   ap.add_argument('--max_clusters', type=int, default=None, help='cluster cap the decode starts with (it doubles on overflow)')
   ap.add_argument('--rnn_depth', type=int, default=None,
                   help='GRU layers of the model (not a BASELINE config: the closed-form tracker weights at that depth)')
@@ -643,6 +645,9 @@ def main(argv=None):
     cfg['rnn_depth'] = args.rnn_depth
   if args.look_ahead is not None:
     cfg['look_ahead'] = args.look_ahead
+  if args.rnn_hidden_size is not None:
+    cfg['rnn_hidden_size'] = args.rnn_hidden_size
+    cfg['workload'] += ' [rnn_hidden_size {}]'.format(args.rnn_hidden_size)
   if args.max_clusters is not None:
     cfg['max_clusters'] = args.max_clusters
   if (args.utterances is not None or args.frames is not None or args.beam_size is not None or args.rnn_depth is not None or
@@ -806,7 +811,7 @@ def main(argv=None):
     extras = None
     if (not args.no_extra_configs and world == 1 and on_gpu and args.config == 1 and not args.ragged and
         args.utterances is None and args.frames is None and args.beam_size is None and args.rnn_depth is None and
-        args.look_ahead is None and args.max_clusters is None):
+        args.look_ahead is None and args.max_clusters is None and args.rnn_hidden_size is None):
       first = w.last
       w_cap = w.cap
       extras = []

@@ -132,6 +132,7 @@ struct uis_handle {
   std::vector<void*> model_allocs;
   double alpha = 1.0;
   int n_cu = 0;  // compute units of the device
+  int hid_map_seg = 0, hid_map_seg_p = 0, H_model = 0;  // (round 6) HidMap of this model's hidden axis; rnn_hidden_size as the caller gave it
   // the one-launch decode relies on observed, not promised, placement (workgroup b on XCD b % 8,
   // all 256 workgroups resident); when its own checks fail once, this handle stops using it
   bool inlaunch_failed = false, resident_off = false;
@@ -235,32 +236,42 @@ void pm_ring(uis_handle::Stream& ss, uint32_t seq, uint32_t type, uint32_t frame
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 
+// Where hidden unit j of the model sits in the padded hidden vector (round 6).  Padding a hidden size up to a kernel's
+// shape is exact only if every canonical K segment (uis_numerics.h: q = ceil(blocks / 8) k-blocks each) keeps its
+// blocks: appending zeros does that where q is the kernel's (q 1 -> 128, 2 -> 256, 4 -> 512), and for q = 3 (hidden sizes
+// 257 .. 384) the zeros go INSIDE: segment s's three blocks into the first three of the kernel's four
+// (unit j -> (j / 48) * 64 + j % 48), a zero block behind each.  fma(0, 0, acc) = acc: no bit moves, every sum keeps
+// its association, and the units in between stay exactly 0 (zero weights and biases: gates 1/2, candidate 0, h' = h / 2 = 0).
+struct HidMap {
+  int seg = 0, seg_p = 0;  // floats per canonical segment of the model / of the kernel's shape (0: identity)
+  int operator()(int j) const { return seg ? (j / seg) * seg_p + j % seg : j; }
+};
+
 // Re-pack a (n_out x K) row-major matrix (optionally 3 stacked gates of `rows_per_gate`
 // rows each, padded to `rows_per_gate_p`) into MFMA tile order:
 //   out[((tile*nKb + kb)*64 + lane)*4 + r] = W[tile*16 + (lane&15)][kb*16 + 4*(lane>>4) + r]
-std::vector<float> tile_weights(const float* W, int gates, int rows_per_gate, int rows_per_gate_p, int K, int Kp) {
+// rmap / kmap: where a row (within its gate) / a column goes in the padded layout (the hidden axis: HidMap).
+std::vector<float> tile_weights(const float* W, int gates, int rows_per_gate, int rows_per_gate_p, int K, int Kp,
+                                HidMap rmap = HidMap(), HidMap kmap = HidMap()) {
   const int Fp = gates * rows_per_gate_p;
   const int nKb = Kp / 16;
   std::vector<float> out((size_t)Fp * Kp, 0.0f);
-  for (int tile = 0; tile < Fp / 16; ++tile)
-    for (int kb = 0; kb < nKb; ++kb)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int fp = tile * 16 + (lane & 15);
-        const int g = fp / rows_per_gate_p, j = fp % rows_per_gate_p;
-        if (j >= rows_per_gate) continue;
-        const float* src = W + (size_t)(g * rows_per_gate + j) * K;
-        for (int r = 0; r < 4; ++r) {
-          const int k = kb * 16 + 4 * (lane >> 4) + r;
-          if (k < K) out[(((size_t)tile * nKb + kb) * 64 + lane) * 4 + r] = src[k];
-        }
+  for (int g = 0; g < gates; ++g)
+    for (int j = 0; j < rows_per_gate; ++j) {
+      const int fp = g * rows_per_gate_p + rmap(j), tile = fp / 16;
+      const float* src = W + (size_t)(g * rows_per_gate + j) * K;
+      for (int k = 0; k < K; ++k) {
+        const int kp = kmap(k), kb = kp / 16, q = (kp % 16) / 4, r = kp % 4;
+        out[(((size_t)tile * nKb + kb) * 64 + (q * 16 + fp % 16)) * 4 + r] = src[k];
       }
+    }
   return out;
 }
 
-std::vector<float> pad_bias(const float* b, int gates, int n, int np) {
+std::vector<float> pad_bias(const float* b, int gates, int n, int np, HidMap map = HidMap()) {
   std::vector<float> out((size_t)gates * np, 0.0f);
   for (int g = 0; g < gates; ++g)
-    for (int j = 0; j < n; ++j) out[(size_t)g * np + j] = b[(size_t)g * n + j];
+    for (int j = 0; j < n; ++j) out[(size_t)g * np + map(j)] = b[(size_t)g * n + j];
   return out;
 }
 
@@ -1887,12 +1898,23 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   // segments, empty segments add +0.0f either way; the MSE's sixteen tile accumulators take zero tiles):
   // hidden sizes 65 .. 256 and 385 .. 512, observation dims up to 256 and 385 .. 512 -- so those models
   // (rnn_depth 1) get the kernels' shapes instead of the launch-per-step path.
+  HidMap hmap;
   if (!getenv("UIS_PAD_TO_16_ONLY")) {  // (any rnn_depth: the upper layers' K axis is the hidden size too)
     const int qh = (m.Hp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT, qd = (m.Dp / 16 + UIS_KSPLIT - 1) / UIS_KSPLIT;
-    const int hp = (qh == 1 && H > 64) ? 128 : qh == 2 ? 256 : qh == 4 ? 512 : 0;  // (up to 64: k_decode_small's)
+    // (round 6) hidden sizes 257 .. 384 have segments of three k-blocks: into the 512 shape with a zero block behind
+    // every segment (HidMap) -- they ran a launch per step before (UIS_NO_SEGMENT_PADDING=1: still do)
+    const bool seg3 = qh == 3 && !getenv("UIS_NO_SEGMENT_PADDING");
+    const int hp = (qh == 1 && H > 64) ? 128 : qh == 2 ? 256 : (qh == 4 || seg3) ? 512 : 0;  // (up to 64: k_decode_small's)
     const int dp = m.Dp <= 128 ? 128 : qd == 2 ? 256 : qd == 4 ? 512 : 0;
-    if (hp && dp) { m.Hp = hp; m.Dp = dp; }
+    if (hp && dp) {
+      m.Hp = hp; m.Dp = dp;
+      if (seg3) {
+        hmap.seg = 3 * 16; hmap.seg_p = 4 * 16;
+        m.H = m.Hp;  // (the kernels' `unit < H` masks: the model's units are spread over the whole padded vector; the rest stay 0 by themselves)
+      }
+    }
   }
+  h->hid_map_seg = hmap.seg; h->hid_map_seg_p = hmap.seg_p; h->H_model = H;
   m.G = 3 * m.Hp;
   m.lp_stay = std::log(1.0 - d->transition_bias);  // np.log(1 - transition_bias), uisrnn.py:416
   m.lp_sw = std::log(d->transition_bias);
@@ -1901,21 +1923,21 @@ UIS_EXPORT int32_t uis_create(const uis_model_desc* d, int32_t device, uis_handl
   int rc;
   for (int l = 0; l < depth; ++l) {
     const int K = l == 0 ? D : H, Kp = l == 0 ? m.Dp : m.Hp;
-    if ((rc = upload(h, tile_weights(d->gru_weight_ih[l], 3, H, m.Hp, K, Kp), &m.wih[l]))) return bail(rc);
-    if ((rc = upload(h, tile_weights(d->gru_weight_hh[l], 3, H, m.Hp, H, m.Hp), &m.whh[l]))) return bail(rc);
-    if ((rc = upload(h, pad_bias(d->gru_bias_ih[l], 3, H, m.Hp), &m.bih[l]))) return bail(rc);
-    if ((rc = upload(h, pad_bias(d->gru_bias_hh[l], 3, H, m.Hp), &m.bhh[l]))) return bail(rc);
+    if ((rc = upload(h, tile_weights(d->gru_weight_ih[l], 3, H, m.Hp, K, Kp, hmap, l == 0 ? HidMap() : hmap), &m.wih[l]))) return bail(rc);
+    if ((rc = upload(h, tile_weights(d->gru_weight_hh[l], 3, H, m.Hp, H, m.Hp, hmap, hmap), &m.whh[l]))) return bail(rc);
+    if ((rc = upload(h, pad_bias(d->gru_bias_ih[l], 3, H, m.Hp, hmap), &m.bih[l]))) return bail(rc);
+    if ((rc = upload(h, pad_bias(d->gru_bias_hh[l], 3, H, m.Hp, hmap), &m.bhh[l]))) return bail(rc);
   }
-  if ((rc = upload(h, tile_weights(d->linear_mean1_weight, 1, H, m.Hp, H, m.Hp), &m.w1))) return bail(rc);
-  if ((rc = upload(h, pad_bias(d->linear_mean1_bias, 1, H, m.Hp), &m.b1))) return bail(rc);
-  if ((rc = upload(h, tile_weights(d->linear_mean2_weight, 1, D, m.Dp, H, m.Hp), &m.w2))) return bail(rc);
+  if ((rc = upload(h, tile_weights(d->linear_mean1_weight, 1, H, m.Hp, H, m.Hp, hmap, hmap), &m.w1))) return bail(rc);
+  if ((rc = upload(h, pad_bias(d->linear_mean1_bias, 1, H, m.Hp, hmap), &m.b1))) return bail(rc);
+  if ((rc = upload(h, tile_weights(d->linear_mean2_weight, 1, D, m.Dp, H, m.Hp, HidMap(), hmap), &m.w2))) return bail(rc);
   if ((rc = upload(h, pad_bias(d->linear_mean2_bias, 1, D, m.Dp), &m.b2))) return bail(rc);
   std::vector<float> wgt(m.Dp, 0.0f);
   for (int i = 0; i < D; ++i) wgt[i] = 1.0f / (2.0f * d->sigma2[i]);  // 1 / (2 * sigma2), uisrnn.py:414
   if ((rc = upload(h, wgt, &m.wgt))) return bail(rc);
   std::vector<float> hinit((size_t)depth * m.Hp, 0.0f);
   for (int l = 0; l < depth; ++l)
-    for (int j = 0; j < H; ++j) hinit[(size_t)l * m.Hp + j] = d->rnn_init_hidden[(size_t)l * H + j];
+    for (int j = 0; j < H; ++j) hinit[(size_t)l * m.Hp + hmap(j)] = d->rnn_init_hidden[(size_t)l * H + j];
   const float* d_hinit = nullptr;
   if ((rc = upload(h, hinit, &d_hinit))) return bail(rc);
   if ((rc = upload(h, std::vector<float>(m.Dp, 0.0f), &m.m0))) return bail(rc);
@@ -2023,7 +2045,9 @@ UIS_EXPORT int32_t uis_model_constants(uis_handle* h, float* m0_out, float* h1_o
   if (h1_out) {
     std::vector<float> tmp((size_t)m.depth * m.Hp);
     HIPCHK(hipMemcpy(tmp.data(), m.h1, tmp.size() * 4, hipMemcpyDeviceToHost));
-    for (int l = 0; l < m.depth; ++l) memcpy(h1_out + (size_t)l * m.H, tmp.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+    const HidMap hmap{h->hid_map_seg, h->hid_map_seg_p};
+    for (int l = 0; l < m.depth; ++l)
+      for (int j = 0; j < h->H_model; ++j) h1_out[(size_t)l * h->H_model + j] = tmp[(size_t)l * m.Hp + hmap(j)];
   }
   return UIS_OK;
 }
@@ -2035,7 +2059,9 @@ UIS_EXPORT int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in
   const size_t hid_elems = (size_t)m.depth * m.Hp;
   std::vector<float> xp(m.Dp, 0.0f), hp(hid_elems, 0.0f), mo(m.Dp), ho(hid_elems);
   memcpy(xp.data(), x, (size_t)m.D * 4);
-  for (int l = 0; l < m.depth; ++l) memcpy(hp.data() + (size_t)l * m.Hp, h_in + (size_t)l * m.H, (size_t)m.H * 4);
+  const HidMap hmap{h->hid_map_seg, h->hid_map_seg_p};
+  for (int l = 0; l < m.depth; ++l)
+    for (int j = 0; j < h->H_model; ++j) hp[(size_t)l * m.Hp + hmap(j)] = h_in[(size_t)l * h->H_model + j];
   float *d_x = nullptr, *d_h = nullptr, *d_m = nullptr, *d_o = nullptr;
   Scratch tmp;
   int rc;
@@ -2048,7 +2074,8 @@ UIS_EXPORT int32_t uis_rnn_step(uis_handle* h, const float* x, const float* h_in
   HIPCHK(hipMemcpy(mo.data(), d_m, mo.size() * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(ho.data(), d_o, ho.size() * 4, hipMemcpyDeviceToHost));
   memcpy(mean_out, mo.data(), (size_t)m.D * 4);
-  for (int l = 0; l < m.depth; ++l) memcpy(h_out + (size_t)l * m.H, ho.data() + (size_t)l * m.Hp, (size_t)m.H * 4);
+  for (int l = 0; l < m.depth; ++l)
+    for (int j = 0; j < h->H_model; ++j) h_out[(size_t)l * h->H_model + j] = ho[(size_t)l * m.Hp + hmap(j)];
   return UIS_OK;
 }
 
