@@ -193,10 +193,11 @@ typedef struct uis_stats {
   int32_t n_overflow;                 /* utterances that hit UIS_ERR_CLUSTER_CAP    */
   int32_t n_streams;                  /* utterance groups used                       */
   int32_t decode_kernel;              /* UIS_DK_*: the kernel family that ran the decode steps */
-  int32_t decode_launches;            /* launches of the one-launch decode kernel in this decode: 1, or 2 when the
-                                         list came from host memory and its later frames travelled behind the first
-                                         launch (uis_decode / uis_decode_f64, equal-length utterances, k_decode_rs /
-                                         k_decode_big<WS>; UIS_NO_SPLIT=1 keeps 1); 0 on the launch-per-step path */
+  int32_t decode_launches;            /* launches of the one-launch decode kernel in this decode: 1, or 2 and more (2 - 4 by
+                                         the library's own slice schedule, up to 8 with UIS_SPLIT_FRAMES) when the list came
+                                         from host memory and its later frames travelled behind the earlier launches
+                                         (uis_decode / uis_decode_f64: k_decode_rs, k_decode_big<WS>, k_decode_resident with
+                                         one utterance per workgroup; UIS_NO_SPLIT=1 keeps 1); 0 on the launch-per-step path */
 } uis_stats;
 
 /* uis_stats.decode_kernel: which kernels ran the decode steps (the dispatch rule lives in the

@@ -523,6 +523,8 @@ class Decoder:
     self._check(rc, 'uis_stream_begin')
     self._stream_n = int(n_utt)
     self._stream_have = np.zeros(int(n_utt), dtype=np.int64)
+    self._stream_counts = np.zeros(int(n_utt), dtype=np.int32)   # (reused by every push: its pointer is bound once)
+    self._stream_counts_ptr = self._stream_counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
 
   def stream_push(self, chunks):
     """chunks: one [n_u, D] array (or None / empty) per utterance: its new frames -- or ONE
@@ -542,19 +544,32 @@ class Decoder:
       self._check(rc, 'uis_stream_push')
       self._stream_have += counts
       return
-    parts, counts = [], np.zeros(self._stream_n, dtype=np.int32)
-    for u, chunk in enumerate(chunks):
-      if chunk is None or len(chunk) == 0:
-        continue
-      arr = np.ascontiguousarray(chunk, dtype=np.float32)
-      if arr.ndim != 2 or arr.shape[1] != dim:
-        raise ValueError('chunk does not match observation_dim')
-      parts.append(arr)
-      counts[u] = arr.shape[0]
-    frames = np.concatenate(parts) if parts else np.zeros((0, dim), dtype=np.float32)
-    rc = self._lib.uis_stream_push(
-        self._handle, frames.ctypes.data_as(_fp) if len(frames) else None,
-        counts.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    # (round 6) the list form without per-chunk numpy work: ONE concatenate over the caller's arrays (it checks that
+    # they are 2-dimensional and of one width), one cast, the counts written into a buffer whose ctypes pointer was
+    # made when the session opened -- a one-frame push of 64 utterances spent 56 us here, against 44 us in the library
+    counts = self._stream_counts
+    try:
+      counts[:] = [c.shape[0] for c in chunks]   # (a None entry has no shape: the careful path below)
+      frames64 = np.concatenate(chunks)
+      if frames64.ndim != 2 or frames64.dtype != np.float64 or len({c.dtype for c in chunks}) != 1:
+        raise TypeError
+    except (TypeError, ValueError, AttributeError, IndexError):
+      # None / empty / non-array / non-float64 entries: the careful path, chunk by chunk
+      parts = []
+      counts[:] = 0
+      for u, chunk in enumerate(chunks):
+        if chunk is None or len(chunk) == 0:
+          continue
+        arr = np.ascontiguousarray(chunk, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] != dim:
+          raise ValueError('chunk does not match observation_dim')
+        parts.append(arr)
+        counts[u] = arr.shape[0]
+      frames64 = np.concatenate(parts) if parts else np.zeros((0, dim), dtype=np.float32)
+    if frames64.shape[0] and frames64.shape[1] != dim:
+      raise ValueError('chunk does not match observation_dim')
+    frames = frames64.astype(np.float32, copy=False)
+    rc = self._lib.uis_stream_push(self._handle, frames.ctypes.data_as(_fp) if len(frames) else None, self._stream_counts_ptr)
     self._check(rc, 'uis_stream_push')
     self._stream_have += counts
 

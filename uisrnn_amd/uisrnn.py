@@ -482,9 +482,25 @@ class OnlineSession:
       if chunks.dtype != float:
         raise TypeError('test_sequence should be a numpy array of float type.')
     else:
-      for chunk in chunks:
-        if chunk is not None and len(chunk):
-          self._model._check_sequence(np.asarray(chunk))
+      # (round 6: one pass over the dtypes -- the reference's TypeError for anything but float64, uisrnn.py:511-513 --
+      # the shapes are checked by the one concatenate in _capi.stream_push; the full per-chunk check of the
+      # reference's messages only when something is off)
+      try:
+        plain = {c.dtype for c in chunks} == {np.dtype(float)}
+      except AttributeError:
+        plain = False
+      if not plain:
+        for chunk in chunks:
+          if chunk is not None and len(chunk):
+            self._model._check_sequence(np.asarray(chunk))
+      try:
+        self._decoder.stream_push(chunks)
+      except ValueError:
+        for chunk in chunks:   # (which chunk, in the reference's words)
+          if chunk is not None and len(chunk):
+            self._model._check_sequence(np.asarray(chunk))
+        raise
+      return
     self._decoder.stream_push(chunks)
 
   def labels(self):
