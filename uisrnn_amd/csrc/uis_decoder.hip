@@ -1054,10 +1054,15 @@ int decode_once(uis_handle* h, const float* d_frames, const int64_t* offsets, in
       // ~45 GB/s (a quarter more through the float64 cast); slice k + 1 = what travels during 0.9 of launch k, and a
       // last slice below a quarter of the utterance is not worth a launch of its own.
       const double step_us = 11.7 + 0.108 * U, frame_us = (double)U * m.D * 4.0 / 45e3 * (h->src64 ? 1.25 : 1.0);
+      // (round 6) ... and no further cut once everything that is left travels within the launch in front of it plus two
+      // relaunches' worth (0.3 ms): configs[1] got the cuts {32, 326} and paid a second relaunch for frames that had
+      // arrived five milliseconds earlier -- 1.607 M frames/s through the float64 list against 1.629 M with the one cut
+      // at 32 (profiles/r06_f64_leg_knobs.txt); the configs[3] share keeps its slices (a launch there lasts 4 ms, the rest 28)
       int64_t prev = 0, cur = 32;
       while (cur <= uniN - 32 && (int)cuts.size() < 6) {
         if (!cuts.empty() && uniN - cur < uniN / 4) break;
         cuts.push_back(cur);
+        if ((double)(uniN - cur) * frame_us <= (double)(cur - prev) * step_us + 300.0) break;
         const int64_t next = cur + std::max<int64_t>(32, (int64_t)(0.9 * (double)(cur - prev) * step_us / frame_us));
         prev = cur; cur = next;
       }
