@@ -202,6 +202,31 @@ def test_in_between_sizes_take_the_one_launch_kernels(dim, hidden, oracle_lib):
   assert np.array_equal(_bits(mean), _bits(mean_o)) and np.array_equal(_bits(hout), _bits(hout_o))
 
 
+@pytest.mark.parametrize('hidden', [320, 384])
+def test_embedded_hidden_sizes_on_the_shape_class_kernels(hidden, oracle_lib):
+  """rnn_hidden_size 257 .. 384 embedded in the 512 shape (round 6) with observation_dim 256, beam 10 and the default
+  cluster cap: the model then looks unpadded to the dispatch (every unit mask open) and takes the compile-time shape
+  classes of BASELINE configs[1] / [3] -- k_decode_rs's class for 40 utterances, k_decode_big<WS>'s for 300 -- and the
+  launch-per-step path under UIS_FLAG_STEPWISE: all three equal the oracle, bit for bit."""
+  from uisrnn_amd import weights
+  params = weights.init_params(256, hidden, 1, sigma2=0.02, transition_bias=0.05, crp_alpha=1.0, seed=hidden)
+  params['rnn_init_hidden'] = (0.2 * np.random.default_rng(3).standard_normal((1, hidden))).astype(np.float32)
+  dec = _capi.Decoder(params)
+  for n_utt, want in ((40, 'k_decode_rs'), (300, 'k_decode_big<WS>')):
+    lens = [6 + (5 * u) % 19 for u in range(n_utt)]
+    seqs, _ = synth.make_utterances(19_000 + hidden + n_utt, n_utt, lens, 256)
+    frames, offsets = oracle_lib.pack(seqs)
+    ref = oracle_lib.decode(params, seqs, 10, 1, 2, n_threads=8)
+    cap = max(int(ref['max_clusters'].max()), 16)
+    for flags in (0, _capi.UIS_FLAG_STEPWISE):
+      out = dec.decode(frames, offsets, 10, 1, 2, max_clusters=cap, want_beam_scores=True, flags=flags)
+      assert out['status'] == 0
+      if cap == 16 and not flags:
+        assert out['stats']['decode_kernel'] == want, out['stats']['decode_kernel']
+      assert np.array_equal(out['labels'], np.concatenate(ref['labels'])), (n_utt, flags)
+      assert np.array_equal(_bits(out['beam_scores']), _bits(ref['beam_scores'])), (n_utt, flags)
+
+
 def test_tracker_d256_bit_exact(oracle_lib):
   params = synth.tracker_params(256, 512, 1, seed=0)
   seqs, _ = synth.make_utterances(2000, 12, [50, 80, 31, 64, 17, 100, 1, 2, 77,

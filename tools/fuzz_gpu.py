@@ -26,7 +26,7 @@ def draw(rng):
   big = rng.random() < 0.45  # shapes of the one-launch kernels
   if big:
     dim = int(rng.choice([30, 120, 128, 250, 256, 400, 512]))
-    hid = int(rng.choice([70, 100, 128, 130, 200, 250, 256, 390, 500, 512]))   # (65 .. 256 / 385 .. 512: padded up to the kernels' shapes)
+    hid = int(rng.choice([70, 100, 128, 130, 200, 250, 256, 257, 300, 320, 370, 384, 390, 500, 512]))   # (65 .. 512: padded up to the kernels' shapes -- 257 .. 384 embedded, round 6)
     depth = 1
     look = int(rng.choice([1, 1, 1, 2, 2, 3]))   # look_ahead >= 2: k_decode_big<WIN>
     beam = int(rng.integers(1, 33))   # up to the wide class of the single-wave select
@@ -82,7 +82,8 @@ def main():
     tag = (dim, hid, depth, beam, look, tau, lengths, seed)
     flag_sets = [0, _capi.UIS_FLAG_STEPWISE, _capi.UIS_FLAG_SMALL_TILES, _capi.UIS_FLAG_OWNER_SELECT,
                  _capi.UIS_FLAG_REPLICATED_SELECT,  # every class of k_decode_rs, also where it is not the default
-                 _capi.UIS_FLAG_COHORTS,            # k_decode_coh (two cohorts in flight) where k_decode_big<WS> is the default
+                 _capi.UIS_FLAG_COHORTS,            # k_decode_coh (two cohorts in flight) where k_decode_big<WS> is the default (-DUIS_WITH_COHORTS builds; else ignored)
+                 _capi.UIS_FLAG_AGENT_FLAGS,        # (round 6) the hand-offs' phase words at agent scope
 
                  int(rng.choice([_capi.UIS_FLAG_NO_DEDUP, _capi.UIS_FLAG_GENERIC_SELECT | _capi.UIS_FLAG_STEPWISE,
                                  _capi.UIS_FLAG_GRAPH | _capi.UIS_FLAG_STEPWISE]))]
