@@ -304,6 +304,20 @@ def case_tracker_long(uisrnn):
   return params, seqs, runs, False
 
 
+@case('tracker_d64_h300')
+def case_tracker_h300(uisrnn):
+  """rnn_hidden_size 300 (19 k-blocks: canonical segments of THREE): the size class the library embeds in its
+  512-wide kernels with a zero k-block behind every segment (round 6, uis_decoder.hip: HidMap).  Recorded from the
+  reference so that the embedding is pinned against google/uis-rnn itself, not only against the oracle.
+  Parameters and utterances are regenerated from seeds."""
+  from uisrnn_amd import synth  # pylint: disable=import-outside-toplevel
+  params = synth.tracker_params(64, 300, 1, seed=3)
+  seqs, _ = synth.make_utterances(1200, 3, [40, 25, 33], 64)
+  runs = [dict(beam_size=10, look_ahead=1, test_iteration=2),
+          dict(beam_size=5, look_ahead=2, test_iteration=1)]
+  return params, seqs, runs, False
+
+
 CHECKPOINT_CASE = 'd20_h24_depth3'  # depth 3, non-zero rnn_init_hidden
 
 

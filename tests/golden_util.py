@@ -12,6 +12,9 @@ SEEDED_CASES = {
                          lengths=[40, 60, 25]),
     'tracker_d256_long': dict(dim=256, hid=512, depth=1, seed=0, utt_seed=1100,
                               lengths=[250]),
+    # round 6: hidden size 300 -- embedded in the 512-wide kernels (segments of three k-blocks)
+    'tracker_d64_h300': dict(dim=64, hid=300, depth=1, seed=3, utt_seed=1200,
+                             lengths=[40, 25, 33]),
 }
 
 

@@ -73,7 +73,7 @@ def test_same_numerics_version(oracle_lib):
 def test_rnn_step_bit_exact(oracle_lib):
   """CoreRNN.forward (uisrnn.py:45-52): kernels vs oracle, and vs the reference's outputs."""
   for name in ('tiny_d16', 'toy_d2_depth2', 'd32_lookahead3', 'd20_h24_depth3',
-               'tracker_d256'):
+               'tracker_d256', 'tracker_d64_h300'):   # (the last: hidden size 300, embedded in the 512-wide kernels: round 6)
     case = golden_util.load_case(name)
     dec = _capi.Decoder(case['params'])
     unit = case['unit']
@@ -92,7 +92,7 @@ def test_rnn_step_bit_exact(oracle_lib):
 
 
 @pytest.mark.parametrize('name', ['tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
-                                  'd20_h24_depth3', 'tracker_d256_long'])
+                                  'd20_h24_depth3', 'tracker_d256_long', 'tracker_d64_h300'])
 def test_golden_cases_bit_exact(name, oracle_lib):
   case = golden_util.load_case(name)
   dec = _capi.Decoder(case['params'])

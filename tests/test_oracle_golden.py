@@ -17,7 +17,7 @@ CASES = golden_util.case_names()
 
 def test_fixtures_present():
   assert set(CASES) >= {'tiny_d16', 'toy_d2_depth2', 'd32_lookahead3',
-                        'd20_h24_depth3', 'tracker_d256', 'tracker_d256_long'}
+                        'd20_h24_depth3', 'tracker_d256', 'tracker_d256_long', 'tracker_d64_h300'}
 
 
 @pytest.mark.parametrize('name', CASES)
